@@ -1,0 +1,341 @@
+"""CPU oracle for the SG x microfacet render path.  TEST INFRASTRUCTURE ONLY.
+
+This module is the *checker* for the HIP kernels: only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+it.  The product package (``inverserenderingofindoorscene_amd``) never does and
+has no CPU compute path.
+
+It is an independent restatement, in plain ``torch`` CPU ops, of the algorithm
+in the reference (file:line are relative to ``/root/reference``):
+
+  * direction table / quadrature weights ........ models.py:353-363, 437-452
+  * view vectors ................................. models.py:415-430
+  * SG pre-map ``tan(pi/2 * 0.999 * x)`` ......... models.py:396-400
+  * SG -> per-pixel hemisphere image ............. models.py:371-389
+  * pooling, local frame, GGX/Fresnel/Smith ...... models.py:461-509
+  * quadrature over the J directions ............. models.py:511-520
+  * 1- and 2-unknown scale regressions ........... models.py:7-21, 23-84
+  * pooled masks, masked-L2 render loss .......... wrapperBRDFLight.py:170-171,192,203-207
+  * log-L2 reconstruction loss ................... wrapperBRDFLight.py:172-188
+
+The restatement is structured differently from the reference (a loop over lobes
+and over images with [pixels, J] working sets instead of 7-D broadcast
+temporaries) so it runs at full size in bounded memory, and it is dtype-generic:
+``torch.float64`` is the arbiter ("truth"), ``torch.float32`` is the CPU "port"
+that ``bench.py`` times.  Gradients come from ``torch.autograd`` on this code,
+i.e. they are independent of the hand-derived backward kernels.
+
+Pinning: the reference has no tests / golden vectors for this path
+(SURVEY.md section 4), so the oracle is pinned against outputs of the reference
+itself, imported from /root/reference in the authoring container
+(``oracle/make_golden.py`` -> ``tests/golden/*.npz``, ``tests/test_oracle_vs_golden.py``
+and, when /root/reference is mounted, ``tests/test_oracle_vs_reference.py``).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+__all__ = [
+    "direction_table",
+    "view_vectors",
+    "premap",
+    "sg_to_env",
+    "output2env",
+    "pool_brdf",
+    "render_env",
+    "render_from_sg",
+    "lsregress",
+    "lsregress_diffspec",
+    "render_loss",
+    "recon_loss",
+]
+
+
+# --------------------------------------------------------------------------- #
+# constant tables                                                              #
+# --------------------------------------------------------------------------- #
+def direction_table(env_height: int = 8, env_width: int = 16) -> Tuple[np.ndarray, np.ndarray]:
+    """Hemisphere directions and quadrature weights, float32 like the reference.
+
+    Follows models.py:353-363 (output2env) and models.py:437-452 (renderingLayer):
+    azimuth ``Az_a = ((a+.5)/ew - .5) * 2pi``, elevation ``El_e = ((e+.5)/eh) * pi/2``,
+    ``l = (sin El cos Az, sin El sin Az, cos El)``, flat index ``j = e*ew + a``,
+    ``omega_j = sin El * pi^2 / (ew*eh)``.  Computed in float64, stored float32.
+
+    Returns ``(ls[J,3] float32, omega[J] float32)``.
+    """
+    az = ((np.arange(env_width, dtype=np.float64) + 0.5) / env_width - 0.5) * 2.0 * np.pi
+    el = ((np.arange(env_height, dtype=np.float64) + 0.5) / env_height) * np.pi / 2.0
+    az_g = np.tile(az[None, :], (env_height, 1)).reshape(-1)
+    el_g = np.tile(el[:, None], (1, env_width)).reshape(-1)
+    ls = np.stack([np.sin(el_g) * np.cos(az_g), np.sin(el_g) * np.sin(az_g), np.cos(el_g)], axis=1)
+    omega = np.sin(el_g) * np.pi * np.pi / env_width / env_height
+    return ls.astype(np.float32), omega.astype(np.float32)
+
+
+def view_vectors(im_width: int, im_height: int, fov_deg: float = 57.0,
+                 camera_pos: Sequence[float] = (0.0, 0.0, 0.0)) -> np.ndarray:
+    """Per-pixel unit view vectors ``v[3,R,C]`` float32 (models.py:415-430).
+
+    The pixel grid is built in float64 and cast to float32 (``pCoord``); the
+    subtraction from the float32 camera position and the normalisation
+    ``v / sqrt(max(|v|^2, 1e-12))`` are float32 operations in the reference.
+    """
+    fov = fov_deg / 180.0 * np.pi
+    x_range = 1.0 * np.tan(fov / 2.0)
+    y_range = float(im_height) / float(im_width) * x_range
+    xs = np.linspace(-x_range, x_range, im_width)
+    ys = np.linspace(-y_range, y_range, im_height)[::-1]
+    p = np.empty((3, im_height, im_width), dtype=np.float32)
+    p[0] = xs[None, :].astype(np.float32)
+    p[1] = ys[:, None].astype(np.float32)
+    p[2] = np.float32(-1.0)
+    cam = np.asarray(camera_pos, dtype=np.float32).reshape(3, 1, 1)
+    v = cam - p
+    nrm = np.sqrt(np.maximum(np.sum(v * v, axis=0), np.float32(1e-12)))
+    return (v / nrm[None]).astype(np.float32)
+
+
+# --------------------------------------------------------------------------- #
+# SG -> environment image                                                      #
+# --------------------------------------------------------------------------- #
+def premap(x: torch.Tensor) -> torch.Tensor:
+    """``tan(pi/2 * (0.999 * x))`` with the reference's op order (models.py:396-400)."""
+    return torch.tan(math.pi / 2.0 * (0.999 * x))
+
+
+def sg_to_env(axis: torch.Tensor, lamb: torch.Tensor, weight: torch.Tensor,
+              env_height: int = 8, env_width: int = 16) -> torch.Tensor:
+    """``env[b,c,r,cc,e,a] = sum_k w[b,k,c,r,cc] * exp(lam[b,k,r,cc] * (a_k . l_j - 1))``.
+
+    models.py:371-389.  ``axis [bn,K,3,R,C]``, ``lamb [bn,K,R,C]`` (post-tan),
+    ``weight [bn,3K,R,C]`` with channel ``k*3 + rgb`` (models.py:378).
+    """
+    bn, K, _, R, C = axis.shape
+    ls_np, _ = direction_table(env_height, env_width)
+    ls = torch.from_numpy(ls_np).to(axis.dtype)            # [J,3]
+    J = ls.shape[0]
+    w = weight.reshape(bn, K, 3, R * C)
+    lam = lamb.reshape(bn, K, R * C)
+    ax = axis.reshape(bn, K, 3, R * C)
+    out = []
+    for b in range(bn):
+        acc = None
+        for k in range(K):
+            a = ax[b, k]                                    # [3,P]
+            dot = (a[0, :, None] * ls[None, :, 0] + a[1, :, None] * ls[None, :, 1]) + a[2, :, None] * ls[None, :, 2]
+            e = torch.exp(lam[b, k][:, None] * (dot - 1.0))  # [P,J]
+            term = w[b, k][:, :, None] * e[None]            # [3,P,J]
+            acc = term if acc is None else acc + term
+        out.append(acc)
+    env = torch.stack(out, 0)
+    return env.reshape(bn, 3, R, C, env_height, env_width)
+
+
+def output2env(axis_orig: torch.Tensor, lamb_orig: torch.Tensor, weight_orig: torch.Tensor,
+               env_height: int = 8, env_width: int = 16):
+    """models.py:391-404: returns ``(env, axis, lamb_tan, weight_tan)``."""
+    weight = premap(weight_orig)
+    lamb = premap(lamb_orig)
+    env = sg_to_env(axis_orig, lamb, weight, env_height, env_width)
+    return env, axis_orig, lamb, weight
+
+
+# --------------------------------------------------------------------------- #
+# microfacet quadrature                                                        #
+# --------------------------------------------------------------------------- #
+def pool_brdf(albedo, normal, rough, R: int, C: int):
+    """Average-pool the BRDF maps to the env grid and renormalise the normal.
+
+    models.py:465-469.  Note the *two-sided* clamp ``[1e-6, 1]`` on ``|N|^2``.
+    """
+    A = F.adaptive_avg_pool2d(albedo, (R, C))
+    N = F.adaptive_avg_pool2d(normal, (R, C))
+    N = N / torch.sqrt(torch.clamp((N * N).sum(1, keepdim=True), 1e-6, 1.0))
+    rho = F.adaptive_avg_pool2d(rough, (R, C))
+    return A, N, rho
+
+
+def _unit(x: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
+    """``F.normalize`` semantics: ``x / max(||x||_2, eps)`` along dim 1.
+
+    ``vector_norm`` (not ``sqrt(sum)``) so that autograd uses the same zero-subgradient at
+    ``x == 0`` as the library call the reference makes (models.py:478-479)."""
+    n = torch.linalg.vector_norm(x, dim=1, keepdim=True)
+    return x / torch.clamp(n, min=eps)
+
+
+def render_env(albedo, normal, rough, env, fov_deg: float = 57.0, F0: float = 0.05,
+               camera_pos: Sequence[float] = (0.0, 0.0, 0.0)):
+    """Diffuse and specular images from BRDF maps and a per-pixel env image.
+
+    models.py:461-522.  ``env [bn,3,R,C,eh,ew]``; the constructor's
+    ``imHeight,imWidth`` are the env grid ``R,C`` (trainLight.py:111-113).
+    Returns ``(colorDiffuse[bn,3,R,C], colorSpec[bn,3,R,C])``.
+    """
+    bn, _, R, C, eh, ew = env.shape
+    dt = env.dtype
+    ls_np, om_np = direction_table(eh, ew)
+    ls = torch.from_numpy(ls_np).to(dt)                      # [J,3]
+    om = torch.from_numpy(om_np).to(dt)                      # [J]
+    v = torch.from_numpy(view_vectors(C, R, fov_deg, camera_pos)).to(dt)[None]   # [1,3,R,C]
+    J = eh * ew
+
+    A, N, rho = pool_brdf(albedo, normal, rough, R, C)
+    up = torch.zeros(1, 3, 1, 1, dtype=dt)
+    up[0, 1] = 1.0
+    camy = _unit(up - (up * N).sum(1, keepdim=True) * N)
+    camx = -_unit(torch.cross(camy, N, dim=1))
+
+    r = (rho + 1.0) / 2.0
+    kk = (r + 1.0) * (r + 1.0) / 8.0
+    alpha = r * r
+    alpha2 = alpha * alpha                                   # [bn,1,R,C]
+    ndv = torch.clamp((N * v).sum(1, keepdim=True), 0.0, 1.0)
+
+    envf = env.reshape(bn, 3, R, C, J)
+    diff = torch.zeros(bn, 3, R, C, dtype=dt)
+    spec = torch.zeros(bn, 3, R, C, dtype=dt)
+    for j in range(J):
+        l = ls[j, 0] * camx + ls[j, 1] * camy + ls[j, 2] * N             # [bn,3,R,C]
+        h = (v + l) / 2.0
+        h = h / torch.sqrt(torch.clamp((h * h).sum(1, keepdim=True), min=1e-6))
+        vdh = (v * h).sum(1, keepdim=True)
+        fres = F0 + (1.0 - F0) * torch.pow(torch.full_like(vdh, 2.0), (-5.55472 * vdh - 6.98316) * vdh)
+        ndh = torch.clamp((N * h).sum(1, keepdim=True), 0.0, 1.0)
+        ndl = torch.clamp((N * l).sum(1, keepdim=True), 0.0, 1.0)
+        nom0 = ndh * ndh * (alpha2 - 1.0) + 1.0
+        nom1 = ndv * (1.0 - kk) + kk
+        nom2 = ndl * (1.0 - kk) + kk
+        nom = torch.clamp(4.0 * math.pi * nom0 * nom0 * nom1 * nom2, 1e-6, 4.0 * math.pi)
+        sp = alpha2 * fres / nom
+        e = envf[..., j]
+        diff = diff + (A / math.pi) * ndl * e * om[j]
+        spec = spec + sp * ndl * e * om[j]
+    return diff, spec
+
+
+def render_from_sg(albedo, normal, rough, axis_orig, lamb_orig, weight_orig,
+                   env_height: int = 8, env_width: int = 16, fov_deg: float = 57.0, F0: float = 0.05,
+                   camera_pos: Sequence[float] = (0.0, 0.0, 0.0)):
+    """output2env followed by forwardEnv: ``(env, diffuse, spec)``."""
+    env, _, _, _ = output2env(axis_orig, lamb_orig, weight_orig, env_height, env_width)
+    d, s = render_env(albedo, normal, rough, env, fov_deg, F0, camera_pos)
+    return env, d, s
+
+
+# --------------------------------------------------------------------------- #
+# scale-invariant regressions and losses                                       #
+# --------------------------------------------------------------------------- #
+def lsregress(pred, gt, origin):
+    """One-unknown scale: ``origin * clamp(<pred,gt>/max(<pred,pred>,1e-5), 1e-3, 1e3)`` per image.
+
+    models.py:7-21.  The coefficient is a constant in backward (``.detach()``).
+    """
+    nb = pred.shape[0]
+    p = pred.reshape(nb, -1)
+    g = gt.reshape(nb, -1)
+    coef = ((p * g).sum(1) / torch.clamp((p * p).sum(1), min=1e-5)).detach()
+    coef = torch.clamp(coef, 0.001, 1000.0)
+    return origin * coef.reshape([nb] + [1] * (origin.dim() - 1))
+
+
+def lsregress_diffspec(diff, spec, im_orig, diff_orig, spec_orig):
+    """Two-unknown (diffuse, specular) scale regression (models.py:23-84)."""
+    nb, nc, nh, nw = diff.shape
+    m = (im_orig < 0.9).to(diff.dtype)
+    d = (diff * m).reshape(nb, -1)
+    s = (spec * m).reshape(nb, -1)
+    im = (im_orig * m).reshape(nb, -1)
+    a11 = (d * d).sum(1)
+    a22 = (s * s).sum(1)
+    a12 = (d * s).sum(1)
+    det = a11 * a22 - a12 * a12
+    b1 = (d * im).sum(1)
+    b2 = (s * im).sum(1)
+    c1 = (b1 * a22 - b2 * a12) / torch.clamp(det, min=1e-2)
+    c2 = (-b1 * a12 + a11 * b2) / torch.clamp(det, min=1e-2)
+    c3 = torch.clamp(b1 / torch.clamp(a11, min=1e-5), 0.001, 1000.0)
+    use2 = ((det / (nc * nh * nw)).detach() > 1e-2).to(diff.dtype)
+    cd = use2 * c1 + (1.0 - use2) * c3
+    cs = use2 * c2
+    cd = torch.clamp(cd, 0.0, 1000.0).reshape(nb, 1, 1, 1)
+    cs = torch.clamp(cs, 0.0, 1000.0).reshape(nb, 1, 1, 1)
+    d_sc = cd * diff_orig
+    s_sc = cs * spec_orig
+    ren = torch.clamp(d_sc + s_sc, 0.0, 1.0).reshape(nb, -1)
+    imf = im_orig.reshape(nb, -1)
+    cim = ((ren * imf).sum(1) / torch.clamp((ren * ren).sum(1), min=1e-5)).detach()
+    cim = torch.clamp(cim, 0.001, 1000.0).reshape(nb, 1, 1, 1)
+    return cim * d_sc, cim * s_sc
+
+
+def render_loss(diffuse, spec, im, seg, R: int, C: int, reduce: bool = True):
+    """Render loss of wrapperBRDFLight.py:170-171,192,197-207.
+
+    ``im [bn,3,imH,imW]``, ``seg [bn,1,imH,imW]`` (``segBRDFBatch``).  Returns
+    ``(renderErr, renderedImPred, num, den)`` with ``renderErr = num/den/3`` and
+    ``den = max(sum(segSmall), 1e-5)``; with ``reduce=False`` only the
+    numerator / un-clamped denominator pair is meaningful (multi-GPU shards sum
+    those).
+    """
+    im_s = F.adaptive_avg_pool2d(im, (R, C))
+    seg_s = F.adaptive_avg_pool2d(seg, (R, C))
+    d_sc, s_sc = lsregress_diffspec(diffuse.detach(), spec.detach(), im_s, diffuse, spec)
+    ren = torch.clamp(d_sc + s_sc, 0.0, 1.0)
+    num = ((ren - im_s) * (ren - im_s) * seg_s).sum()
+    den_raw = seg_s.sum()
+    den = torch.clamp(den_raw.detach(), min=1e-5)
+    err = num / den / 3.0
+    return err, ren, num, den_raw
+
+
+def recon_loss(env_pred, env_gt, seg, env_ind, R: int, C: int, offset: float = 1.0):
+    """Log-L2 env reconstruction loss (wrapperBRDFLight.py:171-188).
+
+    ``seg [bn,1,imH,imW]``, ``env_ind [bn,1,1,1]``.  Returns
+    ``(reconstErr, envScaled, num, den_raw)``.
+    """
+    bn, _, _, _, eh, ew = env_pred.shape
+    seg_s = F.adaptive_avg_pool2d(seg, (R, C))
+    not_dark = (env_gt.mean(5).mean(4).mean(1, keepdim=True) > 0.001).to(env_pred.dtype)
+    m = (seg_s * env_ind.expand_as(seg_s))[..., None, None] * not_dark[..., None, None]
+    m_full = m.expand_as(env_gt)
+    scaled = lsregress(env_pred.detach() * m_full, env_gt * m_full, env_pred)
+    dlog = torch.log(scaled + offset) - torch.log(env_gt + offset)
+    num = (dlog * dlog * m_full).sum()
+    den_raw = m.sum()
+    den = torch.clamp(den_raw.detach(), min=1e-5)
+    err = num / den / 3.0 / ew / eh
+    return err, scaled, num, den_raw
+
+
+# --------------------------------------------------------------------------- #
+# seeded synthetic inputs -- shared by tests and bench   #
+# --------------------------------------------------------------------------- #
+def synthetic_inputs(bn: int, imH: int, imW: int, R: int, C: int, K: int = 12,
+                     eh: int = 8, ew: int = 16, seed: int = 20202, benign: bool = False,
+                     dtype=torch.float32):
+    """Random inputs with the distributions SURVEY.md section 8d prescribes (CPU tensors)."""
+    g = torch.Generator().manual_seed(seed)
+    hi = 0.9 if benign else 1.0
+    albedo = torch.rand(bn, 3, imH, imW, generator=g)
+    n = torch.randn(bn, 3, imH, imW, generator=g)
+    n[:, 2] = n[:, 2].abs() + 0.5
+    normal = n / n.norm(dim=1, keepdim=True)
+    rough = torch.rand(bn, 1, imH, imW, generator=g) * 2.0 - 1.0
+    a = torch.randn(bn, K, 3, R, C, generator=g)
+    axis = a / a.norm(dim=2, keepdim=True)
+    lamb = torch.rand(bn, K, R, C, generator=g) * hi
+    weight = torch.rand(bn, 3 * K, R, C, generator=g) * hi
+    im = torch.rand(bn, 3, imH, imW, generator=g)
+    seg = (torch.rand(bn, 1, imH, imW, generator=g) < 0.9).float()
+    env_gt = torch.rand(bn, 3, R, C, eh, ew, generator=g) * 2.0
+    out = dict(albedo=albedo, normal=normal, rough=rough, axis=axis, lamb=lamb, weight=weight,
+               im=im, seg=seg, env_gt=env_gt)
+    return {k: v.to(dtype).contiguous() for k, v in out.items()}
