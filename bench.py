@@ -1,0 +1,221 @@
+#!/usr/bin/env python
+"""Headline benchmark: shaded Mpix/s (forward + backward) of the SG x microfacet render layer.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic inputs already resident in HBM
+(trainLight mode):
+
+    fused forward  (sgr_fused_fwd: SG -> env image written, diffuse, specular)
+    fused backward (sgr_fused_bwd_sg: dense env cotangent + diffuse/specular cotangents -> SG grads)
+
+through the package's autograd functions (i.e. through the drop-in boundary, not around it).
+Workload = BASELINE.json configs[1] per GPU: batch 16, 240x320 BRDF maps, 120x160 env grid,
+12 SG lobes, 8x16 directions.  For N > 1 the driver launches one rank per GPU with torchrun;
+images shard across ranks (weak scaling: 16 images per GPU), the only collective is the
+all-reduce of the loss numerator/denominator pair.
+
+Rank 0 prints ONE JSON line; see README/DESIGN.md for the field definitions.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes_per_shaded_px(K: int, J: int, q: int) -> dict:
+    """BRDF maps 7q, SG params 7K, env image 3J, outputs 6 (x4 bytes)."""
+    b_brdf, b_sg, b_env, b_out = 7 * q * 4, 7 * K * 4, 3 * J * 4, 6 * 4
+    return dict(fwd_env=b_brdf + b_sg + b_env + b_out,          # fused forward writing the env image
+                fwd_noenv=b_brdf + b_sg + b_out,
+                bwd_sg=b_brdf + b_sg + b_out + b_env + b_sg,    # reads g_env (dense), g_d/g_s; writes SG grads
+                )
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-env", action="store_true", help="render-only variant (env image never materialised)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs a torchrun launch with WORLD_SIZE={args.gpus} (got {world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render layer has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import inverserenderingofindoorscene_amd as pkg
+    from inverserenderingofindoorscene_amd import _lib
+    from oracle import sg_oracle as O      # bench-only: synthetic inputs + the cpu_baseline leg
+
+    _lib.load()
+    bn, imH, imW, R, C, K, eh, ew = args.batch, 240, 320, 120, 160, 12, 8, 16
+    J, q = eh * ew, (imH // R) * (imW // C)
+    need_env = not args.no_env
+
+    # different images on every rank (seed offset), generated on the CPU like SURVEY 8d prescribes
+    inp = O.synthetic_inputs(bn, imH, imW, R, C, K, eh, ew, seed=20202 + 1000 * rank)
+    x = {k: v.to(dev) for k, v in inp.items()}
+    for k in ("axis", "lamb", "weight"):
+        x[k].requires_grad_(True)
+    g = torch.Generator().manual_seed(99 + rank)
+    ct_env = (torch.randn((bn, 3, R, C, eh, ew), generator=g) * 1e-3).to(dev) if need_env else None
+    ct_d = torch.randn((bn, 3, R, C), generator=g).to(dev)
+    ct_s = torch.randn((bn, 3, R, C), generator=g).to(dev)
+    layer = pkg.renderingLayer(imWidth=C, imHeight=R, envWidth=ew, envHeight=eh)
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+
+    def step(i=None):
+        if i is not None:
+            ev[i][0].record()
+        env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=need_env)
+        if i is not None:
+            ev[i][1].record()
+        outs, cts = ([env, d, s], [ct_env, ct_d, ct_s]) if need_env else ([d, s], [ct_d, ct_s])
+        grads = torch.autograd.grad(outs, [x["axis"], x["lamb"], x["weight"]], grad_outputs=cts)
+        if i is not None:
+            ev[i][2].record()
+        return grads
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
+    bwd_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
+
+    if rank == 0:
+        P = bn * R * C                      # shaded (env-grid) pixels per GPU per step
+        img_px = bn * imH * imW
+        ms_per_step = dt / args.steps * 1e3
+        value = world * img_px / (dt / args.steps) / 1e6
+        bpp = algorithmic_bytes_per_shaded_px(K, J, q)
+        fwd_bytes = P * (bpp["fwd_env"] if need_env else bpp["fwd_noenv"])
+        bwd_bytes = P * (bpp["bwd_sg"] if need_env else bpp["bwd_sg"] - 3 * J * 4)
+        fwd_gbps = fwd_bytes / (fwd_ms * 1e-3) / 1e9
+        bwd_gbps = bwd_bytes / (bwd_ms * 1e-3) / 1e9
+        dom = ("sg_bwd_kernel", bwd_ms, bwd_bytes, bwd_gbps) if bwd_ms >= fwd_ms else ("fwd_kernel", fwd_ms, fwd_bytes, fwd_gbps)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.isfile(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom[0])
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mpix/s shaded (fwd+bwd), 240x320x12-SG render layer",
+            "value": round(value, 1),
+            "unit": "Mpix/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1] per GPU: batch {bn} x 240x320 BRDF maps -> 120x160 env grid, "
+                                   f"SGNum=12, 8x16 directions; fused fwd ({'env image written' if need_env else 'render only'}) "
+                                   "+ fused bwd (SG grads), trainLight mode",
+                       "shaded_px_per_step_per_gpu": P, "image_px_per_step_per_gpu": img_px, "q": q,
+                       "Mshade_per_s": round(world * P / (dt / args.steps) / 1e6, 1),
+                       "parallelism": f"batch-sharded x{world}"},
+            "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(dom[3], 1), "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": round(dom[3] / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": dom[2], "avg_launch_ms": round(dom[1], 4)},
+            "kernels": {"fwd_kernel": {"ms": round(fwd_ms, 4), "GBps": round(fwd_gbps, 1), "frac": round(fwd_gbps / HBM_PEAK_GBPS, 4),
+                                       "bytes": fwd_bytes},
+                        "sg_bwd_kernel": {"ms": round(bwd_ms, 4), "GBps": round(bwd_gbps, 1), "frac": round(bwd_gbps / HBM_PEAK_GBPS, 4),
+                                          "bytes": bwd_bytes}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(O, imH, imW, R, C, K, eh, ew)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(O, imH, imW, R, C, K, eh, ew) -> dict:
+    """The fp32 CPU port (oracle/sg_oracle.py) of the same step, timed on this box's host cores on a
+    bounded sample: ONE image of the workload (1/16 of a step), forward + backward (SG grads)."""
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    inp = O.synthetic_inputs(1, imH, imW, R, C, K, eh, ew, seed=20202)
+    names = ("albedo", "normal", "rough", "axis", "lamb", "weight")
+    x = {k: inp[k].clone() for k in names}
+    for k in ("axis", "lamb", "weight"):
+        x[k].requires_grad_(True)
+    g = torch.Generator().manual_seed(99)
+    ct_env = torch.randn((1, 3, R, C, eh, ew), generator=g) * 1e-3
+    ct_d = torch.randn((1, 3, R, C), generator=g)
+    ct_s = torch.randn((1, 3, R, C), generator=g)
+
+    def one():
+        env, d, s = O.render_from_sg(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], eh, ew)
+        torch.autograd.grad([env, d, s], [x["axis"], x["lamb"], x["weight"]], grad_outputs=[ct_env, ct_d, ct_s])
+
+    one()                                   # warm-up
+    times = []
+    t_end = time.perf_counter() + 20.0
+    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 5):
+        t0 = time.perf_counter()
+        one()
+        times.append(time.perf_counter() - t0)
+    best = min(times)
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(imH * imW / best / 1e6, 4), "unit": "Mpix/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 image (1/16 of a step) of the same workload, fwd+bwd (SG grads), torch fp32 CPU port of the "
+                      f"reference algorithm (oracle/sg_oracle.py), best of {len(times)}; {best:.3f} s per image",
+            "cpu": model}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,124 @@
+/* sgrender.h -- C ABI of libsgrender.so: the MI355X (gfx950) implementation of the
+ * spherical-Gaussian x microfacet render path of lzqsd/InverseRenderingOfIndoorScene.
+ *
+ * The reference has no native layer: this path is ~105 eager aten launches made from
+ * Python.  The boundary a maintainer would bind is therefore the
+ * reference's own Python call boundary, and each entry point below names the reference
+ * call it replaces (file:line relative to the reference checkout).  INTEGRATION.md shows
+ * the ctypes stub that goes on the reference side.
+ *
+ * Conventions
+ *   - all tensors are fp32, contiguous, device (HBM) pointers; the layouts are the
+ *     reference's NCHW-style layouts, spelled out per argument;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); every call
+ *     only enqueues work on that stream: no allocation, no host synchronisation;
+ *   - return value: 0 on success, otherwise a hipError_t (> 0) or one of the
+ *     SGR_ERR_* codes (< 0); sgr_last_error() returns a thread-local description;
+ *   - pointers marked "nullable" may be NULL to skip that output / input.
+ *
+ * Shapes:  bn images; K = SGNum lobes per cell (<= SGR_MAX_LOBES); env grid R x C
+ *   (envRow x envCol == the renderingLayer ctor's imHeight x imWidth); J = eh*ew
+ *   quadrature directions per cell; BRDF maps are imH x imW with imH/R == imW/C in {1, 2}
+ *   (other ratios: pool first with sgr_adaptive_avg_pool2d_fwd and pass R x C maps).
+ */
+#ifndef SGRENDER_H_
+#define SGRENDER_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGR_ABI_VERSION 1
+#define SGR_MAX_LOBES 32
+
+#define SGR_OK 0
+#define SGR_ERR_BAD_ARG (-1)        /* NULL required pointer, non-positive size */
+#define SGR_ERR_UNSUPPORTED (-2)    /* K > SGR_MAX_LOBES, pooling ratio not in {1,2} */
+
+int sgr_abi_version(void);
+const char* sgr_last_error(void);
+
+/* Direction table of output2env.__init__ (models.py:353-363) and renderingLayer.__init__
+ * (models.py:437-452), device layout used by every kernel below:
+ *   dirs[j*4 + {0,1,2,3}] = (l_x, l_y, l_z, omega_j),  j = e*ew + a,  padded with zero rows
+ *   up to a multiple of 32 directions.  Host-side helper: fills `out` (host memory,
+ *   4*sgr_dirs_padded(eh*ew) floats). */
+int sgr_dirs_padded(int J);
+int sgr_fill_direction_table(float* out_host, int eh, int ew);
+
+/* View vectors of renderingLayer.__init__ (models.py:415-430): out_host[3*R*C]. */
+int sgr_fill_view_vectors(float* out_host, int R, int C, float fov_deg, const float* camera_pos3);
+
+/* output2env.output2env (models.py:391-404) when premap != 0, output2env.fromSGtoIm
+ * (models.py:371-389) when premap == 0.
+ *   axis   [bn,K,3,R,C]   lamb [bn,K,R,C]   weight [bn,3K,R,C] (channel k*3+rgb)
+ *   env    [bn,3,R,C,eh,ew]  (out)
+ *   lamb_tan [bn,K,R,C], weight_tan [bn,3K,R,C]  (out, nullable; post-tan values the
+ *   reference returns alongside the env image) */
+int sgr_sg_to_env_fwd(const float* axis, const float* lamb, const float* weight, const float* dirs,
+                      float* env, float* lamb_tan, float* weight_tan,
+                      int bn, int K, int R, int C, int eh, int ew, int premap, void* stream);
+
+/* renderingLayer.forwardEnv (models.py:461-522).
+ *   albedo, normal [bn,3,imH,imW]   rough [bn,1,imH,imW]   env [bn,3,R,C,eh,ew]
+ *   view [3,R,C] (sgr_fill_view_vectors)   diffuse, spec [bn,3,R,C] (out) */
+int sgr_render_env_fwd(const float* albedo, const float* normal, const float* rough, const float* env,
+                       const float* dirs, const float* view, float* diffuse, float* spec,
+                       int bn, int R, int C, int eh, int ew, int imH, int imW, float F0, void* stream);
+
+/* Fused output2env.output2env + renderingLayer.forwardEnv (wrapperBRDFLight.py:177,194
+ * back to back): one pass, the env image is written only if `env` is non-NULL. */
+int sgr_fused_fwd(const float* albedo, const float* normal, const float* rough,
+                  const float* axis, const float* lamb, const float* weight,
+                  const float* dirs, const float* view,
+                  float* env /* nullable */, float* diffuse, float* spec,
+                  int bn, int K, int R, int C, int eh, int ew, int imH, int imW, float F0,
+                  int premap, void* stream);
+
+/* Backward of output2env.output2env / fromSGtoIm (torch.autograd of models.py:371-404).
+ *   g_env [bn,3,R,C,eh,ew] in;  g_axis [bn,K,3,R,C], g_lamb [bn,K,R,C], g_weight [bn,3K,R,C] out.
+ *   With premap != 0 the inputs are the raw decoder outputs and the gradients are w.r.t.
+ *   those (chain rule through tan applied); with premap == 0 they are w.r.t. the post-tan
+ *   lamb / weight (fromSGtoIm). */
+int sgr_sg_to_env_bwd(const float* g_env, const float* axis, const float* lamb, const float* weight,
+                      const float* dirs, float* g_axis, float* g_lamb, float* g_weight,
+                      int bn, int K, int R, int C, int eh, int ew, int premap, void* stream);
+
+/* Backward of the fused pass w.r.t. the SG parameters (what trainLight.py needs:
+ * wrapperBRDFLight.py:194 detaches albedo, the BRDF nets are frozen, trainLight.py:121-144).
+ *   g_env (nullable) is the cotangent of the env image coming from other consumers (the
+ *   reconstruction loss, wrapperBRDFLight.py:179-188); the quadrature's own contribution
+ *   to dL/dEnv is recomputed in-kernel from g_diffuse / g_spec and never written to HBM. */
+int sgr_fused_bwd_sg(const float* g_env /* nullable */, const float* g_diffuse, const float* g_spec,
+                     const float* albedo, const float* normal, const float* rough,
+                     const float* axis, const float* lamb, const float* weight,
+                     const float* dirs, const float* view,
+                     float* g_axis, float* g_lamb, float* g_weight,
+                     int bn, int K, int R, int C, int eh, int ew, int imH, int imW, float F0,
+                     int premap, void* stream);
+
+/* dL/dEnv of renderingLayer.forwardEnv alone (autograd of models.py:511-520):
+ *   g_env[b,c,r,cc,j] = omega_j ndl_j (g_diffuse_c A_c/pi + g_spec_c spec_j)   (out, dense) */
+int sgr_render_env_bwd_env(const float* g_diffuse, const float* g_spec,
+                           const float* albedo, const float* normal, const float* rough,
+                           const float* dirs, const float* view, float* g_env,
+                           int bn, int R, int C, int eh, int ew, int imH, int imW, float F0, void* stream);
+
+/* d/d{albedo, normal, rough} of renderingLayer.forwardEnv (autograd of models.py:461-522,
+ * including the 2x2 pooling, the normal renormalisation and the local-frame construction).
+ * The env image is either given (`env` non-NULL: the un-fused API) or re-evaluated from the
+ * SG parameters (`env` NULL: the fused API; premap as in sgr_fused_fwd).
+ *   g_albedo, g_normal [bn,3,imH,imW], g_rough [bn,1,imH,imW]  (out, fully written) */
+int sgr_render_bwd_brdf(const float* g_diffuse, const float* g_spec,
+                        const float* albedo, const float* normal, const float* rough,
+                        const float* env /* nullable */,
+                        const float* axis, const float* lamb, const float* weight /* nullable trio */,
+                        const float* dirs, const float* view,
+                        float* g_albedo, float* g_normal, float* g_rough,
+                        int bn, int K, int R, int C, int eh, int ew, int imH, int imW, float F0,
+                        int premap, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGRENDER_H_ */

@@ -1,0 +1,89 @@
+"""ctypes binding of ``libsgrender.so`` (the C ABI declared in ``include/sgrender.h``).
+
+The shared library is the product; this module only finds it, declares the
+argument types and turns non-zero return codes into Python exceptions.  There
+is deliberately no fallback: if the library is missing, every entry point of
+the package raises ``SgrenderUnavailable`` (build it with
+``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C
+inverserenderingofindoorscene_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("SGR_LIB", os.path.join(_HERE, "libsgrender.so"))
+
+ABI_VERSION = 1
+
+
+class SgrenderUnavailable(RuntimeError):
+    pass
+
+
+class SgrenderError(RuntimeError):
+    pass
+
+
+_P = c_void_p   # device / host pointers travel as plain addresses
+_I = c_int
+_F = c_float
+
+# symbol -> argument types; must mirror include/sgrender.h exactly (tests/test_abi.py checks
+# that every function declared in the header is exported and listed here).
+SIGNATURES = {
+    "sgr_abi_version": ([], c_int),
+    "sgr_last_error": ([], c_char_p),
+    "sgr_dirs_padded": ([_I], c_int),
+    "sgr_fill_direction_table": ([_P, _I, _I], c_int),
+    "sgr_fill_view_vectors": ([_P, _I, _I, _F, _P], c_int),
+    "sgr_sg_to_env_fwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], c_int),
+    "sgr_render_env_fwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P], c_int),
+    "sgr_fused_fwd": ([_P] * 11 + [_I] * 8 + [_F, _I, _P], c_int),
+    "sgr_sg_to_env_bwd": ([_P] * 8 + [_I] * 7 + [_P], c_int),
+    "sgr_fused_bwd_sg": ([_P] * 14 + [_I] * 8 + [_F, _I, _P], c_int),
+    "sgr_render_env_bwd_env": ([_P] * 8 + [_I] * 7 + [_F, _P], c_int),
+    "sgr_render_bwd_brdf": ([_P] * 14 + [_I] * 8 + [_F, _I, _P], c_int),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes library handle."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise SgrenderUnavailable(
+            f"{LIB_PATH} not found: the HIP library has not been built "
+            "(run __graft_entry__.build() or `make -C inverserenderingofindoorscene_amd/csrc`). "
+            "This package has no CPU / PyTorch fallback.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. missing libamdhip64
+        raise SgrenderUnavailable(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (argtypes, restype) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise SgrenderUnavailable(f"{LIB_PATH} does not export {name}; stale build?") from e
+        fn.argtypes = argtypes
+        fn.restype = restype
+    ver = lib.sgr_abi_version()
+    if ver != ABI_VERSION:
+        raise SgrenderUnavailable(f"{LIB_PATH} has ABI version {ver}, this package needs {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().sgr_last_error()
+        raise SgrenderError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def call(name: str, *args) -> None:
+    check(getattr(load(), name)(*args), name)

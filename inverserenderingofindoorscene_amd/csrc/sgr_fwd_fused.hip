@@ -1,0 +1,21 @@
+// Fused output2env.output2env + renderingLayer.forwardEnv (wrapperBRDFLight.py:177,194) on gfx950.
+#include "sgr_forward.inl"
+using namespace sgr;
+
+extern "C" int sgr_fused_fwd(const float* albedo, const float* normal, const float* rough, const float* axis,
+                             const float* lamb, const float* weight, const float* dirs, const float* view,
+                             float* env, float* diffuse, float* spec, int bn, int K, int R, int C, int eh, int ew,
+                             int imH, int imW, float F0, int premap, void* stream) {
+  SGR_REQUIRE(albedo && normal && rough && axis && lamb && weight && dirs && view && diffuse && spec,
+              "sgr_fused_fwd: NULL tensor");
+  SGR_REQUIRE(bn > 0 && K > 0 && R > 0 && C > 0 && eh > 0 && ew > 0, "sgr_fused_fwd: non-positive size");
+  SGR_SUPPORTED(K <= SGR_MAX_LOBES, "sgr_fused_fwd: SGNum > 32 is not supported");
+  if (int rc = check_pool(R, C, imH, imW, "sgr_fused_fwd: BRDF-map / env-grid ratio must be 1 or 2 (pool first)")) return rc;
+  Args a{};
+  a.albedo = albedo; a.normal = normal; a.rough = rough; a.axis = axis; a.lamb = lamb; a.weight = weight;
+  a.dirs = reinterpret_cast<const float4*>(dirs); a.view = view; a.env_out = env; a.diffuse = diffuse; a.spec = spec;
+  set_dims(a, bn, K, R, C, eh, ew, imH, imW);
+  a.F0 = F0; a.premap = premap;
+  const hipStream_t st = (hipStream_t)stream;
+  return sgr_check(env ? fwd_launch<true, true, true>(a, st) : fwd_launch<true, false, true>(a, st), "sgr_fused_fwd");
+}

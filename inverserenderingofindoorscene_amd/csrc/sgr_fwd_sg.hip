@@ -1,0 +1,17 @@
+// output2env.output2env / fromSGtoIm (models.py:371-404) on gfx950.
+#include "sgr_forward.inl"
+using namespace sgr;
+
+extern "C" int sgr_sg_to_env_fwd(const float* axis, const float* lamb, const float* weight, const float* dirs,
+                                 float* env, float* lamb_tan, float* weight_tan, int bn, int K, int R, int C,
+                                 int eh, int ew, int premap, void* stream) {
+  SGR_REQUIRE(axis && lamb && weight && dirs && env, "sgr_sg_to_env_fwd: NULL tensor");
+  SGR_REQUIRE(bn > 0 && K > 0 && R > 0 && C > 0 && eh > 0 && ew > 0, "sgr_sg_to_env_fwd: non-positive size");
+  SGR_SUPPORTED(K <= SGR_MAX_LOBES, "sgr_sg_to_env_fwd: SGNum > 32 is not supported");
+  Args a{};
+  a.axis = axis; a.lamb = lamb; a.weight = weight; a.dirs = reinterpret_cast<const float4*>(dirs);
+  a.env_out = env; a.lamb_tan = lamb_tan; a.weight_tan = weight_tan;
+  set_dims(a, bn, K, R, C, eh, ew, R, C);
+  a.premap = premap;
+  return sgr_check(fwd_launch<true, true, false>(a, (hipStream_t)stream), "sgr_sg_to_env_fwd");
+}

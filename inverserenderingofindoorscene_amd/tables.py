@@ -1,0 +1,51 @@
+"""Constant tables of the render path, built on the host exactly as the reference builds them.
+
+``direction_table``: output2env.__init__ (models.py:353-363) and renderingLayer.__init__
+(models.py:437-452).  ``view_vectors``: renderingLayer.__init__ (models.py:415-430).
+Both are computed with numpy in float64 and stored as float32, like the reference, and then
+packed into the device layout the kernels read (see include/sgrender.h).
+"""
+from __future__ import annotations
+
+from typing import Sequence, Tuple
+
+import numpy as np
+
+
+def direction_table(env_height: int, env_width: int) -> Tuple[np.ndarray, np.ndarray]:
+    """``(ls[J,3], omega[J])`` float32; ``j = e*env_width + a``."""
+    az = ((np.arange(env_width) + 0.5) / env_width - 0.5) * 2 * np.pi
+    el = ((np.arange(env_height) + 0.5) / env_height) * np.pi / 2.0
+    az, el = np.meshgrid(az, el)
+    az = az.reshape(-1)
+    el = el.reshape(-1)
+    ls = np.stack([np.sin(el) * np.cos(az), np.sin(el) * np.sin(az), np.cos(el)], axis=1)
+    omega = np.sin(el) * np.pi * np.pi / env_width / env_height
+    return ls.astype(np.float32), omega.astype(np.float32)
+
+
+def packed_direction_table(env_height: int, env_width: int) -> np.ndarray:
+    """Device layout ``[Jpad,4] = (lx, ly, lz, omega)``, zero rows up to a multiple of 32."""
+    ls, omega = direction_table(env_height, env_width)
+    J = ls.shape[0]
+    jpad = (J + 31) // 32 * 32
+    out = np.zeros((jpad, 4), dtype=np.float32)
+    out[:J, :3] = ls
+    out[:J, 3] = omega
+    return out
+
+
+def view_vectors(im_width: int, im_height: int, fov_deg: float = 57.0,
+                 camera_pos: Sequence[float] = (0, 0, 0)) -> np.ndarray:
+    """Unit view vectors ``v[3,imHeight,imWidth]`` float32 (imHeight x imWidth is the env grid)."""
+    fov = fov_deg / 180.0 * np.pi
+    x_range = 1 * np.tan(fov / 2)
+    y_range = float(im_height) / float(im_width) * x_range
+    x, y = np.meshgrid(np.linspace(-x_range, x_range, im_width), np.linspace(-y_range, y_range, im_height))
+    y = np.flip(y, axis=0)
+    z = -np.ones((im_height, im_width), dtype=np.float32)
+    p = np.stack([x, y, z]).astype(np.float32)
+    cam = np.array(camera_pos, dtype=np.float32).reshape(3, 1, 1)
+    v = cam - p
+    v = v / np.sqrt(np.maximum(np.sum(v * v, axis=0), 1e-12))[np.newaxis]
+    return np.ascontiguousarray(v.astype(np.float32))

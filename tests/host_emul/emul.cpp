@@ -1,0 +1,202 @@
+// TEST INFRASTRUCTURE ONLY -- never shipped, never loaded by the product package.
+//
+// Compiles the kernels' per-pixel arithmetic (inverserenderingofindoorscene_amd/csrc/sgr_math.h,
+// the same expressions the gfx950 kernels evaluate) for the host and drives it with plain
+// loops that mirror the kernels' loop structure, so the hand-derived forward/backward math can
+// be checked against the oracle on a machine without a GPU (tests/test_host_emulation.py).
+// It does not test indexing through LDS, coalescing or launch plumbing: the GPU tests do.
+#include <cstddef>
+#include <vector>
+
+#include "../../inverserenderingofindoorscene_amd/csrc/sgr_math.h"
+
+using namespace sgr;
+
+namespace {
+struct Dims { int bn, K, R, C, J, imH, imW; };
+
+inline float pooled(const float* plane, int r, int c, int imW, int q) {
+  if (q == 1) return plane[(size_t)r * imW + c];
+  const float* t = plane + (size_t)(2 * r) * imW + 2 * c;
+  const float* u = plane + (size_t)(2 * r + 1) * imW + 2 * c;
+  return (((t[0] + t[1]) + u[0]) + u[1]) * 0.25f;
+}
+}  // namespace
+
+extern "C" {
+
+void emul_premap(const float* x, float* y, int n) {
+  for (int i = 0; i < n; ++i) y[i] = premap(x[i]);
+}
+
+// fused forward (env nullable)
+void emul_fused_fwd(const float* albedo, const float* normal, const float* rough, const float* axis,
+                    const float* lamb, const float* weight, const float* dirs, const float* view, float* env,
+                    float* diffuse, float* spec, int bn, int K, int R, int C, int J, int imH, int imW, float F0,
+                    int do_premap) {
+  const int RC = R * C, q = imH / R;
+  const size_t plane = (size_t)imH * imW;
+  std::vector<float> ax(K), ay(K), az(K), lam(K), w0(K), w1(K), w2(K);
+  for (int b = 0; b < bn; ++b)
+    for (int p = 0; p < RC; ++p) {
+      for (int k = 0; k < K; ++k) {
+        const size_t ab = ((size_t)(b * K + k) * 3) * RC + p;
+        ax[k] = axis[ab]; ay[k] = axis[ab + RC]; az[k] = axis[ab + 2 * (size_t)RC];
+        float l = lamb[(size_t)(b * K + k) * RC + p];
+        float t0 = weight[ab], t1 = weight[ab + RC], t2 = weight[ab + 2 * (size_t)RC];
+        if (do_premap) { l = premap(l); t0 = premap(t0); t1 = premap(t1); t2 = premap(t2); }
+        lam[k] = l * kLog2e; w0[k] = t0; w1[k] = t1; w2[k] = t2;
+      }
+      const int r = p / C, c = p - r * C;
+      const float* al = albedo + (size_t)b * 3 * plane;
+      const float* no = normal + (size_t)b * 3 * plane;
+      const float* ro = rough + (size_t)b * plane;
+      const float a0 = pooled(al, r, c, imW, q), a1 = pooled(al + plane, r, c, imW, q), a2 = pooled(al + 2 * plane, r, c, imW, q);
+      const Frame f = make_frame(pooled(no, r, c, imW, q), pooled(no + plane, r, c, imW, q), pooled(no + 2 * plane, r, c, imW, q),
+                                 pooled(ro, r, c, imW, q), view[p], view[RC + p], view[2 * RC + p]);
+      float d0 = 0, d1 = 0, d2 = 0, s0 = 0, s1 = 0, s2 = 0;
+      for (int j = 0; j < J; ++j) {
+        const float* dir = dirs + 4 * j;
+        float c0 = 0, c1 = 0, c2 = 0;
+        for (int k = 0; k < K; ++k) {
+          float t = fmaf(az[k], dir[2], -1.0f);
+          t = fmaf(ay[k], dir[1], t);
+          t = fmaf(ax[k], dir[0], t);
+          const float ex = fexp2(lam[k] * t);
+          c0 = fmaf(w0[k], ex, c0); c1 = fmaf(w1[k], ex, c1); c2 = fmaf(w2[k], ex, c2);
+        }
+        if (env) {
+          env[(((size_t)b * 3 + 0) * RC + p) * J + j] = c0;
+          env[(((size_t)b * 3 + 1) * RC + p) * J + j] = c1;
+          env[(((size_t)b * 3 + 2) * RC + p) * J + j] = c2;
+        }
+        float ndl, sp;
+        brdf_dir(f, dir[0], dir[1], dir[2], F0, ndl, sp);
+        const float wt = ndl * dir[3];
+        const float q0 = wt * c0, q1 = wt * c1, q2 = wt * c2;
+        d0 += q0; d1 += q1; d2 += q2;
+        s0 = fmaf(sp, q0, s0); s1 = fmaf(sp, q1, s1); s2 = fmaf(sp, q2, s2);
+      }
+      const size_t o = (size_t)b * 3 * RC + p;
+      diffuse[o] = (a0 * kInvPi) * d0; diffuse[o + RC] = (a1 * kInvPi) * d1; diffuse[o + 2 * (size_t)RC] = (a2 * kInvPi) * d2;
+      spec[o] = s0; spec[o + RC] = s1; spec[o + 2 * (size_t)RC] = s2;
+    }
+}
+
+// fused backward w.r.t. the SG parameters (g_env nullable; g_diffuse/g_spec nullable together)
+void emul_sg_bwd(const float* g_env, const float* g_diffuse, const float* g_spec, const float* albedo,
+                 const float* normal, const float* rough, const float* axis, const float* lamb, const float* weight,
+                 const float* dirs, const float* view, float* g_axis, float* g_lamb, float* g_weight, int bn, int K,
+                 int R, int C, int J, int imH, int imW, float F0, int do_premap) {
+  const int RC = R * C, q = imH / R;
+  const size_t plane = (size_t)imH * imW;
+  const bool has_render = g_diffuse != nullptr;
+  for (int b = 0; b < bn; ++b)
+    for (int p = 0; p < RC; ++p) {
+      Frame f{};
+      float gd0 = 0, gd1 = 0, gd2 = 0, gs0 = 0, gs1 = 0, gs2 = 0;
+      if (has_render) {
+        const int r = p / C, c = p - r * C;
+        const float* al = albedo + (size_t)b * 3 * plane;
+        const float* no = normal + (size_t)b * 3 * plane;
+        const float* ro = rough + (size_t)b * plane;
+        const float a0 = pooled(al, r, c, imW, q), a1 = pooled(al + plane, r, c, imW, q), a2 = pooled(al + 2 * plane, r, c, imW, q);
+        f = make_frame(pooled(no, r, c, imW, q), pooled(no + plane, r, c, imW, q), pooled(no + 2 * plane, r, c, imW, q),
+                       pooled(ro, r, c, imW, q), view[p], view[RC + p], view[2 * RC + p]);
+        const size_t o = (size_t)b * 3 * RC + p;
+        gd0 = g_diffuse[o] * (a0 * kInvPi); gd1 = g_diffuse[o + RC] * (a1 * kInvPi); gd2 = g_diffuse[o + 2 * (size_t)RC] * (a2 * kInvPi);
+        gs0 = g_spec[o]; gs1 = g_spec[o + RC]; gs2 = g_spec[o + 2 * (size_t)RC];
+      }
+      for (int k = 0; k < K; ++k) {
+        const size_t ab = ((size_t)(b * K + k) * 3) * RC + p;
+        const size_t lb = (size_t)(b * K + k) * RC + p;
+        const float ax = axis[ab], ay = axis[ab + RC], az = axis[ab + 2 * (size_t)RC];
+        float lam = lamb[lb];
+        float w0 = weight[ab], w1 = weight[ab + RC], w2 = weight[ab + 2 * (size_t)RC];
+        if (do_premap) { lam = premap(lam); w0 = premap(w0); w1 = premap(w1); w2 = premap(w2); }
+        float gax = 0, gay = 0, gaz = 0, glam = 0, gw0 = 0, gw1 = 0, gw2 = 0;
+        for (int j = 0; j < J; ++j) {
+          const float* dir = dirs + 4 * j;
+          float c0 = 0, c1 = 0, c2 = 0;
+          if (g_env) {
+            c0 = g_env[(((size_t)b * 3 + 0) * RC + p) * J + j];
+            c1 = g_env[(((size_t)b * 3 + 1) * RC + p) * J + j];
+            c2 = g_env[(((size_t)b * 3 + 2) * RC + p) * J + j];
+          }
+          if (has_render) {
+            float ndl, sp;
+            brdf_dir(f, dir[0], dir[1], dir[2], F0, ndl, sp);
+            const float wt = ndl * dir[3];
+            c0 = fmaf(wt, fmaf(gs0, sp, gd0), c0);
+            c1 = fmaf(wt, fmaf(gs1, sp, gd1), c1);
+            c2 = fmaf(wt, fmaf(gs2, sp, gd2), c2);
+          }
+          float t = fmaf(az, dir[2], -1.0f);
+          t = fmaf(ay, dir[1], t);
+          t = fmaf(ax, dir[0], t);
+          const float ex = fexp2((lam * kLog2e) * t);
+          gw0 = fmaf(c0, ex, gw0); gw1 = fmaf(c1, ex, gw1); gw2 = fmaf(c2, ex, gw2);
+          const float s = fmaf(c2, w2, fmaf(c1, w1, c0 * w0));
+          const float T = s * ex;
+          glam = fmaf(T, t, glam);
+          gax = fmaf(T, dir[0], gax); gay = fmaf(T, dir[1], gay); gaz = fmaf(T, dir[2], gaz);
+        }
+        g_axis[ab] = lam * gax; g_axis[ab + RC] = lam * gay; g_axis[ab + 2 * (size_t)RC] = lam * gaz;
+        if (do_premap) { glam *= premap_grad(lam); gw0 *= premap_grad(w0); gw1 *= premap_grad(w1); gw2 *= premap_grad(w2); }
+        g_lamb[lb] = glam;
+        g_weight[ab] = gw0; g_weight[ab + RC] = gw1; g_weight[ab + 2 * (size_t)RC] = gw2;
+      }
+    }
+}
+
+// d/d{albedo, normal, rough} given the env image
+void emul_brdf_bwd(const float* g_diffuse, const float* g_spec, const float* albedo, const float* normal,
+                   const float* rough, const float* env, const float* dirs, const float* view, float* g_albedo,
+                   float* g_normal, float* g_rough, int bn, int R, int C, int J, int imH, int imW, float F0) {
+  const int RC = R * C, q = imH / R;
+  const size_t plane = (size_t)imH * imW;
+  for (int b = 0; b < bn; ++b)
+    for (int p = 0; p < RC; ++p) {
+      const int r = p / C, c = p - r * C;
+      const float* al = albedo + (size_t)b * 3 * plane;
+      const float* no = normal + (size_t)b * 3 * plane;
+      const float* ro = rough + (size_t)b * plane;
+      const float a0 = pooled(al, r, c, imW, q), a1 = pooled(al + plane, r, c, imW, q), a2 = pooled(al + 2 * plane, r, c, imW, q);
+      const float pn0 = pooled(no, r, c, imW, q), pn1 = pooled(no + plane, r, c, imW, q), pn2 = pooled(no + 2 * plane, r, c, imW, q);
+      const float prho = pooled(ro, r, c, imW, q);
+      const Frame f = make_frame(pn0, pn1, pn2, prho, view[p], view[RC + p], view[2 * RC + p]);
+      const size_t o = (size_t)b * 3 * RC + p;
+      const float gD0 = g_diffuse[o], gD1 = g_diffuse[o + RC], gD2 = g_diffuse[o + 2 * (size_t)RC];
+      const float gs0 = g_spec[o], gs1 = g_spec[o + RC], gs2 = g_spec[o + 2 * (size_t)RC];
+      const float gd0 = gD0 * (a0 * kInvPi), gd1 = gD1 * (a1 * kInvPi), gd2 = gD2 * (a2 * kInvPi);
+      FrameGrad g;
+      frame_grad_zero(g);
+      float ds0 = 0, ds1 = 0, ds2 = 0;
+      for (int j = 0; j < J; ++j) {
+        const float* dir = dirs + 4 * j;
+        const float e0 = env[(((size_t)b * 3 + 0) * RC + p) * J + j];
+        const float e1 = env[(((size_t)b * 3 + 1) * RC + p) * J + j];
+        const float e2 = env[(((size_t)b * 3 + 2) * RC + p) * J + j];
+        const float Ed = dir[3] * (gd0 * e0 + gd1 * e1 + gd2 * e2);
+        const float Es = dir[3] * (gs0 * e0 + gs1 * e1 + gs2 * e2);
+        const float ndl = brdf_dir_bwd(f, dir[0], dir[1], dir[2], F0, Ed, Es, g);
+        const float wt = ndl * dir[3];
+        ds0 = fmaf(wt, e0, ds0); ds1 = fmaf(wt, e1, ds1); ds2 = fmaf(wt, e2, ds2);
+      }
+      float gpn[3], gprho;
+      frame_bwd(pn0, pn1, pn2, prho, f, g, gpn, gprho);
+      const float vals[7] = {gD0 * kInvPi * ds0, gD1 * kInvPi * ds1, gD2 * kInvPi * ds2, gpn[0], gpn[1], gpn[2], gprho};
+      float* outs[7] = {g_albedo + (size_t)b * 3 * plane, g_albedo + (size_t)b * 3 * plane + plane,
+                        g_albedo + (size_t)b * 3 * plane + 2 * plane, g_normal + (size_t)b * 3 * plane,
+                        g_normal + (size_t)b * 3 * plane + plane, g_normal + (size_t)b * 3 * plane + 2 * plane,
+                        g_rough + (size_t)b * plane};
+      for (int i = 0; i < 7; ++i) {
+        if (q == 1) outs[i][(size_t)r * imW + c] = vals[i];
+        else
+          for (int dy = 0; dy < 2; ++dy)
+            for (int dx = 0; dx < 2; ++dx) outs[i][(size_t)(2 * r + dy) * imW + 2 * c + dx] = 0.25f * vals[i];
+      }
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,265 @@
+"""GPU parity tests proper (run with -m gpu on an MI355X): the HIP kernels, called through the
+C ABI by the package's autograd functions, against
+  * the golden fixtures produced by the unmodified reference (tests/golden/*.npz), and
+  * the fp64 CPU oracle on seeded inputs,
+with the tolerances of BASELINE.md section 3: rel-L2 <= 1e-4 and max-abs/max|ref| <= 2e-4
+versus the reference's fp32 results (floating-point path: not bit-exact by nature), and an
+error versus the fp64 arbiter no worse than ~the reference's own fp32 noise."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2, rel_max
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ("albedo", "normal", "rough", "axis", "lamb", "weight")
+TOL_L2 = 1e-4
+TOL_MAX = 2e-4
+
+
+@pytest.fixture(scope="module")
+def sgr():
+    import inverserenderingofindoorscene_amd as pkg
+    from inverserenderingofindoorscene_amd import _lib
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    _lib.load()        # fail loudly if libsgrender.so is missing -- there is no fallback
+    return pkg
+
+
+def _dev_inputs(z, grad=()):
+    x = {}
+    for k in NAMES:
+        t = torch.from_numpy(np.ascontiguousarray(z["in_" + k])).cuda()
+        if k in grad:
+            t.requires_grad_(True)
+        x[k] = t
+    return x
+
+
+def _nondegenerate_mask(z, cfg):
+    n = torch.from_numpy(z["in_normal"])
+    pn = torch.nn.functional.adaptive_avg_pool2d(n, (cfg["R"], cfg["C"]))
+    nn = (pn * pn).sum(1, keepdim=True)
+    un = pn / nn.clamp(1e-6, 1).sqrt()
+    ok = ((un[:, 1:2].abs() < 0.999) & (nn > 1e-4)).float()
+    return torch.nn.functional.interpolate(ok, size=(cfg["imH"], cfg["imW"]), mode="nearest").numpy() > 0.5
+
+
+def _check_fwd(name, z, got):
+    for k, v in got.items():
+        v = v.detach().cpu().numpy()
+        ref32, ref64 = z["ref32_" + k], z["ref64_" + k]
+        assert np.isfinite(v).all(), (name, k)
+        assert rel_l2(v, ref32) < TOL_L2, (name, k, rel_l2(v, ref32))
+        assert rel_max(v, ref32) < TOL_MAX, (name, k, rel_max(v, ref32))
+        e_ref = rel_l2(ref32, ref64)
+        assert rel_l2(v, ref64) < max(3 * e_ref, 3e-5), (name, k, rel_l2(v, ref64), e_ref)
+
+
+def _check_grads(name, z, cfg, grads, which="glin"):
+    mask = _nondegenerate_mask(z, cfg)
+    for k, g in grads.items():
+        g = g.detach().cpu().numpy()
+        ref32, ref64 = z[f"ref32_{which}_{k}"], z[f"ref64_{which}_{k}"]
+        m = np.broadcast_to(mask, g.shape) if k == "normal" else np.ones(g.shape, bool)
+        assert np.isfinite(g).all(), (name, k)
+        e_ref = rel_l2(ref32[m], ref64[m])
+        e = rel_l2(g[m], ref64[m])
+        assert e < max(3 * e_ref, 3e-5), (name, k, e, e_ref)
+        assert rel_l2(g[m], ref32[m]) < max(4 * e_ref, TOL_L2), (name, k, rel_l2(g[m], ref32[m]), e_ref)
+
+
+def test_fused_forward_vs_golden(sgr, golden):
+    name, z, cfg = golden
+    x = _dev_inputs(z)
+    layer = sgr.renderingLayer(imWidth=cfg["C"], imHeight=cfg["R"], fov=cfg["fov"], F0=cfg["F0"],
+                               envWidth=cfg["ew"], envHeight=cfg["eh"])
+    env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=True)
+    _check_fwd(name, z, dict(env=env, diffuse=d, spec=s))
+    none, d2, s2 = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=False)
+    assert none is None
+    _check_fwd(name, z, dict(diffuse=d2, spec=s2))
+
+
+def test_dropin_two_call_forward_vs_golden(sgr, golden):
+    """The reference call sequence wrapperBRDFLight.py:177,194."""
+    name, z, cfg = golden
+    x = _dev_inputs(z)
+    o2e = sgr.output2env(SGNum=cfg["K"], envWidth=cfg["ew"], envHeight=cfg["eh"])
+    rl = sgr.renderingLayer(imWidth=cfg["C"], imHeight=cfg["R"], fov=cfg["fov"], F0=cfg["F0"],
+                            envWidth=cfg["ew"], envHeight=cfg["eh"])
+    env, axis, lam_t, w_t = o2e.output2env(x["axis"], x["lamb"], x["weight"])
+    assert axis is x["axis"]
+    d, s = rl.forwardEnv(x["albedo"], x["normal"], x["rough"], env)
+    _check_fwd(name, z, dict(env=env, diffuse=d, spec=s, lamb_tan=lam_t, weight_tan=w_t))
+    # fromSGtoIm on the post-tan values is the same env image
+    env2 = o2e.fromSGtoIm(x["axis"], lam_t, w_t)
+    assert rel_l2(env2.cpu(), env.cpu()) < 1e-6
+    # the nn.Module aliases route to the same kernels
+    env3, _, _, _ = sgr.output_radiance(cfg["K"], cfg["ew"], cfg["eh"])(x["axis"], x["lamb"], x["weight"])
+    assert torch.equal(env3, env)
+    d3, s3 = sgr.renderLayer(cfg["C"], cfg["R"], cfg["fov"], cfg["F0"], [0, 0, 0], cfg["ew"], cfg["eh"])(
+        x["albedo"], x["normal"], x["rough"], env)
+    assert torch.equal(d3, d) and torch.equal(s3, s)
+
+
+def _cotangents(z):
+    return (torch.from_numpy(z["ct_env"]).cuda(), torch.from_numpy(z["ct_d"]).cuda(), torch.from_numpy(z["ct_s"]).cuda())
+
+
+def test_fused_backward_vs_golden(sgr, golden):
+    name, z, cfg = golden
+    x = _dev_inputs(z, grad=NAMES)
+    layer = sgr.renderingLayer(imWidth=cfg["C"], imHeight=cfg["R"], fov=cfg["fov"], F0=cfg["F0"],
+                               envWidth=cfg["ew"], envHeight=cfg["eh"])
+    env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=True)
+    ce, cd, cs = _cotangents(z)
+    lin = (env * ce).sum() + (d * cd).sum() + (s * cs).sum()
+    grads = torch.autograd.grad(lin, [x[k] for k in NAMES])
+    _check_grads(name, z, cfg, dict(zip(NAMES, grads)))
+
+
+def test_dropin_two_call_backward_vs_golden(sgr, golden):
+    name, z, cfg = golden
+    x = _dev_inputs(z, grad=NAMES)
+    o2e = sgr.output2env(SGNum=cfg["K"], envWidth=cfg["ew"], envHeight=cfg["eh"])
+    rl = sgr.renderingLayer(imWidth=cfg["C"], imHeight=cfg["R"], fov=cfg["fov"], F0=cfg["F0"],
+                            envWidth=cfg["ew"], envHeight=cfg["eh"])
+    env, _, _, _ = o2e.output2env(x["axis"], x["lamb"], x["weight"])
+    d, s = rl.forwardEnv(x["albedo"], x["normal"], x["rough"], env)
+    ce, cd, cs = _cotangents(z)
+    lin = (env * ce).sum() + (d * cd).sum() + (s * cs).sum()
+    grads = torch.autograd.grad(lin, [x[k] for k in NAMES])
+    _check_grads(name, z, cfg, dict(zip(NAMES, grads)))
+
+
+def test_sg_only_grads_like_trainlight(sgr, golden):
+    """trainLight mode: only the SG parameters need gradients, no env cotangent."""
+    name, z, cfg = golden
+    x = _dev_inputs(z, grad=("axis", "lamb", "weight"))
+    layer = sgr.renderingLayer(imWidth=cfg["C"], imHeight=cfg["R"], fov=cfg["fov"], F0=cfg["F0"],
+                               envWidth=cfg["ew"], envHeight=cfg["eh"])
+    _, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=False)
+    _, cd, cs = _cotangents(z)
+    g = torch.autograd.grad((d * cd).sum() + (s * cs).sum(), [x["axis"], x["lamb"], x["weight"]])
+    # same thing through the oracle in fp64
+    from oracle import sg_oracle as O
+    xo = {k: torch.from_numpy(z["in_" + k]).double() for k in NAMES}
+    for k in ("axis", "lamb", "weight"):
+        xo[k].requires_grad_(True)
+    _, do, so = O.render_from_sg(xo["albedo"], xo["normal"], xo["rough"], xo["axis"], xo["lamb"], xo["weight"],
+                                 cfg["eh"], cfg["ew"], cfg["fov"], cfg["F0"])
+    go = torch.autograd.grad((do * cd.cpu().double()).sum() + (so * cs.cpu().double()).sum(),
+                             [xo["axis"], xo["lamb"], xo["weight"]])
+    for k, a, b in zip(("axis", "lamb", "weight"), g, go):
+        assert rel_l2(a.cpu(), b) < 3e-4, (name, k, rel_l2(a.cpu(), b))
+
+
+@pytest.mark.parametrize("shape", [
+    dict(bn=2, imH=14, imW=18, R=7, C=9, K=12, eh=8, ew=16),     # RC not a multiple of 64, q=4
+    dict(bn=1, imH=9, imW=11, R=9, C=11, K=3, eh=3, ew=5),       # J=15: scalar env path, K padded to 4
+    dict(bn=1, imH=12, imW=20, R=6, C=10, K=24, eh=16, ew=32),   # config-5-like lobes / directions
+    dict(bn=1, imH=10, imW=13, R=4, C=5, K=7, eh=4, ew=8),       # non-integer pooling ratio -> pre-pool
+    dict(bn=1, imH=8, imW=8, R=8, C=8, K=32, eh=2, ew=4),        # maximum lobes, J=8 < one tile
+])
+def test_shapes_vs_oracle(sgr, shape):
+    from oracle import sg_oracle as O
+    inp = O.synthetic_inputs(shape["bn"], shape["imH"], shape["imW"], shape["R"], shape["C"], shape["K"],
+                             shape["eh"], shape["ew"], seed=4242)
+    x = {k: inp[k].cuda().requires_grad_(True) for k in NAMES}
+    layer = sgr.renderingLayer(imWidth=shape["C"], imHeight=shape["R"], envWidth=shape["ew"], envHeight=shape["eh"])
+    env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=True)
+    xo = {k: inp[k].double().requires_grad_(True) for k in NAMES}
+    envo, do, so = O.render_from_sg(xo["albedo"], xo["normal"], xo["rough"], xo["axis"], xo["lamb"], xo["weight"],
+                                    shape["eh"], shape["ew"])
+    assert rel_l2(env.detach().cpu(), envo.detach()) < TOL_L2
+    assert rel_l2(d.detach().cpu(), do.detach()) < TOL_L2
+    assert rel_l2(s.detach().cpu(), so.detach()) < 2e-4
+    g = torch.Generator().manual_seed(7)
+    ce, cd, cs = torch.randn(env.shape, generator=g), torch.randn(d.shape, generator=g), torch.randn(s.shape, generator=g)
+    grads = torch.autograd.grad((env * ce.cuda()).sum() + (d * cd.cuda()).sum() + (s * cs.cuda()).sum(), [x[k] for k in NAMES])
+    gro = torch.autograd.grad((envo * ce.double()).sum() + (do * cd.double()).sum() + (so * cs.double()).sum(),
+                              [xo[k] for k in NAMES])
+    for k, a, b in zip(NAMES, grads, gro):
+        assert torch.isfinite(a).all(), k
+        assert rel_l2(a.cpu(), b) < (2e-3 if k in ("normal", "rough") else 5e-4), (shape, k, rel_l2(a.cpu(), b))
+
+
+def test_full_size_properties(sgr):
+    """BASELINE config 2 (bn=16, 240x320 -> 120x160, K=12, 8x16): size-independent properties plus an
+    oracle check of two of the sixteen images."""
+    from oracle import sg_oracle as O
+    bn, imH, imW, R, C, K = 16, 240, 320, 120, 160, 12
+    inp = O.synthetic_inputs(bn, imH, imW, R, C, K, seed=20202)
+    x = {k: inp[k].cuda() for k in NAMES}
+    layer = sgr.renderingLayer(imWidth=C, imHeight=R)
+    env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(env).all() and torch.isfinite(d).all() and torch.isfinite(s).all()
+    # determinism: a second run is bit-identical
+    env2, d2, s2 = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=True)
+    assert torch.equal(env, env2) and torch.equal(d, d2) and torch.equal(s, s2)
+    # batch-permutation equivariance, bit-exact (images are independent)
+    perm = torch.randperm(bn, generator=torch.Generator().manual_seed(3)).cuda()
+    envp, dp, sp = layer.forwardSG(x["albedo"][perm].contiguous(), x["normal"][perm].contiguous(), x["rough"][perm].contiguous(),
+                                   x["axis"][perm].contiguous(), x["lamb"][perm].contiguous(), x["weight"][perm].contiguous(), need_env=True)
+    assert torch.equal(envp, env[perm]) and torch.equal(dp, d[perm]) and torch.equal(sp, s[perm])
+    # fused == two-call, and the env-less variant gives the same images (same arithmetic)
+    _, d3, s3 = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=False)
+    assert rel_l2(d3.cpu(), d.cpu()) < 1e-6 and rel_l2(s3.cpu(), s.cpu()) < 1e-6
+    d4, s4 = layer.forwardEnv(x["albedo"], x["normal"], x["rough"], env)
+    assert rel_l2(d4.cpu(), d.cpu()) < 1e-6 and rel_l2(s4.cpu(), s.cpu()) < 1e-6
+    # linearity in the (post-tan) weights, exact for a power-of-two scale
+    o2e = sgr.output2env(K)
+    lam_t = torch.tan(np.pi / 2 * (0.999 * x["lamb"]))
+    w_t = torch.tan(np.pi / 2 * (0.999 * x["weight"]))
+    e1 = o2e.fromSGtoIm(x["axis"], lam_t, w_t)
+    e2 = o2e.fromSGtoIm(x["axis"], lam_t, 2.0 * w_t)
+    assert torch.equal(e2, 2.0 * e1)
+    # two images against the fp64 oracle
+    for b in (0, 15):
+        sub = {k: inp[k][b:b + 1].double() for k in NAMES}
+        eo, do, so = O.render_from_sg(sub["albedo"], sub["normal"], sub["rough"], sub["axis"], sub["lamb"], sub["weight"])
+        assert rel_l2(env[b:b + 1].cpu(), eo) < TOL_L2
+        assert rel_l2(d[b:b + 1].cpu(), do) < TOL_L2
+        assert rel_l2(s[b:b + 1].cpu(), so) < TOL_L2
+
+
+def test_full_size_backward_one_image(sgr):
+    from oracle import sg_oracle as O
+    bn, imH, imW, R, C, K = 2, 240, 320, 120, 160, 12
+    inp = O.synthetic_inputs(bn, imH, imW, R, C, K, seed=20203)
+    x = {k: inp[k].cuda() for k in NAMES}
+    for k in ("axis", "lamb", "weight"):
+        x[k].requires_grad_(True)
+    layer = sgr.renderingLayer(imWidth=C, imHeight=R)
+    env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=True)
+    g = torch.Generator().manual_seed(11)
+    ce, cd, cs = torch.randn(env.shape, generator=g), torch.randn(d.shape, generator=g), torch.randn(s.shape, generator=g)
+    grads = torch.autograd.grad((env * ce.cuda()).sum() + (d * cd.cuda()).sum() + (s * cs.cuda()).sum(),
+                                [x["axis"], x["lamb"], x["weight"]])
+    b = 1
+    sub = {k: inp[k][b:b + 1].double() for k in NAMES}
+    for k in ("axis", "lamb", "weight"):
+        sub[k].requires_grad_(True)
+    eo, do, so = O.render_from_sg(sub["albedo"], sub["normal"], sub["rough"], sub["axis"], sub["lamb"], sub["weight"])
+    gro = torch.autograd.grad((eo * ce[b:b + 1].double()).sum() + (do * cd[b:b + 1].double()).sum() + (so * cs[b:b + 1].double()).sum(),
+                              [sub["axis"], sub["lamb"], sub["weight"]])
+    for k, a, r in zip(("axis", "lamb", "weight"), grads, gro):
+        assert rel_l2(a[b:b + 1].cpu(), r) < 3e-4, (k, rel_l2(a[b:b + 1].cpu(), r))
+
+
+def test_error_behaviour(sgr):
+    o2e = sgr.output2env(SGNum=12)
+    rl = sgr.renderingLayer(imWidth=16, imHeight=12)
+    a = torch.zeros(1, 12, 3, 12, 16)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        o2e.output2env(a, torch.zeros(1, 12, 12, 16), torch.zeros(1, 36, 12, 16))
+    with pytest.raises(RuntimeError, match="lamb must be"):
+        o2e.output2env(a.cuda(), torch.zeros(1, 11, 12, 16).cuda(), torch.zeros(1, 36, 12, 16).cuda())
+    with pytest.raises(RuntimeError, match="does not match"):
+        rl.forwardEnv(torch.zeros(1, 3, 24, 32).cuda(), torch.zeros(1, 3, 24, 32).cuda(), torch.zeros(1, 1, 24, 32).cuda(),
+                      torch.zeros(1, 3, 10, 16, 8, 16).cuda())
+    with pytest.raises(RuntimeError, match="fp32"):
+        o2e.output2env(a.cuda().double(), torch.zeros(1, 12, 12, 16).cuda().double(), torch.zeros(1, 36, 12, 16).cuda().double())

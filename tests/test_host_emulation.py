@@ -1,0 +1,141 @@
+"""CPU: the kernels' per-pixel arithmetic (csrc/sgr_math.h compiled for the host,
+tests/host_emul/emul.cpp) against the golden fixtures and the fp64 oracle.
+
+This checks the hand-derived forward and adjoint math without a GPU; the `-m gpu`
+tests check the same quantities through the real kernels and the C ABI."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, rel_l2, rel_max
+from inverserenderingofindoorscene_amd import tables
+
+EMUL_DIR = os.path.join(ROOT, "tests", "host_emul")
+NAMES = ("albedo", "normal", "rough", "axis", "lamb", "weight")
+FP = ctypes.POINTER(ctypes.c_float)
+
+
+@pytest.fixture(scope="module")
+def emul():
+    so = os.path.join(EMUL_DIR, "libemul.so")
+    src = os.path.join(EMUL_DIR, "emul.cpp")
+    hdr = os.path.join(ROOT, "inverserenderingofindoorscene_amd", "csrc", "sgr_math.h")
+    if (not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", src, "-o", so])
+    return ctypes.CDLL(so)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(FP)
+
+
+def _inputs(z):
+    return {k: np.ascontiguousarray(z["in_" + k], dtype=np.float32) for k in NAMES}
+
+
+def _forward(emul, z, cfg):
+    x = _inputs(z)
+    bn, K, R, C, eh, ew = cfg["bn"], cfg["K"], cfg["R"], cfg["C"], cfg["eh"], cfg["ew"]
+    J = eh * ew
+    dirs = tables.packed_direction_table(eh, ew)
+    view = tables.view_vectors(C, R, cfg["fov"])
+    env = np.empty((bn, 3, R, C, eh, ew), np.float32)
+    d = np.empty((bn, 3, R, C), np.float32)
+    s = np.empty((bn, 3, R, C), np.float32)
+    emul.emul_fused_fwd(_p(x["albedo"]), _p(x["normal"]), _p(x["rough"]), _p(x["axis"]), _p(x["lamb"]), _p(x["weight"]),
+                        _p(dirs), _p(view), _p(env), _p(d), _p(s), bn, K, R, C, J, cfg["imH"], cfg["imW"],
+                        ctypes.c_float(cfg["F0"]), 1)
+    return x, dirs, view, env, d, s
+
+
+def test_premap_accuracy(emul):
+    """tan(pi/2*0.999*x) of the kernels vs float64 on the whole decoder range, incl. x == 1."""
+    x = np.concatenate([np.linspace(0, 1, 200001), 1 - np.logspace(-7, -1, 4001), [0.0, 1.0]]).astype(np.float32)
+    y = np.empty_like(x)
+    emul.emul_premap(_p(x), _p(y), x.size)
+    # the reference's fp32 argument rounding, then exact tan
+    arg = (np.float32(0.999) * x).astype(np.float32) * np.float32(np.pi / 2)
+    truth = np.tan(arg.astype(np.float64))
+    rel = np.abs(y - truth) / np.maximum(np.abs(truth), 1e-30)
+    assert rel.max() < 4e-7, rel.max()
+    ref = torch.tan(np.pi / 2 * (0.999 * torch.from_numpy(x))).numpy()      # torch's own fp32 tan
+    assert (np.abs(y - ref) / np.maximum(np.abs(ref), 1e-30)).max() < 5e-7
+
+
+def test_forward_math_vs_golden(emul, golden):
+    name, z, cfg = golden
+    _, _, _, env, d, s = _forward(emul, z, cfg)
+    for k, got in (("env", env), ("diffuse", d), ("spec", s)):
+        e_ref = rel_l2(z["ref32_" + k], z["ref64_" + k])       # the reference's own fp32 noise
+        assert rel_l2(got, z["ref32_" + k]) < 1e-4, (name, k, rel_l2(got, z["ref32_" + k]))
+        assert rel_max(got, z["ref32_" + k]) < 2e-4, (name, k)
+        # vs the fp64 arbiter: no worse than ~the reference's own fp32 noise (the spec term is
+        # ill-conditioned where alpha^2 is tiny; both fp32 evaluations sit on that floor)
+        assert rel_l2(got, z["ref64_" + k]) < max(3 * e_ref, 3e-5), (name, k, rel_l2(got, z["ref64_" + k]), e_ref)
+
+
+def test_sg_backward_math_vs_golden(emul, golden):
+    name, z, cfg = golden
+    x, dirs, view, _, _, _ = _forward(emul, z, cfg)
+    bn, K, R, C, J = cfg["bn"], cfg["K"], cfg["R"], cfg["C"], cfg["eh"] * cfg["ew"]
+    ga, gl, gw = np.empty_like(x["axis"]), np.empty_like(x["lamb"]), np.empty_like(x["weight"])
+    ct_env, ct_d, ct_s = (np.ascontiguousarray(z[k]) for k in ("ct_env", "ct_d", "ct_s"))
+    emul.emul_sg_bwd(_p(ct_env), _p(ct_d), _p(ct_s), _p(x["albedo"]), _p(x["normal"]), _p(x["rough"]), _p(x["axis"]),
+                     _p(x["lamb"]), _p(x["weight"]), _p(dirs), _p(view), _p(ga), _p(gl), _p(gw), bn, K, R, C, J,
+                     cfg["imH"], cfg["imW"], ctypes.c_float(cfg["F0"]), 1)
+    for k, got in (("axis", ga), ("lamb", gl), ("weight", gw)):
+        e_ref = rel_l2(z["ref32_glin_" + k], z["ref64_glin_" + k])
+        e = rel_l2(got, z["ref64_glin_" + k])
+        assert e < max(2 * e_ref, 1e-5), (name, k, e, e_ref)
+        assert rel_l2(got, z["ref32_glin_" + k]) < max(3 * e_ref, 1e-4), (name, k)
+
+
+def _nondegenerate_mask(z, cfg):
+    """Pixels where the reference's normal gradient is meaningful: away from N || up (the local
+    frame is singular there and torch returns O(1e20) values) and away from |N|^2 clamps."""
+    n = torch.from_numpy(z["in_normal"])
+    R, C = cfg["R"], cfg["C"]
+    pn = torch.nn.functional.adaptive_avg_pool2d(n, (R, C))
+    nn = (pn * pn).sum(1, keepdim=True)
+    un = pn / nn.clamp(1e-6, 1).sqrt()
+    ok = ((un[:, 1:2].abs() < 0.999) & (nn > 1e-4)).float()
+    return torch.nn.functional.interpolate(ok, size=(cfg["imH"], cfg["imW"]), mode="nearest").numpy() > 0.5
+
+
+def test_brdf_backward_math_vs_golden(emul, golden):
+    name, z, cfg = golden
+    x, dirs, view, env, _, _ = _forward(emul, z, cfg)
+    bn, R, C, J = cfg["bn"], cfg["R"], cfg["C"], cfg["eh"] * cfg["ew"]
+    gA, gN, gR = np.empty_like(x["albedo"]), np.empty_like(x["normal"]), np.empty_like(x["rough"])
+    ct_d, ct_s = np.ascontiguousarray(z["ct_d"]), np.ascontiguousarray(z["ct_s"])
+    env_ref = np.ascontiguousarray(z["ref32_env"])
+    emul.emul_brdf_bwd(_p(ct_d), _p(ct_s), _p(x["albedo"]), _p(x["normal"]), _p(x["rough"]), _p(env_ref), _p(dirs),
+                       _p(view), _p(gA), _p(gN), _p(gR), bn, R, C, J, cfg["imH"], cfg["imW"], ctypes.c_float(cfg["F0"]))
+    mask = _nondegenerate_mask(z, cfg)
+    for k, got, m in (("albedo", gA, np.ones_like(gA, bool)), ("normal", gN, np.broadcast_to(mask, gN.shape)),
+                      ("rough", gR, np.ones_like(gR, bool))):
+        ref64, ref32 = z["ref64_glin_" + k], z["ref32_glin_" + k]
+        assert np.isfinite(got).all(), (name, k)
+        e_ref = rel_l2(ref32[m], ref64[m])
+        e = rel_l2(got[m], ref64[m])
+        assert e < max(3 * e_ref, 2e-5), (name, k, e, e_ref)
+
+
+def test_c_tables_match_numpy():
+    """sgr_fill_* helpers of the C ABI vs the numpy tables (needs libsgrender.so, no GPU)."""
+    from inverserenderingofindoorscene_amd import _lib
+    lib = _lib.load()
+    for eh, ew in [(8, 16), (16, 32), (4, 8), (3, 5)]:
+        want = tables.packed_direction_table(eh, ew)
+        got = np.empty_like(want)
+        assert lib.sgr_fill_direction_table(got.ctypes.data, eh, ew) == 0
+        assert np.abs(got - want).max() <= 1.2e-7
+    for R, C, fov in [(120, 160, 57.0), (6, 8, 42.75), (1, 1, 57.0)]:
+        want = tables.view_vectors(C, R, fov)
+        got = np.empty_like(want)
+        assert lib.sgr_fill_view_vectors(got.ctypes.data, R, C, ctypes.c_float(fov), None) == 0
+        assert np.abs(got - want).max() <= 1.2e-7
