@@ -118,6 +118,39 @@ int sgr_render_bwd_brdf(const float* g_diffuse, const float* g_spec,
                         int bn, int K, int R, int C, int eh, int ew, int imH, int imW, float F0,
                         int premap, void* stream);
 
+/* ---- scale-invariant regressions and the render loss ------------------------------------- */
+
+/* Floats of scratch the loss entry points need for a batch of bn images. */
+int sgr_loss_workspace_floats(int bn);
+
+/* Render loss of wrapperBRDFLight.py:170-171,192,197-207 for this rank's shard:
+ *   im_small = avgpool(im), seg_small = avgpool(seg)              (:170-171)
+ *   (kd, ks) = LSregressDiffSpec coefficients of (diffuse, spec, im_small)   (models.py:23-84)
+ *   rendered = clamp(kd diffuse + ks spec, 0, 1)                  (:203)
+ *   parts[0] = sum (rendered - im_small)^2 seg_small,  parts[1] = sum seg_small   (:192,205-207)
+ * The caller forms renderErr = parts[0] / max(parts[1], 1e-5) / 3 (after summing parts over
+ * ranks when the batch is sharded).  No host synchronisation.
+ *   diffuse, spec [bn,3,R,C]   im [bn,3,imH,imW]   seg [bn,1,imH,imW]   (imH/R == imW/C in {1,2})
+ *   out: im_small, rendered [bn,3,R,C]; seg_small [bn,1,R,C]; coef [bn,2]; parts [2] */
+int sgr_render_loss_fwd(const float* diffuse, const float* spec, const float* im, const float* seg,
+                        float* im_small, float* seg_small, float* rendered, float* coef, float* parts,
+                        float* workspace, int bn, int R, int C, int imH, int imW, void* stream);
+
+/* d parts[0] / d{diffuse, spec} times *g_num (a device scalar); coefficients are constants as in
+ * the reference (detached, models.py:54,76; wrapperBRDFLight.py:197-201). */
+int sgr_render_loss_bwd(const float* g_num, const float* diffuse, const float* spec,
+                        const float* im_small, const float* seg_small, const float* coef,
+                        float* g_diffuse, float* g_spec, int bn, int R, int C, void* stream);
+
+/* models.LSregress (models.py:7-21): coef[b] = clamp(<pred_b,gt_b> / max(<pred_b,pred_b>,1e-5), 1e-3, 1e3);
+ * n elements per image. */
+int sgr_lsregress_coef(const float* pred, const float* gt, float* coef, float* workspace,
+                       int bn, long long n, void* stream);
+
+/* models.LSregressDiffSpec (models.py:23-84): coef[b] = (c_im c_d, c_im c_s); n elements per image. */
+int sgr_lsregress_diffspec_coef(const float* diffuse, const float* spec, const float* im, float* coef,
+                                float* workspace, int bn, int n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,11 @@ SIGNATURES = {
     "sgr_fused_bwd_sg": ([_P] * 14 + [_I] * 8 + [_F, _I, _P], c_int),
     "sgr_render_env_bwd_env": ([_P] * 8 + [_I] * 7 + [_F, _P], c_int),
     "sgr_render_bwd_brdf": ([_P] * 14 + [_I] * 8 + [_F, _I, _P], c_int),
+    "sgr_loss_workspace_floats": ([_I], c_int),
+    "sgr_render_loss_fwd": ([_P] * 10 + [_I] * 5 + [_P], c_int),
+    "sgr_render_loss_bwd": ([_P] * 8 + [_I] * 3 + [_P], c_int),
+    "sgr_lsregress_coef": ([_P] * 4 + [_I, ctypes.c_longlong, _P], c_int),
+    "sgr_lsregress_diffspec_coef": ([_P] * 5 + [_I, _I, _P], c_int),
 }
 
 _lib = None

@@ -1,0 +1,321 @@
+// Scale-invariant regressions and the masked-L2 render loss on gfx950.
+//
+//   LSregressDiffSpec ........ models.py:23-84      LSregress ........ models.py:7-21
+//   render loss .............. wrapperBRDFLight.py:170-171,192,197-207
+//
+// These are HBM-bound streaming reductions over a few MB (launch-latency territory at the
+// reference's sizes), so the structure is: grid = (SPLIT, bn) blocks, fp32 per-thread partials,
+// wave reduction by DPP shuffles, cross-wave through LDS, one partial per block written to a
+// workspace; the NEXT kernel's prologue folds the SPLIT partials of its image (in a fixed order,
+// in double) -- no atomics, bit-reproducible, no host synchronisation (the reference's
+// `.item()` on pixelNum, wrapperBRDFLight.py:192, stays on the device).
+#include "sgr_launch.h"
+
+namespace sgr {
+
+constexpr int kLossThreads = 256;
+constexpr int kSplit = 16;           // blocks per image
+
+template <int N>
+__device__ __forceinline__ void block_reduce(float (&v)[N], float* lds /* [4*N] */) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_down(v[i], off, 64);
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) lds[wave * N + i] = v[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = (lds[i] + lds[N + i]) + (lds[2 * N + i] + lds[3 * N + i]);
+  }
+  __syncthreads();
+}
+
+// fold the kSplit partials of image b (N values each) in double, fixed order
+template <int N>
+__device__ __forceinline__ void fold(const float* __restrict__ ws, int b, double (&out)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) out[i] = 0.0;
+  for (int s = 0; s < kSplit; ++s) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] += (double)ws[((size_t)b * kSplit + s) * N + i];
+  }
+}
+
+// (c_d, c_s) of models.py:44-63 from the five masked sums
+__device__ __forceinline__ void diffspec_coefs(const double (&s)[5], float n_elems, float& cd, float& cs) {
+  const float a11 = (float)s[0], a22 = (float)s[1], a12 = (float)s[2], b1 = (float)s[3], b2 = (float)s[4];
+  const float frac = a11 * a22 - a12 * a12;
+  const float c1 = (b1 * a22 - b2 * a12) / fmaxf(frac, 1e-2f);
+  const float c2 = (-b1 * a12 + a11 * b2) / fmaxf(frac, 1e-2f);
+  const float c3 = fminf(fmaxf(b1 / fmaxf(a11, 1e-5f), 0.001f), 1000.0f);
+  const bool two = (frac / n_elems) > 1e-2f;
+  cd = fminf(fmaxf(two ? c1 : c3, 0.0f), 1000.0f);
+  cs = fminf(fmaxf(two ? c2 : 0.0f, 0.0f), 1000.0f);
+}
+__device__ __forceinline__ float unit_coef(double num, double den) {   // models.py:13-14, 72-77
+  return fminf(fmaxf((float)num / fmaxf((float)den, 1e-5f), 0.001f), 1000.0f);
+}
+
+template <int POOL>
+__device__ __forceinline__ float pool_at(const float* __restrict__ plane, int r, int c, int imW) {
+  if (POOL == 1) return plane[(size_t)r * imW + c];
+  const float2 t = *reinterpret_cast<const float2*>(plane + (size_t)(2 * r) * imW + 2 * c);
+  const float2 u = *reinterpret_cast<const float2*>(plane + (size_t)(2 * r + 1) * imW + 2 * c);
+  return (((t.x + t.y) + u.x) + u.y) * 0.25f;
+}
+
+// ---- stage A: pool im/seg to the env grid, five masked sums + sum(seg) ------------------------
+template <int POOL>
+__global__ __launch_bounds__(kLossThreads) void loss_stage_a(const float* __restrict__ diffuse, const float* __restrict__ spec,
+                                                              const float* __restrict__ im, const float* __restrict__ seg,
+                                                              float* __restrict__ im_s, float* __restrict__ seg_s,
+                                                              float* __restrict__ wsA /* [bn,kSplit,6] */, int R, int C, int imH,
+                                                              int imW) {
+  __shared__ float lds[4 * 6];
+  const int b = blockIdx.y, RC = R * C, n = 3 * RC;
+  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const size_t plane = (size_t)imH * imW;
+  for (int i = blockIdx.x * kLossThreads + threadIdx.x; i < n; i += kSplit * kLossThreads) {
+    const int ch = i / RC, p = i - ch * RC, r = p / C, c = p - r * C;
+    const float v = pool_at<POOL>(im + ((size_t)b * 3 + ch) * plane, r, c, imW);
+    im_s[(size_t)b * n + i] = v;
+    const float m = v < 0.9f ? 1.0f : 0.0f;
+    const float d = diffuse[(size_t)b * n + i] * m, s = spec[(size_t)b * n + i] * m, vm = v * m;
+    acc[0] = fmaf(d, d, acc[0]); acc[1] = fmaf(s, s, acc[1]); acc[2] = fmaf(d, s, acc[2]);
+    acc[3] = fmaf(d, vm, acc[3]); acc[4] = fmaf(s, vm, acc[4]);
+    if (ch == 0) {
+      const float sg = pool_at<POOL>(seg + (size_t)b * plane, r, c, imW);
+      seg_s[(size_t)b * RC + p] = sg;
+      acc[5] += sg;
+    }
+  }
+  block_reduce<6>(acc, lds);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) wsA[((size_t)b * kSplit + blockIdx.x) * 6 + k] = acc[k];
+  }
+}
+
+// ---- stage B: sums for the second (one-unknown) regression -------------------------------------
+__global__ __launch_bounds__(kLossThreads) void loss_stage_b(const float* __restrict__ diffuse, const float* __restrict__ spec,
+                                                              const float* __restrict__ im_s, const float* __restrict__ wsA,
+                                                              float* __restrict__ wsB /* [bn,kSplit,2] */, int n) {
+  __shared__ float lds[4 * 2];
+  const int b = blockIdx.y;
+  double sA[6];
+  fold<6>(wsA, b, sA);
+  const double s5[5] = {sA[0], sA[1], sA[2], sA[3], sA[4]};
+  float cd, cs;
+  diffspec_coefs(s5, (float)n, cd, cs);
+  float acc[2] = {0.f, 0.f};
+  for (int i = blockIdx.x * kLossThreads + threadIdx.x; i < n; i += kSplit * kLossThreads) {
+    const size_t o = (size_t)b * n + i;
+    const float r = fminf(fmaxf(cd * diffuse[o] + cs * spec[o], 0.0f), 1.0f);
+    acc[0] = fmaf(r, im_s[o], acc[0]);
+    acc[1] = fmaf(r, r, acc[1]);
+  }
+  block_reduce<2>(acc, lds);
+  if (threadIdx.x == 0) {
+    wsB[((size_t)b * kSplit + blockIdx.x) * 2 + 0] = acc[0];
+    wsB[((size_t)b * kSplit + blockIdx.x) * 2 + 1] = acc[1];
+  }
+}
+
+// ---- stage C: final coefficients, rendered image, masked squared error -------------------------
+__global__ __launch_bounds__(kLossThreads) void loss_stage_c(const float* __restrict__ diffuse, const float* __restrict__ spec,
+                                                              const float* __restrict__ im_s, const float* __restrict__ seg_s,
+                                                              const float* __restrict__ wsA, const float* __restrict__ wsB,
+                                                              float* __restrict__ coef /* [bn,2] */, float* __restrict__ rendered,
+                                                              float* __restrict__ wsC /* [bn,kSplit] */, int RC) {
+  __shared__ float lds[4];
+  const int b = blockIdx.y, n = 3 * RC;
+  double sA[6], sB[2];
+  fold<6>(wsA, b, sA);
+  fold<2>(wsB, b, sB);
+  const double s5[5] = {sA[0], sA[1], sA[2], sA[3], sA[4]};
+  float cd, cs;
+  diffspec_coefs(s5, (float)n, cd, cs);
+  const float cim = unit_coef(sB[0], sB[1]);
+  const float kd = cim * cd, ks = cim * cs;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    coef[2 * b] = kd;
+    coef[2 * b + 1] = ks;
+  }
+  float acc[1] = {0.f};
+  for (int i = blockIdx.x * kLossThreads + threadIdx.x; i < n; i += kSplit * kLossThreads) {
+    const size_t o = (size_t)b * n + i;
+    const int p = i % RC;
+    const float r = fminf(fmaxf(kd * diffuse[o] + ks * spec[o], 0.0f), 1.0f);
+    rendered[o] = r;
+    const float e = r - im_s[o];
+    acc[0] = fmaf(e * e, seg_s[(size_t)b * RC + p], acc[0]);
+  }
+  block_reduce<1>(acc, lds);
+  if (threadIdx.x == 0) wsC[(size_t)b * kSplit + blockIdx.x] = acc[0];
+}
+
+// ---- stage D: batch totals [num, den_raw] (this rank's shard) ----------------------------------
+__global__ void loss_stage_d(const float* __restrict__ wsA, const float* __restrict__ wsC, float* __restrict__ parts, int bn) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double num = 0.0, den = 0.0;
+  for (int b = 0; b < bn; ++b)
+    for (int s = 0; s < kSplit; ++s) {
+      num += (double)wsC[(size_t)b * kSplit + s];
+      den += (double)wsA[((size_t)b * kSplit + s) * 6 + 5];
+    }
+  parts[0] = (float)num;
+  parts[1] = (float)den;
+}
+
+// ---- backward: d(num)/d{diffuse, spec} * g_num ------------------------------------------------
+// num = sum (clamp(kd D + ks S, 0, 1) - imS)^2 seg ; kd, ks are constants (models.py:54,76 detach,
+// wrapperBRDFLight.py:197-201 passes detached images for the regression).
+__global__ __launch_bounds__(kLossThreads) void loss_bwd(const float* __restrict__ g_num /* device scalar */,
+                                                          const float* __restrict__ diffuse, const float* __restrict__ spec,
+                                                          const float* __restrict__ im_s, const float* __restrict__ seg_s,
+                                                          const float* __restrict__ coef, float* __restrict__ g_diffuse,
+                                                          float* __restrict__ g_spec, int RC, size_t total) {
+  const float gn = g_num[0];
+  const int n = 3 * RC;
+  for (size_t o = (size_t)blockIdx.x * kLossThreads + threadIdx.x; o < total; o += (size_t)gridDim.x * kLossThreads) {
+    const int b = (int)(o / n);
+    const int p = (int)(o % RC);
+    const float kd = coef[2 * b], ks = coef[2 * b + 1];
+    const float raw = kd * diffuse[o] + ks * spec[o];
+    const float r = fminf(fmaxf(raw, 0.0f), 1.0f);
+    float g = (raw >= 0.0f && raw <= 1.0f) ? 2.0f * (r - im_s[o]) * seg_s[(size_t)b * RC + p] * gn : 0.0f;
+    g_diffuse[o] = g * kd;
+    g_spec[o] = g * ks;
+  }
+}
+
+// ---- generic per-image <a,b>, <a,a> (LSregress, models.py:7-21) --------------------------------
+__global__ __launch_bounds__(kLossThreads) void dot2_partial(const float* __restrict__ a, const float* __restrict__ bb,
+                                                              float* __restrict__ ws /* [bn,kSplit,2] */, size_t n) {
+  __shared__ float lds[4 * 2];
+  const int b = blockIdx.y;
+  float acc[2] = {0.f, 0.f};
+  for (size_t i = (size_t)blockIdx.x * kLossThreads + threadIdx.x; i < n; i += (size_t)kSplit * kLossThreads) {
+    const float x = a[(size_t)b * n + i], y = bb[(size_t)b * n + i];
+    acc[0] = fmaf(x, y, acc[0]);
+    acc[1] = fmaf(x, x, acc[1]);
+  }
+  block_reduce<2>(acc, lds);
+  if (threadIdx.x == 0) {
+    ws[((size_t)b * kSplit + blockIdx.x) * 2 + 0] = acc[0];
+    ws[((size_t)b * kSplit + blockIdx.x) * 2 + 1] = acc[1];
+  }
+}
+__global__ void unit_coef_finish(const float* __restrict__ ws, float* __restrict__ coef, int bn) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= bn) return;
+  double s[2];
+  fold<2>(ws, b, s);
+  coef[b] = unit_coef(s[0], s[1]);
+}
+
+// (c_im c_d, c_im c_s) of LSregressDiffSpec for images already on a common grid
+__global__ __launch_bounds__(kLossThreads) void diffspec_partial_a(const float* __restrict__ diffuse, const float* __restrict__ spec,
+                                                                    const float* __restrict__ im, float* __restrict__ wsA, int n) {
+  __shared__ float lds[4 * 6];
+  const int b = blockIdx.y;
+  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int i = blockIdx.x * kLossThreads + threadIdx.x; i < n; i += kSplit * kLossThreads) {
+    const size_t o = (size_t)b * n + i;
+    const float v = im[o];
+    const float m = v < 0.9f ? 1.0f : 0.0f;
+    const float d = diffuse[o] * m, s = spec[o] * m, vm = v * m;
+    acc[0] = fmaf(d, d, acc[0]); acc[1] = fmaf(s, s, acc[1]); acc[2] = fmaf(d, s, acc[2]);
+    acc[3] = fmaf(d, vm, acc[3]); acc[4] = fmaf(s, vm, acc[4]);
+  }
+  block_reduce<6>(acc, lds);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) wsA[((size_t)b * kSplit + blockIdx.x) * 6 + k] = acc[k];
+  }
+}
+__global__ void diffspec_finish(const float* __restrict__ wsA, const float* __restrict__ wsB, float* __restrict__ coef, int bn, int n) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= bn) return;
+  double sA[6], sB[2];
+  fold<6>(wsA, b, sA);
+  fold<2>(wsB, b, sB);
+  const double s5[5] = {sA[0], sA[1], sA[2], sA[3], sA[4]};
+  float cd, cs;
+  diffspec_coefs(s5, (float)n, cd, cs);
+  const float cim = unit_coef(sB[0], sB[1]);
+  coef[2 * b] = cim * cd;
+  coef[2 * b + 1] = cim * cs;
+}
+
+}  // namespace sgr
+
+using namespace sgr;
+
+extern "C" int sgr_loss_workspace_floats(int bn) { return bn * kSplit * (6 + 2 + 1); }
+
+extern "C" int sgr_render_loss_fwd(const float* diffuse, const float* spec, const float* im, const float* seg,
+                                   float* im_small, float* seg_small, float* rendered, float* coef, float* parts,
+                                   float* workspace, int bn, int R, int C, int imH, int imW, void* stream) {
+  SGR_REQUIRE(diffuse && spec && im && seg && im_small && seg_small && rendered && coef && parts && workspace,
+              "sgr_render_loss_fwd: NULL tensor");
+  SGR_REQUIRE(bn > 0 && R > 0 && C > 0, "sgr_render_loss_fwd: non-positive size");
+  const bool ok = (imH == R && imW == C) || (imH == 2 * R && imW == 2 * C);
+  SGR_SUPPORTED(ok, "sgr_render_loss_fwd: image / env-grid ratio must be 1 or 2 (pool first)");
+  const hipStream_t st = (hipStream_t)stream;
+  float* wsA = workspace;
+  float* wsB = wsA + (size_t)bn * kSplit * 6;
+  float* wsC = wsB + (size_t)bn * kSplit * 2;
+  const dim3 grid(kSplit, bn), block(kLossThreads);
+  const int RC = R * C;
+  if (imH == R)
+    hipLaunchKernelGGL((loss_stage_a<1>), grid, block, 0, st, diffuse, spec, im, seg, im_small, seg_small, wsA, R, C, imH, imW);
+  else
+    hipLaunchKernelGGL((loss_stage_a<2>), grid, block, 0, st, diffuse, spec, im, seg, im_small, seg_small, wsA, R, C, imH, imW);
+  hipLaunchKernelGGL(loss_stage_b, grid, block, 0, st, diffuse, spec, im_small, wsA, wsB, 3 * RC);
+  hipLaunchKernelGGL(loss_stage_c, grid, block, 0, st, diffuse, spec, im_small, seg_small, wsA, wsB, coef, rendered, wsC, RC);
+  hipLaunchKernelGGL(loss_stage_d, dim3(1), dim3(64), 0, st, wsA, wsC, parts, bn);
+  return sgr_check((int)hipGetLastError(), "sgr_render_loss_fwd");
+}
+
+extern "C" int sgr_render_loss_bwd(const float* g_num, const float* diffuse, const float* spec, const float* im_small,
+                                   const float* seg_small, const float* coef, float* g_diffuse, float* g_spec, int bn,
+                                   int R, int C, void* stream) {
+  SGR_REQUIRE(g_num && diffuse && spec && im_small && seg_small && coef && g_diffuse && g_spec, "sgr_render_loss_bwd: NULL tensor");
+  SGR_REQUIRE(bn > 0 && R > 0 && C > 0, "sgr_render_loss_bwd: non-positive size");
+  const size_t total = (size_t)bn * 3 * R * C;
+  const int blocks = (int)((total + kLossThreads * 4 - 1) / (kLossThreads * 4));
+  hipLaunchKernelGGL(loss_bwd, dim3(blocks > 2048 ? 2048 : blocks), dim3(kLossThreads), 0, (hipStream_t)stream, g_num, diffuse,
+                     spec, im_small, seg_small, coef, g_diffuse, g_spec, R * C, total);
+  return sgr_check((int)hipGetLastError(), "sgr_render_loss_bwd");
+}
+
+extern "C" int sgr_lsregress_coef(const float* pred, const float* gt, float* coef, float* workspace, int bn, long long n,
+                                  void* stream) {
+  SGR_REQUIRE(pred && gt && coef && workspace, "sgr_lsregress_coef: NULL tensor");
+  SGR_REQUIRE(bn > 0 && n > 0, "sgr_lsregress_coef: non-positive size");
+  const hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(dot2_partial, dim3(kSplit, bn), dim3(kLossThreads), 0, st, pred, gt, workspace, (size_t)n);
+  hipLaunchKernelGGL(unit_coef_finish, dim3((bn + 63) / 64), dim3(64), 0, st, workspace, coef, bn);
+  return sgr_check((int)hipGetLastError(), "sgr_lsregress_coef");
+}
+
+extern "C" int sgr_lsregress_diffspec_coef(const float* diffuse, const float* spec, const float* im, float* coef,
+                                           float* workspace, int bn, int n, void* stream) {
+  SGR_REQUIRE(diffuse && spec && im && coef && workspace, "sgr_lsregress_diffspec_coef: NULL tensor");
+  SGR_REQUIRE(bn > 0 && n > 0, "sgr_lsregress_diffspec_coef: non-positive size");
+  const hipStream_t st = (hipStream_t)stream;
+  float* wsA = workspace;
+  float* wsB = wsA + (size_t)bn * kSplit * 6;
+  const dim3 grid(kSplit, bn), block(kLossThreads);
+  hipLaunchKernelGGL(diffspec_partial_a, grid, block, 0, st, diffuse, spec, im, wsA, n);
+  hipLaunchKernelGGL(loss_stage_b, grid, block, 0, st, diffuse, spec, im, wsA, wsB, n);
+  hipLaunchKernelGGL(diffspec_finish, dim3((bn + 63) / 64), dim3(64), 0, st, wsA, wsB, coef, bn, n);
+  return sgr_check((int)hipGetLastError(), "sgr_lsregress_diffspec_coef");
+}

@@ -1,0 +1,145 @@
+"""Scale-invariant regressions and the render loss, backed by libsgrender.so.
+
+Drop-in free functions (same names / argument meaning as the reference's ``models.py``):
+
+  ``LSregress(pred, gt, origin)``                                     models.py:7-21
+  ``LSregressDiffSpec(diff, spec, imOrig, diffOrig, specOrig)``       models.py:23-84
+
+and the fused loss glue of ``wrapperBRDFLight.py:170-171,192,197-207``:
+
+  ``render_loss(diffuse, spec, im, seg, envRow, envCol, group=None)``
+
+which keeps ``pixelNum`` on the device (the reference synchronises with ``.item()``) and, when
+the batch is sharded over ranks, all-reduces the ``[numerator, denominator]`` pair so that the
+loss is the reference's batch-global ratio.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from . import _lib
+from .layers import _ptr, _require_hip, _stream
+
+__all__ = ["LSregress", "LSregressDiffSpec", "render_loss", "combine_loss_parts"]
+
+
+def _workspace(bn: int, dev) -> torch.Tensor:
+    return torch.empty(_lib.load().sgr_loss_workspace_floats(bn), device=dev, dtype=torch.float32)
+
+
+def _no_coef_grad(*ts):
+    for t in ts:
+        if t.requires_grad:
+            raise NotImplementedError(
+                "sgrender: the regression coefficients are treated as constants (every reference call site passes "
+                "detached / data tensors for the images that define them, e.g. wrapperBRDFLight.py:197-201); "
+                "detach the first arguments")
+
+
+def LSregress(pred, gt, origin):
+    """``origin * clamp(<pred,gt> / max(<pred,pred>, 1e-5), 1e-3, 1e3)`` per image (models.py:7-21)."""
+    dev = _require_hip(pred, gt, origin)
+    _no_coef_grad(pred)
+    nb = pred.shape[0]
+    p, g = pred.detach().contiguous(), gt.detach().contiguous()
+    coef = torch.empty(nb, device=dev, dtype=torch.float32)
+    ws = _workspace(nb, dev)
+    with torch.cuda.device(dev):
+        _lib.call("sgr_lsregress_coef", _ptr(p), _ptr(g), _ptr(coef), _ptr(ws), nb, p.numel() // nb, _stream(dev))
+    return origin * coef.reshape([nb] + [1] * (origin.dim() - 1))
+
+
+def LSregressDiffSpec(diff, spec, imOrig, diffOrig, specOrig):
+    """Two-unknown (diffuse, specular) scale regression, then the one-unknown rescale of the clamped
+    sum (models.py:23-84).  Returns ``(diffScaled, specScaled)``."""
+    dev = _require_hip(diff, spec, imOrig, diffOrig, specOrig)
+    _no_coef_grad(diff, spec)
+    nb = diff.shape[0]
+    d, s, im = diff.detach().contiguous(), spec.detach().contiguous(), imOrig.detach().contiguous()
+    if d.shape != s.shape or d.shape != im.shape:
+        raise RuntimeError("sgrender: LSregressDiffSpec needs diff, spec and imOrig of one shape")
+    coef = torch.empty((nb, 2), device=dev, dtype=torch.float32)
+    ws = _workspace(nb, dev)
+    with torch.cuda.device(dev):
+        _lib.call("sgr_lsregress_diffspec_coef", _ptr(d), _ptr(s), _ptr(im), _ptr(coef), _ptr(ws), nb, d.numel() // nb,
+                  _stream(dev))
+    kd = coef[:, 0].reshape(nb, 1, 1, 1)
+    ks = coef[:, 1].reshape(nb, 1, 1, 1)
+    return kd * diffOrig, ks * specOrig
+
+
+class _RenderLossParts(torch.autograd.Function):
+    """sgr_render_loss_fwd / sgr_render_loss_bwd: ``(num, den_raw, rendered)`` of this rank's shard."""
+
+    @staticmethod
+    def forward(ctx, diffuse, spec, im, seg, R: int, C: int):
+        dev = _require_hip(diffuse, spec, im, seg)
+        d, s, im_c, seg_c = diffuse.contiguous(), spec.contiguous(), im.contiguous(), seg.contiguous()
+        bn = d.shape[0]
+        if tuple(d.shape) != (bn, 3, R, C) or tuple(s.shape) != (bn, 3, R, C):
+            raise RuntimeError(f"sgrender: diffuse/spec must be [bn,3,{R},{C}]")
+        imH, imW = im_c.shape[2], im_c.shape[3]
+        if tuple(seg_c.shape) != (bn, 1, imH, imW) or im_c.shape[1] != 3:
+            raise RuntimeError("sgrender: im must be [bn,3,h,w] and seg [bn,1,h,w]")
+        im_s = torch.empty((bn, 3, R, C), device=dev, dtype=torch.float32)
+        seg_s = torch.empty((bn, 1, R, C), device=dev, dtype=torch.float32)
+        rendered = torch.empty_like(im_s)
+        coef = torch.empty((bn, 2), device=dev, dtype=torch.float32)
+        parts = torch.empty(2, device=dev, dtype=torch.float32)
+        ws = _workspace(bn, dev)
+        with torch.cuda.device(dev):
+            _lib.call("sgr_render_loss_fwd", _ptr(d), _ptr(s), _ptr(im_c), _ptr(seg_c), _ptr(im_s), _ptr(seg_s),
+                      _ptr(rendered), _ptr(coef), _ptr(parts), _ptr(ws), bn, R, C, imH, imW, _stream(dev))
+        ctx.save_for_backward(d, s, im_s, seg_s, coef)
+        ctx.mark_non_differentiable(rendered)
+        num, den = parts[0], parts[1]
+        ctx.mark_non_differentiable(den)
+        return num, den, rendered
+
+    @staticmethod
+    def backward(ctx, g_num, _g_den, _g_ren):
+        d, s, im_s, seg_s, coef = ctx.saved_tensors
+        dev = d.device
+        bn, _, R, C = d.shape
+        g_num = g_num.contiguous().reshape(1).to(torch.float32)
+        g_d, g_s = torch.empty_like(d), torch.empty_like(s)
+        with torch.cuda.device(dev):
+            _lib.call("sgr_render_loss_bwd", _ptr(g_num), _ptr(d), _ptr(s), _ptr(im_s), _ptr(seg_s), _ptr(coef),
+                      _ptr(g_d), _ptr(g_s), bn, R, C, _stream(dev))
+        return g_d, g_s, None, None, None, None
+
+
+def combine_loss_parts(num: torch.Tensor, den_raw: torch.Tensor, group=None, divisor: float = 3.0) -> torch.Tensor:
+    """``loss = sum_ranks(num) / max(sum_ranks(den), 1e-5) / divisor`` with the gradient
+    ``d loss / d num_local = 1 / (divisor * den_global)``.
+
+    The reference's losses are ratios of two batch-global sums (wrapperBRDFLight.py:192,205-207), not
+    means of per-image losses, so under batch sharding the pair is summed across ranks first: one
+    all-reduce of two floats (RCCL over xGMI on the GPU path; pure torch + torch.distributed, so the
+    same code runs under gloo in the CPU tests)."""
+    if group is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        pair = torch.stack([num.detach(), den_raw.detach().to(num.dtype)])
+        dist.all_reduce(pair, op=dist.ReduceOp.SUM, group=group)
+        num_g, den_g = pair[0], pair[1]
+    else:
+        num_g, den_g = num.detach(), den_raw.detach()
+    den_c = torch.clamp(den_g, min=1e-5)
+    return (num + (num_g - num.detach())) / den_c / divisor
+
+
+def render_loss(diffuse, spec, im, seg, envRow: int, envCol: int, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``(renderErr, renderedImPred)`` of wrapperBRDFLight.py:170-171,192,197-207.
+
+    ``diffuse, spec [bn,3,envRow,envCol]`` (outputs of the render layer), ``im [bn,3,h,w]``,
+    ``seg [bn,1,h,w]`` (``segBRDFBatch``).  Image sizes other than 1x / 2x the env grid are
+    average-pooled with torch first (same window arithmetic as the reference)."""
+    h, w = im.shape[2], im.shape[3]
+    if (h, w) != (envRow, envCol) and (h, w) != (2 * envRow, 2 * envCol):
+        im = F.adaptive_avg_pool2d(im, (envRow, envCol))
+        seg = F.adaptive_avg_pool2d(seg, (envRow, envCol))
+    num, den, rendered = _RenderLossParts.apply(diffuse, spec, im, seg, envRow, envCol)
+    return combine_loss_parts(num, den, group), rendered
