@@ -181,9 +181,20 @@ def test_shapes_vs_oracle(sgr, shape):
     grads = torch.autograd.grad((env * ce.cuda()).sum() + (d * cd.cuda()).sum() + (s * cs.cuda()).sum(), [x[k] for k in NAMES])
     gro = torch.autograd.grad((envo * ce.double()).sum() + (do * cd.double()).sum() + (so * cs.double()).sum(),
                               [xo[k] for k in NAMES])
-    for k, a, b in zip(NAMES, grads, gro):
+    # The normal gradient is discontinuous at |N|^2 == 1 (two-sided clamp, models.py:467-468): with unit
+    # input normals and no pooling, fp32 and fp64 evaluations of |N|^2 land on different sides of the
+    # kink pixel by pixel.  The reference semantics are the fp32 ones, so that gradient is compared with
+    # the oracle evaluated in fp32.
+    x32 = {k: inp[k].clone().requires_grad_(True) for k in NAMES}
+    e32, d32, s32 = O.render_from_sg(x32["albedo"], x32["normal"], x32["rough"], x32["axis"], x32["lamb"], x32["weight"],
+                                     shape["eh"], shape["ew"])
+    g32 = torch.autograd.grad((e32 * ce).sum() + (d32 * cd).sum() + (s32 * cs).sum(), [x32[k] for k in NAMES])
+    for k, a, b, b32 in zip(NAMES, grads, gro, g32):
         assert torch.isfinite(a).all(), k
-        assert rel_l2(a.cpu(), b) < (2e-3 if k in ("normal", "rough") else 5e-4), (shape, k, rel_l2(a.cpu(), b))
+        if k == "normal":
+            assert rel_l2(a.cpu(), b32) < 2e-3, (shape, k, rel_l2(a.cpu(), b32))
+        else:
+            assert rel_l2(a.cpu(), b) < (2e-3 if k == "rough" else 5e-4), (shape, k, rel_l2(a.cpu(), b))
 
 
 def test_full_size_properties(sgr):
