@@ -39,11 +39,15 @@ int sgr_abi_version(void);
 const char* sgr_last_error(void);
 
 /* Direction table of output2env.__init__ (models.py:353-363) and renderingLayer.__init__
- * (models.py:437-452), device layout used by every kernel below:
+ * (models.py:437-452), device layout used by every kernel below (`dirs` argument):
  *   dirs[j*4 + {0,1,2,3}] = (l_x, l_y, l_z, omega_j),  j = e*ew + a,  padded with zero rows
- *   up to a multiple of 32 directions.  Host-side helper: fills `out` (host memory,
- *   4*sgr_dirs_padded(eh*ew) floats). */
+ *   up to Jpad = sgr_dirs_padded(eh*ew) directions (a multiple of 32); followed by the same
+ *   table in separable form (l_j = (s_e ca_a, s_e sa_a, c_e)):
+ *   rows[e*8 + ..] = (s_e, c_e, omega_e, s_e^2, 2 s_e c_e, c_e^2, 0, 0)  for e < eh rounded up to even,
+ *   cols[a*8 + ..] = (ca_a, sa_a, ca_a^2, 2 ca_a sa_a, sa_a^2, 0, 0, 0)  for a < ew.
+ * Host-side helper: fills `out_host` (sgr_dirs_floats(eh, ew) floats of host memory). */
 int sgr_dirs_padded(int J);
+int sgr_dirs_floats(int eh, int ew);
 int sgr_fill_direction_table(float* out_host, int eh, int ew);
 
 /* View vectors of renderingLayer.__init__ (models.py:415-430): out_host[3*R*C]. */

@@ -37,6 +37,7 @@ SIGNATURES = {
     "sgr_abi_version": ([], c_int),
     "sgr_last_error": ([], c_char_p),
     "sgr_dirs_padded": ([_I], c_int),
+    "sgr_dirs_floats": ([_I, _I], c_int),
     "sgr_fill_direction_table": ([_P, _I, _I], c_int),
     "sgr_fill_view_vectors": ([_P, _I, _I, _F, _P], c_int),
     "sgr_sg_to_env_fwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], c_int),

@@ -27,6 +27,8 @@ extern "C" int sgr_abi_version(void) { return SGR_ABI_VERSION; }
 extern "C" const char* sgr_last_error(void) { return sgr::g_err; }
 
 extern "C" int sgr_dirs_padded(int J) { return (J + 31) / 32 * 32; }
+static int rows_padded(int eh) { return (eh + 1) / 2 * 2; }
+extern "C" int sgr_dirs_floats(int eh, int ew) { return 4 * sgr_dirs_padded(eh * ew) + 8 * rows_padded(eh) + 8 * ew; }
 
 // models.py:353-363 (output2env.__init__) and models.py:437-452 (renderingLayer.__init__):
 // float64 arithmetic, results stored as float32; the evaluation order of the scalar
@@ -34,7 +36,23 @@ extern "C" int sgr_dirs_padded(int J) { return (J + 31) / 32 * 32; }
 extern "C" int sgr_fill_direction_table(float* out, int eh, int ew) {
   SGR_REQUIRE(out && eh > 0 && ew > 0, "sgr_fill_direction_table: bad argument");
   const int J = eh * ew, Jp = sgr_dirs_padded(J);
-  memset(out, 0, sizeof(float) * 4 * (size_t)Jp);
+  memset(out, 0, sizeof(float) * (size_t)sgr_dirs_floats(eh, ew));
+  // separable form: l_j = (s_e ca_a, s_e sa_a, c_e); rows (s, c, omega, s^2, 2sc, c^2), cols (ca, sa, ca^2, 2 ca sa, sa^2)
+  float* rows = out + 4 * (size_t)Jp;
+  float* cols = rows + 8 * (size_t)rows_padded(eh);
+  for (int e = 0; e < eh; ++e) {
+    const double el = (((double)e + 0.5) / (double)eh) * M_PI / 2.0;
+    const double sd = sin(el), cd = cos(el);
+    float* o = rows + 8 * (size_t)e;
+    o[0] = (float)sd; o[1] = (float)cd; o[2] = (float)(sd * M_PI * M_PI / (double)ew / (double)eh);
+    o[3] = (float)(sd * sd); o[4] = (float)(2.0 * sd * cd); o[5] = (float)(cd * cd);
+  }
+  for (int a = 0; a < ew; ++a) {
+    const double az = ((((double)a + 0.5) / (double)ew) - 0.5) * 2.0 * M_PI;
+    const double cad = cos(az), sad = sin(az);
+    float* o = cols + 8 * (size_t)a;
+    o[0] = (float)cad; o[1] = (float)sad; o[2] = (float)(cad * cad); o[3] = (float)(2.0 * cad * sad); o[4] = (float)(sad * sad);
+  }
   for (int e = 0; e < eh; ++e) {
     const double el = (((double)e + 0.5) / (double)eh) * M_PI / 2.0;
     for (int a = 0; a < ew; ++a) {

@@ -12,8 +12,10 @@
 //   dL/da_k   = lam_k sum_j T_kj l_j     and through the pre-map y = tan(pi/2 * 0.999 x):
 //   dL/dx     = dL/dy * 0.999 * pi/2 * (1 + y^2)                         (models.py:396-400)
 #pragma once
+#include <stdlib.h>
 #include "sgr_common.h"
 #include "sgr_launch.h"
+#include "sgr_fast.inl"
 
 #ifndef SGR_TJ
 #define SGR_TJ 32
@@ -37,13 +39,14 @@ __global__ __launch_bounds__(kWave, 1) void sg_bwd_kernel(const Args a) {
   if (HAS_RENDER) {
     float alb[3];
     f = load_frame<POOL>(a, x, alb);
-    const size_t o = (size_t)b * 3 * RC + p;
-    gd0 = a.g_diffuse[o] * (alb[0] * kInvPi);
-    gd1 = a.g_diffuse[o + RC] * (alb[1] * kInvPi);
-    gd2 = a.g_diffuse[o + 2 * (size_t)RC] * (alb[2] * kInvPi);
-    gs0 = a.g_spec[o];
-    gs1 = a.g_spec[o + RC];
-    gs2 = a.g_spec[o + 2 * (size_t)RC];
+    const size_t o = (size_t)b * 3 * RC;
+    const unsigned up = (unsigned)p;
+    gd0 = (a.g_diffuse + o)[up] * (alb[0] * kInvPi);
+    gd1 = (a.g_diffuse + o + RC)[up] * (alb[1] * kInvPi);
+    gd2 = (a.g_diffuse + o + 2 * (size_t)RC)[up] * (alb[2] * kInvPi);
+    gs0 = (a.g_spec + o)[up];
+    gs1 = (a.g_spec + o + RC)[up];
+    gs2 = (a.g_spec + o + 2 * (size_t)RC)[up];
   }
   const DirTable dirs = as_dir_table(a.dirs);
   const size_t img = (size_t)b * 3 * RC * a.J;
@@ -57,12 +60,13 @@ __global__ __launch_bounds__(kWave, 1) void sg_bwd_kernel(const Args a) {
       ax[k] = ay[k] = az[k] = lam[k] = w0[k] = w1[k] = w2[k] = 0.0f;
       gax[k] = gay[k] = gaz[k] = glam[k] = gw0[k] = gw1[k] = gw2[k] = 0.0f;
       if (kg + k < K) {
-        const size_t ab = ((size_t)(b * K + kg + k) * 3) * RC + p;
-        ax[k] = a.axis[ab];
-        ay[k] = a.axis[ab + RC];
-        az[k] = a.axis[ab + 2 * (size_t)RC];
-        float l = a.lamb[(size_t)(b * K + kg + k) * RC + p];
-        float t0 = a.weight[ab], t1 = a.weight[ab + RC], t2 = a.weight[ab + 2 * (size_t)RC];
+        const size_t ab = ((size_t)(b * K + kg + k) * 3) * RC;
+        const unsigned up = (unsigned)p;
+        ax[k] = (a.axis + ab)[up];
+        ay[k] = (a.axis + ab + RC)[up];
+        az[k] = (a.axis + ab + 2 * (size_t)RC)[up];
+        float l = (a.lamb + (size_t)(b * K + kg + k) * RC)[up];
+        float t0 = (a.weight + ab)[up], t1 = (a.weight + ab + RC)[up], t2 = (a.weight + ab + 2 * (size_t)RC)[up];
         if (a.premap) {
           l = premap(l);
           t0 = premap(t0); t1 = premap(t1); t2 = premap(t2);
@@ -119,20 +123,21 @@ __global__ __launch_bounds__(kWave, 1) void sg_bwd_kernel(const Args a) {
 #pragma unroll
       for (int k = 0; k < KP; ++k) {
         if (kg + k < K) {
-          const size_t ab = ((size_t)(b * K + kg + k) * 3) * RC + p;
-          const size_t lb = (size_t)(b * K + kg + k) * RC + p;
-          a.g_axis[ab] = lam[k] * gax[k];
-          a.g_axis[ab + RC] = lam[k] * gay[k];
-          a.g_axis[ab + 2 * (size_t)RC] = lam[k] * gaz[k];
+          const size_t ab = ((size_t)(b * K + kg + k) * 3) * RC;
+          const size_t lb = (size_t)(b * K + kg + k) * RC;
+          const unsigned up = (unsigned)p;
+          (a.g_axis + ab)[up] = lam[k] * gax[k];
+          (a.g_axis + ab + RC)[up] = lam[k] * gay[k];
+          (a.g_axis + ab + 2 * (size_t)RC)[up] = lam[k] * gaz[k];
           float gl = glam[k], q0 = gw0[k], q1 = gw1[k], q2 = gw2[k];
           if (a.premap) {
             gl *= premap_grad(lam[k]);
             q0 *= premap_grad(w0[k]); q1 *= premap_grad(w1[k]); q2 *= premap_grad(w2[k]);
           }
-          a.g_lamb[lb] = gl;
-          a.g_weight[ab] = q0;
-          a.g_weight[ab + RC] = q1;
-          a.g_weight[ab + 2 * (size_t)RC] = q2;
+          (a.g_lamb + lb)[up] = gl;
+          (a.g_weight + ab)[up] = q0;
+          (a.g_weight + ab + RC)[up] = q1;
+          (a.g_weight + ab + 2 * (size_t)RC)[up] = q2;
         }
       }
     }
@@ -149,11 +154,12 @@ __global__ __launch_bounds__(kWave, 2) void render_genv_kernel(const Args a) {
   const int RC = a.R * a.C;
   float alb[3];
   const Frame f = load_frame<POOL>(a, x, alb);
-  const size_t o = (size_t)b * 3 * RC + p;
-  const float gd0 = a.g_diffuse[o] * (alb[0] * kInvPi);
-  const float gd1 = a.g_diffuse[o + RC] * (alb[1] * kInvPi);
-  const float gd2 = a.g_diffuse[o + 2 * (size_t)RC] * (alb[2] * kInvPi);
-  const float gs0 = a.g_spec[o], gs1 = a.g_spec[o + RC], gs2 = a.g_spec[o + 2 * (size_t)RC];
+  const size_t o = (size_t)b * 3 * RC;
+  const unsigned up = (unsigned)p;
+  const float gd0 = (a.g_diffuse + o)[up] * (alb[0] * kInvPi);
+  const float gd1 = (a.g_diffuse + o + RC)[up] * (alb[1] * kInvPi);
+  const float gd2 = (a.g_diffuse + o + 2 * (size_t)RC)[up] * (alb[2] * kInvPi);
+  const float gs0 = (a.g_spec + o)[up], gs1 = (a.g_spec + o + RC)[up], gs2 = (a.g_spec + o + 2 * (size_t)RC)[up];
   const DirTable dirs = as_dir_table(a.dirs);
   const size_t img = (size_t)b * 3 * RC * a.J;
   for (int j0 = 0; j0 < a.Jpad; j0 += TJ) {
@@ -197,8 +203,20 @@ static int sgbwd_launch_k(const Args& a, hipStream_t st) {
   return sgbwd_launch_vec<12, POOL, HAS_GENV, HAS_RENDER>(a, st);
 }
 
+template <int EW, bool HAS_GENV, bool HAS_RENDER>
+static int sgbwd_fast_launch_pool(const Args& a, hipStream_t st) {
+  const dim3 grid = wave_grid(a.bn, a.R, a.C), block(kWave);
+  if (!HAS_RENDER || (a.imH == a.R && a.imW == a.C))
+    hipLaunchKernelGGL((sg_bwd_fast_kernel<12, 1, EW, HAS_GENV, HAS_RENDER>), grid, block, 0, st, a);
+  else
+    hipLaunchKernelGGL((sg_bwd_fast_kernel<12, 2, EW, HAS_GENV, HAS_RENDER>), grid, block, 0, st, a);
+  return (int)hipGetLastError();
+}
+
 template <bool HAS_GENV, bool HAS_RENDER>
 static int sgbwd_launch(const Args& a, hipStream_t st) {
+  if (fast_ok(a) && !getenv("SGR_GENERIC"))
+    return a.ew == 16 ? sgbwd_fast_launch_pool<16, HAS_GENV, HAS_RENDER>(a, st) : sgbwd_fast_launch_pool<32, HAS_GENV, HAS_RENDER>(a, st);
   if (!HAS_RENDER || (a.imH == a.R && a.imW == a.C)) return sgbwd_launch_k<1, HAS_GENV, HAS_RENDER>(a, st);
   return sgbwd_launch_k<2, HAS_GENV, HAS_RENDER>(a, st);
 }
@@ -211,6 +229,9 @@ static inline int check_pool_b(int R, int C, int imH, int imW, const char* who) 
 
 static inline void set_dims_b(Args& a, int bn, int K, int R, int C, int eh, int ew, int imH, int imW) {
   a.bn = bn; a.K = K; a.R = R; a.C = C; a.J = eh * ew; a.Jpad = sgr_dirs_padded(a.J); a.imH = imH; a.imW = imW;
+  a.eh = eh; a.ew = ew;
+  a.rows = reinterpret_cast<const float*>(a.dirs) + 4 * (size_t)a.Jpad;
+  a.cols = a.rows + 8 * (size_t)((eh + 1) / 2 * 2);
 }
 
 }  // namespace sgr

@@ -94,18 +94,18 @@ __global__ __launch_bounds__(kWave, 1) void brdf_bwd_kernel(const Args a) {
   float gpn[3], gprho;
   frame_bwd(pooled[3], pooled[4], pooled[5], pooled[6], f, g, gpn, gprho);
   if (x.active) {
-    const int r = p / a.C, c = p - r * a.C;
+    const unsigned off = pooled_offset<POOL>(p, a.C, a.imW);
     const size_t plane = (size_t)a.imH * a.imW;
     float* ga = a.g_albedo + (size_t)b * 3 * plane;
     float* gn = a.g_normal + (size_t)b * 3 * plane;
     float* gr = a.g_rough + (size_t)b * plane;
-    scatter_pooled<POOL>(ga, r, c, a.imW, gD0 * kInvPi * ds0);
-    scatter_pooled<POOL>(ga + plane, r, c, a.imW, gD1 * kInvPi * ds1);
-    scatter_pooled<POOL>(ga + 2 * plane, r, c, a.imW, gD2 * kInvPi * ds2);
-    scatter_pooled<POOL>(gn, r, c, a.imW, gpn[0]);
-    scatter_pooled<POOL>(gn + plane, r, c, a.imW, gpn[1]);
-    scatter_pooled<POOL>(gn + 2 * plane, r, c, a.imW, gpn[2]);
-    scatter_pooled<POOL>(gr, r, c, a.imW, gprho);
+    scatter_pooled<POOL>(ga, off, a.imW, gD0 * kInvPi * ds0);
+    scatter_pooled<POOL>(ga + plane, off, a.imW, gD1 * kInvPi * ds1);
+    scatter_pooled<POOL>(ga + 2 * plane, off, a.imW, gD2 * kInvPi * ds2);
+    scatter_pooled<POOL>(gn, off, a.imW, gpn[0]);
+    scatter_pooled<POOL>(gn + plane, off, a.imW, gpn[1]);
+    scatter_pooled<POOL>(gn + 2 * plane, off, a.imW, gpn[2]);
+    scatter_pooled<POOL>(gr, off, a.imW, gprho);
   }
 }
 

@@ -18,12 +18,33 @@ namespace sgr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef SGR_NT
+#define SGR_NT 1   // non-temporal hint on the streamed env tiles (A/B switch)
+#endif
+__device__ __forceinline__ void stream_store(f32x4 v, f32x4* p) {
+#if SGR_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ f32x4 stream_load(const f32x4* p) {
+#if SGR_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+
 // The direction table is read-only for the lifetime of every kernel and indexed wave-uniformly.
 // Reading it through the constant address space makes the compiler emit scalar loads
 // (s_load_dwordx4 -> SGPR operands) instead of per-lane vector loads, even though the kernel
 // also stores to global memory through other pointers.
 typedef const f32x4 __attribute__((address_space(4))) * DirTable;
 __device__ __forceinline__ DirTable as_dir_table(const float4* p) { return (DirTable)(p); }
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef const f32x8 __attribute__((address_space(4))) * SepTable;
+__device__ __forceinline__ SepTable as_sep_table(const float* p) { return (SepTable)(p); }
 
 constexpr int kWave = 64;        // pixels per workgroup (one wavefront)
 // LDS env tile: 64 pixels x TJ directions x RGB, rows padded by 4 dwords (16-B aligned rows,
@@ -39,30 +60,37 @@ template <int TJ> struct Tile {
 
 // ---- env tile <-> global (coalesced: 8 lanes cover one pixel's 128-byte segment) ----------
 // tile[c][row][col], row = pixel within the wave's run, col = direction within the chunk.
+// Addressing discipline (all hot kernels): a wave-uniform 64-bit base (SGPR pair) plus ONE 32-bit
+// per-lane offset, so global accesses select the `saddr + voffset` form and no 64-bit per-lane
+// addresses are kept live in VGPRs (hoisted per-lane addresses were the dominant register hog).
 template <int TJ, bool VEC>
 __device__ __forceinline__ void tile_store_global(const float* tile, float* __restrict__ env_img /* [3,RC,J] of image b */,
                                                   int p0, int RC, int J, int j0, int lane) {
+  const int lrow = lane / Tile<TJ>::kLanesPerRow;
+  const int col = (lane % Tile<TJ>::kLanesPerRow) * 4;
+  const unsigned lane_off = (unsigned)(lrow * J + col);
+  const int rows_valid = RC - p0;
+  const bool col_ok = (j0 + col) < J;
 #pragma unroll 1   // one colour (<= 32 VGPRs of payload) in flight at a time
   for (int c = 0; c < 3; ++c) {
+    float* cbase = env_img + ((size_t)c * RC + p0) * J + j0;   // wave-uniform
 #pragma unroll
     for (int it = 0; it < Tile<TJ>::kIts; ++it) {
-      const int row = it * Tile<TJ>::kRowsPerIt + lane / Tile<TJ>::kLanesPerRow;
-      const int col = (lane % Tile<TJ>::kLanesPerRow) * 4;
-      const int px = p0 + row;
-      const int j = j0 + col;
+      const int row = it * Tile<TJ>::kRowsPerIt + lrow;
       const float4 v = *reinterpret_cast<const float4*>(tile + (c * kWave + row) * Tile<TJ>::kStride + col);
-      if (px < RC) {
-        float* dst = env_img + ((size_t)c * RC + px) * J + j;
+      float* dst = cbase + (size_t)(it * Tile<TJ>::kRowsPerIt) * J;   // uniform
+      if (row < rows_valid) {
         if (VEC) {
-          if (j < J) {
+          if (col_ok) {
             f32x4 nv = {v.x, v.y, v.z, v.w};
-            __builtin_nontemporal_store(nv, reinterpret_cast<f32x4*>(dst));
+            stream_store(nv, reinterpret_cast<f32x4*>(dst + lane_off));
           }
         } else {
-          if (j + 0 < J) dst[0] = v.x;
-          if (j + 1 < J) dst[1] = v.y;
-          if (j + 2 < J) dst[2] = v.z;
-          if (j + 3 < J) dst[3] = v.w;
+          const int j = j0 + col;
+          if (j + 0 < J) dst[lane_off + 0] = v.x;
+          if (j + 1 < J) dst[lane_off + 1] = v.y;
+          if (j + 2 < J) dst[lane_off + 2] = v.z;
+          if (j + 3 < J) dst[lane_off + 3] = v.w;
         }
       }
     }
@@ -72,27 +100,31 @@ __device__ __forceinline__ void tile_store_global(const float* tile, float* __re
 template <int TJ, bool VEC>
 __device__ __forceinline__ void tile_load_global(float* tile, const float* __restrict__ env_img, int p0, int RC, int J,
                                                  int j0, int lane) {
-#pragma unroll 1   // one colour (<= 32 VGPRs of payload) in flight at a time
+  const int lrow = lane / Tile<TJ>::kLanesPerRow;
+  const int col = (lane % Tile<TJ>::kLanesPerRow) * 4;
+  const unsigned lane_off = (unsigned)(lrow * J + col);
+  const int rows_valid = RC - p0;
+  const bool col_ok = (j0 + col) < J;
+#pragma unroll 1
   for (int c = 0; c < 3; ++c) {
+    const float* cbase = env_img + ((size_t)c * RC + p0) * J + j0;   // wave-uniform
 #pragma unroll
     for (int it = 0; it < Tile<TJ>::kIts; ++it) {
-      const int row = it * Tile<TJ>::kRowsPerIt + lane / Tile<TJ>::kLanesPerRow;
-      const int col = (lane % Tile<TJ>::kLanesPerRow) * 4;
-      const int px = p0 + row;
-      const int j = j0 + col;
+      const int row = it * Tile<TJ>::kRowsPerIt + lrow;
+      const float* src = cbase + (size_t)(it * Tile<TJ>::kRowsPerIt) * J;   // uniform
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (px < RC) {
-        const float* src = env_img + ((size_t)c * RC + px) * J + j;
+      if (row < rows_valid) {
         if (VEC) {
-          if (j < J) {
-            const f32x4 nv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+          if (col_ok) {
+            const f32x4 nv = stream_load(reinterpret_cast<const f32x4*>(src + lane_off));
             v = make_float4(nv.x, nv.y, nv.z, nv.w);
           }
         } else {
-          if (j + 0 < J) v.x = src[0];
-          if (j + 1 < J) v.y = src[1];
-          if (j + 2 < J) v.z = src[2];
-          if (j + 3 < J) v.w = src[3];
+          const int j = j0 + col;
+          if (j + 0 < J) v.x = src[lane_off + 0];
+          if (j + 1 < J) v.y = src[lane_off + 1];
+          if (j + 2 < J) v.z = src[lane_off + 2];
+          if (j + 3 < J) v.w = src[lane_off + 3];
         }
       }
       *reinterpret_cast<float4*>(tile + (c * kWave + row) * Tile<TJ>::kStride + col) = v;
@@ -103,15 +135,22 @@ __device__ __forceinline__ void tile_load_global(float* tile, const float* __res
 // ---- pooled BRDF-map fetch ---------------------------------------------------------------
 // POOL == 1: maps are already on the env grid.  POOL == 2: 2x2 average (the integer-ratio
 // case of F.adaptive_avg_pool2d, models.py:465-469), read as two 8-byte loads per plane.
+// `plane` is wave-uniform; `off` is the lane's 32-bit offset of its cell's top-left image pixel
+// (r*imW + c for POOL 1, 2r*imW + 2c for POOL 2).
 template <int POOL>
-__device__ __forceinline__ float fetch_pooled(const float* __restrict__ plane, int r, int c, int imW) {
+__device__ __forceinline__ float fetch_pooled(const float* __restrict__ plane, unsigned off, int imW) {
   if (POOL == 1) {
-    return plane[(size_t)r * imW + c];
+    return plane[off];
   } else {
-    const float2 t = *reinterpret_cast<const float2*>(plane + (size_t)(2 * r) * imW + 2 * c);
-    const float2 u = *reinterpret_cast<const float2*>(plane + (size_t)(2 * r + 1) * imW + 2 * c);
+    const float2 t = *reinterpret_cast<const float2*>(plane + off);
+    const float2 u = *reinterpret_cast<const float2*>(plane + imW + off);
     return (((t.x + t.y) + u.x) + u.y) * 0.25f;
   }
+}
+template <int POOL>
+__device__ __forceinline__ unsigned pooled_offset(int p, int C, int imW) {
+  const int r = p / C, c = p - r * C;
+  return POOL == 1 ? (unsigned)(r * imW + c) : (unsigned)(2 * r * imW + 2 * c);
 }
 
 // ---- kernel argument block (superset used by every hot kernel) ------------------------------
@@ -126,6 +165,8 @@ struct Args {
   const float* weight;    // [bn,3K,R,C]   channel k*3 + rgb
   const float* env_in;    // [bn,3,R,C,J]
   const float4* dirs;     // [Jpad] (lx, ly, lz, omega)
+  const float* rows;      // [ehp,8] (s, c, omega, s^2, 2sc, c^2, 0, 0)   separable form of the table
+  const float* cols;      // [ew,8]  (ca, sa, ca^2, 2 ca sa, sa^2, 0, 0, 0)
   const float* view;      // [3,R,C]
   // cotangents
   const float* g_env;     // [bn,3,R,C,J]
@@ -144,7 +185,7 @@ struct Args {
   float* g_albedo;        // [bn,3,imH,imW]
   float* g_normal;        // [bn,3,imH,imW]
   float* g_rough;         // [bn,1,imH,imW]
-  int bn, K, R, C, J, Jpad, imH, imW;
+  int bn, K, R, C, J, Jpad, imH, imW, eh, ew;
   float F0;
   int premap;
 };
@@ -173,19 +214,20 @@ static inline dim3 wave_grid(int bn, int R, int C) {
 template <int POOL>
 __device__ __forceinline__ Frame load_frame_pooled(const Args& a, const Pix& x, float pooled[7]) {
   const int RC = a.R * a.C;
-  const int r = x.p / a.C, c = x.p - r * a.C;
+  const unsigned off = pooled_offset<POOL>(x.p, a.C, a.imW);
+  const unsigned up = (unsigned)x.p;
   const size_t plane = (size_t)a.imH * a.imW;
-  const float* al = a.albedo + (size_t)x.b * 3 * plane;
+  const float* al = a.albedo + (size_t)x.b * 3 * plane;     // wave-uniform bases
   const float* no = a.normal + (size_t)x.b * 3 * plane;
   const float* ro = a.rough + (size_t)x.b * plane;
-  pooled[0] = fetch_pooled<POOL>(al, r, c, a.imW);
-  pooled[1] = fetch_pooled<POOL>(al + plane, r, c, a.imW);
-  pooled[2] = fetch_pooled<POOL>(al + 2 * plane, r, c, a.imW);
-  pooled[3] = fetch_pooled<POOL>(no, r, c, a.imW);
-  pooled[4] = fetch_pooled<POOL>(no + plane, r, c, a.imW);
-  pooled[5] = fetch_pooled<POOL>(no + 2 * plane, r, c, a.imW);
-  pooled[6] = fetch_pooled<POOL>(ro, r, c, a.imW);
-  return make_frame(pooled[3], pooled[4], pooled[5], pooled[6], a.view[x.p], a.view[RC + x.p], a.view[2 * RC + x.p]);
+  pooled[0] = fetch_pooled<POOL>(al, off, a.imW);
+  pooled[1] = fetch_pooled<POOL>(al + plane, off, a.imW);
+  pooled[2] = fetch_pooled<POOL>(al + 2 * plane, off, a.imW);
+  pooled[3] = fetch_pooled<POOL>(no, off, a.imW);
+  pooled[4] = fetch_pooled<POOL>(no + plane, off, a.imW);
+  pooled[5] = fetch_pooled<POOL>(no + 2 * plane, off, a.imW);
+  pooled[6] = fetch_pooled<POOL>(ro, off, a.imW);
+  return make_frame(pooled[3], pooled[4], pooled[5], pooled[6], a.view[up], (a.view + RC)[up], (a.view + 2 * RC)[up]);
 }
 template <int POOL>
 __device__ __forceinline__ Frame load_frame(const Args& a, const Pix& x, float alb[3]) {
@@ -197,13 +239,13 @@ __device__ __forceinline__ Frame load_frame(const Args& a, const Pix& x, float a
 
 // Adjoint of fetch_pooled: the env cell's gradient goes to its POOL x POOL image pixels / POOL^2.
 template <int POOL>
-__device__ __forceinline__ void scatter_pooled(float* __restrict__ plane, int r, int c, int imW, float g) {
+__device__ __forceinline__ void scatter_pooled(float* __restrict__ plane, unsigned off, int imW, float g) {
   if (POOL == 1) {
-    plane[(size_t)r * imW + c] = g;
+    plane[off] = g;
   } else {
     const float q = 0.25f * g;
-    *reinterpret_cast<float2*>(plane + (size_t)(2 * r) * imW + 2 * c) = make_float2(q, q);
-    *reinterpret_cast<float2*>(plane + (size_t)(2 * r + 1) * imW + 2 * c) = make_float2(q, q);
+    *reinterpret_cast<float2*>(plane + off) = make_float2(q, q);
+    *reinterpret_cast<float2*>(plane + imW + off) = make_float2(q, q);
   }
 }
 

@@ -1,0 +1,344 @@
+// Fast-path kernels for the reference's direction grids (envWidth 16 or 32, any envHeight):
+// the hemisphere table is a tensor product  l_j = (s_e ca_a, s_e sa_a, c_e),  j = e*EW + a, and
+// the azimuths are antisymmetric (ca, sa)(a + EW/2) = -(ca, sa)(a).  Per lobe k and direction j
+//
+//     lam (a_k . l_j - 1) = s_e * U_ka + C_ke ,     U_ka = lam (ax ca_a + ay sa_a),  C_ke = lam (az c_e - 1)
+//
+// so one FMA (with +-s_e as an SGPR operand) replaces the 3-FMA dot product + scale, U_ka serves the
+// 2*RPC directions (e, a), (e, a + EW/2) of a chunk and C_ke all EW azimuths of a row.  The
+// microfacet terms use the same factorisation in the local frame (sgr_math.h: brdf_local_dir).
+// Everything else (lanes <-> pixels, LDS-transposed env tiles) is as in sgr_common.h.
+#pragma once
+#include "sgr_common.h"
+#include "sgr_launch.h"
+
+namespace sgr {
+
+template <int KP>
+struct Lobes {   // raw or folded SG parameters of the lane's pixel
+  float ax[KP], ay[KP], az[KP], lp[KP], w0[KP], w1[KP], w2[KP];
+};
+
+// FOLD: ax,ay,az are pre-multiplied by lp = lam*log2e (forward); otherwise unit axes (backward).
+template <int KP, bool FOLD>
+__device__ __forceinline__ void load_lobes(const Args& a, const Pix& x, int kg, Lobes<KP>& L, bool write_tan) {
+  const int RC = a.R * a.C, K = a.K;
+#pragma unroll
+  for (int k = 0; k < KP; ++k) {
+    L.ax[k] = L.ay[k] = L.az[k] = L.lp[k] = L.w0[k] = L.w1[k] = L.w2[k] = 0.0f;
+    if (kg + k < K) {
+      const size_t ab = ((size_t)(x.b * K + kg + k) * 3) * RC;   // wave-uniform plane bases
+      const size_t lb = (size_t)(x.b * K + kg + k) * RC;
+      const unsigned up = (unsigned)x.p;                          // the lane's 32-bit offset
+      float ax = (a.axis + ab)[up], ay = (a.axis + ab + RC)[up], az = (a.axis + ab + 2 * (size_t)RC)[up];
+      float l = (a.lamb + lb)[up];
+      float t0 = (a.weight + ab)[up], t1 = (a.weight + ab + RC)[up], t2 = (a.weight + ab + 2 * (size_t)RC)[up];
+      if (a.premap) {
+        l = premap(l);
+        t0 = premap(t0); t1 = premap(t1); t2 = premap(t2);
+        if (write_tan && x.active) {
+          if (a.lamb_tan) (a.lamb_tan + lb)[up] = l;
+          if (a.weight_tan) {
+            (a.weight_tan + ab)[up] = t0; (a.weight_tan + ab + RC)[up] = t1; (a.weight_tan + ab + 2 * (size_t)RC)[up] = t2;
+          }
+        }
+      }
+      const float lp = l * kLog2e;
+      L.lp[k] = lp;
+      if (FOLD) { ax *= lp; ay *= lp; az *= lp; }
+      L.ax[k] = ax; L.ay[k] = ay; L.az[k] = az;
+      L.w0[k] = t0; L.w1[k] = t1; L.w2[k] = t2;
+    }
+  }
+}
+
+// ============================== forward ==========================================================
+template <int KP, int POOL, int EW, bool WRITE_ENV, bool DO_RENDER>
+__global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
+  constexpr int TJ = 32;
+  constexpr int RPC = TJ / EW;      // table rows per 32-direction chunk (2 for EW=16, 1 for EW=32)
+  constexpr int HALF = EW / 2;
+  constexpr int NQ = HALF / 4;      // azimuth quads per half row
+  __shared__ __attribute__((aligned(16))) float tile[WRITE_ENV ? Tile<TJ>::kFloats : 4];
+
+  const Pix x = locate(a);
+  const int lane = x.lane, b = x.b, p = x.p;
+  const int RC = a.R * a.C;
+
+  Lobes<KP> L;
+  load_lobes<KP, true>(a, x, 0, L, true);
+
+  PixLocal q;
+  float alb[3] = {0.f, 0.f, 0.f};
+  if (DO_RENDER) {
+    const Frame f = load_frame<POOL>(a, x, alb);
+    q = make_local(f, a.F0);
+  }
+  float d0 = 0.f, d1 = 0.f, d2 = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  const SepTable rows = as_sep_table(a.rows), cols = as_sep_table(a.cols);
+  const size_t img = (size_t)b * 3 * RC * a.J;
+  const int ehp = (a.eh + 1) & ~1;
+
+  for (int e0 = 0; e0 < ehp; e0 += RPC) {
+    float sr[RPC], om[RPC], s2r[RPC], scr[RPC];
+    float Ck[KP][RPC], Cv[RPC], Cn[RPC], Cz[RPC];
+#pragma unroll
+    for (int r = 0; r < RPC; ++r) {
+      const f32x8 row = rows[e0 + r];
+      sr[r] = row[0]; om[r] = row[2]; s2r[r] = row[3]; scr[r] = row[4];
+#pragma unroll
+      for (int k = 0; k < KP; ++k) Ck[k][r] = fmaf(L.az[k], row[1], -L.lp[k]);
+      if (DO_RENDER) {
+        Cv[r] = q.vBz * row[1];
+        Cn[r] = q.nBz * row[1];
+        Cz[r] = q.Gzz * row[5];
+      }
+    }
+#pragma unroll 1
+    for (int aq = 0; aq < NQ; ++aq) {
+      float acc[RPC][2][3][4];   // [row][sign][colour][azimuth in quad]
+#pragma unroll
+      for (int r = 0; r < RPC; ++r)
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[r][sg][c][i] = 0.0f;
+
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x8 col = cols[aq * 4 + i];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+          const float U = fmaf(L.ay[k], col[1], L.ax[k] * col[0]);
+#pragma unroll
+          for (int r = 0; r < RPC; ++r) {
+            const float ep = fexp2(fmaf(sr[r], U, Ck[k][r]));
+            const float em = fexp2(fmaf(-sr[r], U, Ck[k][r]));
+            acc[r][0][0][i] = fmaf(L.w0[k], ep, acc[r][0][0][i]);
+            acc[r][0][1][i] = fmaf(L.w1[k], ep, acc[r][0][1][i]);
+            acc[r][0][2][i] = fmaf(L.w2[k], ep, acc[r][0][2][i]);
+            acc[r][1][0][i] = fmaf(L.w0[k], em, acc[r][1][0][i]);
+            acc[r][1][1][i] = fmaf(L.w1[k], em, acc[r][1][1][i]);
+            acc[r][1][2][i] = fmaf(L.w2[k], em, acc[r][1][2][i]);
+          }
+        }
+        if (DO_RENDER) {
+          const float Pv = fmaf(q.vBy, col[1], q.vBx * col[0]);
+          const float Pn = fmaf(q.nBy, col[1], q.nBx * col[0]);
+          const float Qa = fmaf(q.Gyy, col[4], fmaf(q.Gxy, col[3], q.Gxx * col[2]));
+          const float Ra = fmaf(q.Gyz, col[1], q.Gxz * col[0]);
+#pragma unroll
+          for (int r = 0; r < RPC; ++r) {
+#pragma unroll
+            for (int sg = 0; sg < 2; ++sg) {
+              const float ss = sg ? -sr[r] : sr[r];
+              const float sc = sg ? -scr[r] : scr[r];
+              const float vdl = fmaf(ss, Pv, Cv[r]);
+              const float ndr = fmaf(ss, Pn, Cn[r]);
+              const float ll = fmaf(s2r[r], Qa, fmaf(sc, Ra, Cz[r]));
+              float ndl, sp;
+              brdf_local_dir(q, vdl, ndr, ll, ndl, sp);
+              const float wt = ndl * om[r];
+              const float sw = sp * wt;
+              d0 = fmaf(wt, acc[r][sg][0][i], d0);
+              d1 = fmaf(wt, acc[r][sg][1][i], d1);
+              d2 = fmaf(wt, acc[r][sg][2][i], d2);
+              s0 = fmaf(sw, acc[r][sg][0][i], s0);
+              s1 = fmaf(sw, acc[r][sg][1][i], s1);
+              s2 = fmaf(sw, acc[r][sg][2][i], s2);
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (WRITE_ENV) {
+#pragma unroll
+        for (int r = 0; r < RPC; ++r)
+#pragma unroll
+          for (int sg = 0; sg < 2; ++sg)
+            tile_row_write<TJ>(tile, lane, r * EW + sg * HALF + aq * 4, acc[r][sg][0], acc[r][sg][1], acc[r][sg][2]);
+      }
+    }
+    if (WRITE_ENV) {
+      __syncthreads();
+      tile_store_global<TJ, true>(tile, a.env_out + img, x.p0, RC, a.J, e0 * EW, lane);
+      __syncthreads();
+    }
+  }
+
+  if (DO_RENDER && x.active) {
+    const size_t o = (size_t)b * 3 * RC;
+    const unsigned up = (unsigned)p;
+    (a.diffuse + o)[up] = (alb[0] * kInvPi) * d0;
+    (a.diffuse + o + RC)[up] = (alb[1] * kInvPi) * d1;
+    (a.diffuse + o + 2 * (size_t)RC)[up] = (alb[2] * kInvPi) * d2;
+    (a.spec + o)[up] = s0;
+    (a.spec + o + RC)[up] = s1;
+    (a.spec + o + 2 * (size_t)RC)[up] = s2;
+  }
+}
+
+// ============================== backward w.r.t. the SG parameters ================================
+// g[c,j] = gEnv[c,j] (+) omega_j ndl_j (gD_c A_c/pi + gS_c spec_j);  per lobe, with T = (g . w) E:
+//   dL/dw_c = sum g_c E,   dL/dlam = sum T t,   dL/da = lam (ca A, sa A, sum T c_e),  A_a = sum_e (+-s_e) T
+template <int KP, int POOL, int EW, bool HAS_GENV, bool HAS_RENDER>
+__global__ __launch_bounds__(kWave, 2) void sg_bwd_fast_kernel(const Args a) {
+  constexpr int TJ = 32;
+  constexpr int RPC = TJ / EW;
+  constexpr int HALF = EW / 2;
+  constexpr int NP = HALF / 2;      // azimuth pairs per half row
+  __shared__ __attribute__((aligned(16))) float tile[HAS_GENV ? Tile<TJ>::kFloats : 4];
+
+  const Pix x = locate(a);
+  const int lane = x.lane, b = x.b, p = x.p;
+  const int RC = a.R * a.C, K = a.K;
+
+  PixLocal q;
+  float gd0 = 0.f, gd1 = 0.f, gd2 = 0.f, gs0 = 0.f, gs1 = 0.f, gs2 = 0.f;
+  if (HAS_RENDER) {
+    float alb[3];
+    const Frame f = load_frame<POOL>(a, x, alb);
+    q = make_local(f, a.F0);
+    const size_t o = (size_t)b * 3 * RC;
+    const unsigned up = (unsigned)p;
+    gd0 = (a.g_diffuse + o)[up] * (alb[0] * kInvPi);
+    gd1 = (a.g_diffuse + o + RC)[up] * (alb[1] * kInvPi);
+    gd2 = (a.g_diffuse + o + 2 * (size_t)RC)[up] * (alb[2] * kInvPi);
+    gs0 = (a.g_spec + o)[up];
+    gs1 = (a.g_spec + o + RC)[up];
+    gs2 = (a.g_spec + o + 2 * (size_t)RC)[up];
+  }
+  const SepTable rows = as_sep_table(a.rows), cols = as_sep_table(a.cols);
+  const size_t img = (size_t)b * 3 * RC * a.J;
+  const int ehp = (a.eh + 1) & ~1;
+
+  for (int kg = 0; kg < K; kg += KP) {
+    Lobes<KP> L;
+    load_lobes<KP, false>(a, x, kg, L, false);
+    float gax[KP], gay[KP], gaz[KP], glam[KP], gw0[KP], gw1[KP], gw2[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) gax[k] = gay[k] = gaz[k] = glam[k] = gw0[k] = gw1[k] = gw2[k] = 0.0f;
+
+    for (int e0 = 0; e0 < ehp; e0 += RPC) {
+      if (HAS_GENV) {
+        tile_load_global<TJ, true>(tile, a.g_env + img, x.p0, RC, a.J, e0 * EW, lane);
+        __syncthreads();
+      }
+      float sr[RPC], cr[RPC], om[RPC], s2r[RPC], scr[RPC], Cv[RPC], Cn[RPC], Cz[RPC];
+#pragma unroll
+      for (int r = 0; r < RPC; ++r) {
+        const f32x8 row = rows[e0 + r];
+        sr[r] = row[0]; cr[r] = row[1]; om[r] = row[2]; s2r[r] = row[3]; scr[r] = row[4];
+        if (HAS_RENDER) {
+          Cv[r] = q.vBz * row[1];
+          Cn[r] = q.nBz * row[1];
+          Cz[r] = q.Gzz * row[5];
+        }
+      }
+#pragma unroll 1
+      for (int ap = 0; ap < NP; ++ap) {
+        float g[RPC][2][3][2];   // [row][sign][colour][azimuth in pair]
+#pragma unroll
+        for (int r = 0; r < RPC; ++r)
+#pragma unroll
+          for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              float2 v = make_float2(0.f, 0.f);
+              if (HAS_GENV)
+                v = *reinterpret_cast<const float2*>(tile + (c * kWave + lane) * Tile<TJ>::kStride + r * EW + sg * HALF + ap * 2);
+              g[r][sg][c][0] = v.x;
+              g[r][sg][c][1] = v.y;
+            }
+        float ca[2], sa[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const f32x8 col = cols[ap * 2 + i];
+          ca[i] = col[0]; sa[i] = col[1];
+          if (HAS_RENDER) {
+            const float Pv = fmaf(q.vBy, col[1], q.vBx * col[0]);
+            const float Pn = fmaf(q.nBy, col[1], q.nBx * col[0]);
+            const float Qa = fmaf(q.Gyy, col[4], fmaf(q.Gxy, col[3], q.Gxx * col[2]));
+            const float Ra = fmaf(q.Gyz, col[1], q.Gxz * col[0]);
+#pragma unroll
+            for (int r = 0; r < RPC; ++r)
+#pragma unroll
+              for (int sg = 0; sg < 2; ++sg) {
+                const float ss = sg ? -sr[r] : sr[r];
+                const float sc = sg ? -scr[r] : scr[r];
+                float ndl, sp;
+                brdf_local_dir(q, fmaf(ss, Pv, Cv[r]), fmaf(ss, Pn, Cn[r]), fmaf(s2r[r], Qa, fmaf(sc, Ra, Cz[r])), ndl, sp);
+                const float wt = ndl * om[r];
+                g[r][sg][0][i] = fmaf(wt, fmaf(gs0, sp, gd0), g[r][sg][0][i]);
+                g[r][sg][1][i] = fmaf(wt, fmaf(gs1, sp, gd1), g[r][sg][1][i]);
+                g[r][sg][2][i] = fmaf(wt, fmaf(gs2, sp, gd2), g[r][sg][2][i]);
+              }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+          float czr[RPC];
+#pragma unroll
+          for (int r = 0; r < RPC; ++r) czr[r] = fmaf(L.az[k], cr[r], -1.0f);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const float u = fmaf(L.ay[k], sa[i], L.ax[k] * ca[i]);
+            float A = 0.0f;
+#pragma unroll
+            for (int r = 0; r < RPC; ++r)
+#pragma unroll
+              for (int sg = 0; sg < 2; ++sg) {
+                const float ss = sg ? -sr[r] : sr[r];
+                const float t = fmaf(ss, u, czr[r]);
+                const float ex = fexp2(L.lp[k] * t);
+                const float c0 = g[r][sg][0][i], c1 = g[r][sg][1][i], c2 = g[r][sg][2][i];
+                gw0[k] = fmaf(c0, ex, gw0[k]);
+                gw1[k] = fmaf(c1, ex, gw1[k]);
+                gw2[k] = fmaf(c2, ex, gw2[k]);
+                const float T = fmaf(c2, L.w2[k], fmaf(c1, L.w1[k], c0 * L.w0[k])) * ex;
+                glam[k] = fmaf(T, t, glam[k]);
+                A = fmaf(ss, T, A);
+                gaz[k] = fmaf(cr[r], T, gaz[k]);
+              }
+            gax[k] = fmaf(ca[i], A, gax[k]);
+            gay[k] = fmaf(sa[i], A, gay[k]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (HAS_GENV) __syncthreads();
+    }
+
+    if (x.active) {
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        if (kg + k < K) {
+          const size_t ab = ((size_t)(b * K + kg + k) * 3) * RC;
+          const size_t lb = (size_t)(b * K + kg + k) * RC;
+          const unsigned up = (unsigned)p;
+          const float lam = L.lp[k] * kLn2;
+          (a.g_axis + ab)[up] = lam * gax[k];
+          (a.g_axis + ab + RC)[up] = lam * gay[k];
+          (a.g_axis + ab + 2 * (size_t)RC)[up] = lam * gaz[k];
+          float gl = glam[k], q0 = gw0[k], q1 = gw1[k], q2 = gw2[k];
+          if (a.premap) {
+            gl *= premap_grad(lam);
+            q0 *= premap_grad(L.w0[k]); q1 *= premap_grad(L.w1[k]); q2 *= premap_grad(L.w2[k]);
+          }
+          (a.g_lamb + lb)[up] = gl;
+          (a.g_weight + ab)[up] = q0;
+          (a.g_weight + ab + RC)[up] = q1;
+          (a.g_weight + ab + 2 * (size_t)RC)[up] = q2;
+        }
+      }
+    }
+  }
+}
+
+// fast path applies to the reference's direction grids
+static inline bool fast_ok(const Args& a) { return (a.ew == 16 || a.ew == 32); }
+
+}  // namespace sgr

@@ -1,8 +1,10 @@
 // Forward kernel template: SG -> env image, env -> (diffuse, specular), and the fused pass.
 // gfx950 (MI355X) only.  See sgr_common.h for the work decomposition.
 #pragma once
+#include <stdlib.h>
 #include "sgr_common.h"
 #include "sgr_launch.h"
+#include "sgr_fast.inl"
 
 #ifndef SGR_TJ
 #define SGR_TJ 32
@@ -33,19 +35,20 @@ __global__ __launch_bounds__(kWave, 2) void fwd_kernel(const Args a) {
     for (int k = 0; k < KP; ++k) {
       ax[k] = ay[k] = az[k] = lam[k] = w0[k] = w1[k] = w2[k] = 0.0f;
       if (k < K) {
-        const size_t ab = ((size_t)(b * K + k) * 3) * RC + p;
-        ax[k] = a.axis[ab];
-        ay[k] = a.axis[ab + RC];
-        az[k] = a.axis[ab + 2 * (size_t)RC];
-        const size_t lb = (size_t)(b * K + k) * RC + p;
-        float l = a.lamb[lb];
-        float t0 = a.weight[ab], t1 = a.weight[ab + RC], t2 = a.weight[ab + 2 * (size_t)RC];
+        const size_t ab = ((size_t)(b * K + k) * 3) * RC;   // wave-uniform plane bases + 32-bit lane offset
+        const size_t lb = (size_t)(b * K + k) * RC;
+        const unsigned up = (unsigned)p;
+        ax[k] = (a.axis + ab)[up];
+        ay[k] = (a.axis + ab + RC)[up];
+        az[k] = (a.axis + ab + 2 * (size_t)RC)[up];
+        float l = (a.lamb + lb)[up];
+        float t0 = (a.weight + ab)[up], t1 = (a.weight + ab + RC)[up], t2 = (a.weight + ab + 2 * (size_t)RC)[up];
         if (a.premap) {
           l = premap(l);
           t0 = premap(t0); t1 = premap(t1); t2 = premap(t2);
-          if (a.lamb_tan && x.active) a.lamb_tan[lb] = l;
+          if (a.lamb_tan && x.active) (a.lamb_tan + lb)[up] = l;
           if (a.weight_tan && x.active) {
-            a.weight_tan[ab] = t0; a.weight_tan[ab + RC] = t1; a.weight_tan[ab + 2 * (size_t)RC] = t2;
+            (a.weight_tan + ab)[up] = t0; (a.weight_tan + ab + RC)[up] = t1; (a.weight_tan + ab + 2 * (size_t)RC)[up] = t2;
           }
         }
         lam[k] = l * kLog2e;   // exp(lam*t) == exp2(lam*log2e*t)
@@ -111,13 +114,14 @@ __global__ __launch_bounds__(kWave, 2) void fwd_kernel(const Args a) {
   }
 
   if (DO_RENDER && x.active) {
-    const size_t o = (size_t)b * 3 * RC + p;
-    a.diffuse[o] = (alb[0] * kInvPi) * d0;
-    a.diffuse[o + RC] = (alb[1] * kInvPi) * d1;
-    a.diffuse[o + 2 * (size_t)RC] = (alb[2] * kInvPi) * d2;
-    a.spec[o] = s0;
-    a.spec[o + RC] = s1;
-    a.spec[o + 2 * (size_t)RC] = s2;
+    const size_t o = (size_t)b * 3 * RC;
+    const unsigned up = (unsigned)p;
+    (a.diffuse + o)[up] = (alb[0] * kInvPi) * d0;
+    (a.diffuse + o + RC)[up] = (alb[1] * kInvPi) * d1;
+    (a.diffuse + o + 2 * (size_t)RC)[up] = (alb[2] * kInvPi) * d2;
+    (a.spec + o)[up] = s0;
+    (a.spec + o + RC)[up] = s1;
+    (a.spec + o + 2 * (size_t)RC)[up] = s2;
   }
 }
 
@@ -143,8 +147,27 @@ static int fwd_launch_k(const Args& a, hipStream_t st) {
   return fwd_launch_vec<32, POOL, FROM_SG, WRITE_ENV, DO_RENDER>(a, st);
 }
 
+// fast path (separable table, EW in {16,32}, K <= 24)
+template <int KP, int EW, bool WRITE_ENV, bool DO_RENDER>
+static int fwd_fast_launch_pool(const Args& a, hipStream_t st) {
+  const dim3 grid = wave_grid(a.bn, a.R, a.C), block(kWave);
+  if (!DO_RENDER || (a.imH == a.R && a.imW == a.C))
+    hipLaunchKernelGGL((fwd_fast_kernel<KP, 1, EW, WRITE_ENV, DO_RENDER>), grid, block, 0, st, a);
+  else
+    hipLaunchKernelGGL((fwd_fast_kernel<KP, 2, EW, WRITE_ENV, DO_RENDER>), grid, block, 0, st, a);
+  return (int)hipGetLastError();
+}
+template <bool WRITE_ENV, bool DO_RENDER>
+static int fwd_fast_launch(const Args& a, hipStream_t st) {
+  if (a.ew == 16) return a.K <= 12 ? fwd_fast_launch_pool<12, 16, WRITE_ENV, DO_RENDER>(a, st)
+                                   : fwd_fast_launch_pool<24, 16, WRITE_ENV, DO_RENDER>(a, st);
+  return a.K <= 12 ? fwd_fast_launch_pool<12, 32, WRITE_ENV, DO_RENDER>(a, st)
+                   : fwd_fast_launch_pool<24, 32, WRITE_ENV, DO_RENDER>(a, st);
+}
+
 template <bool FROM_SG, bool WRITE_ENV, bool DO_RENDER>
 static int fwd_launch(const Args& a, hipStream_t st) {
+  if (FROM_SG && fast_ok(a) && a.K <= 24 && !getenv("SGR_GENERIC")) return fwd_fast_launch<WRITE_ENV, DO_RENDER>(a, st);
   if (!DO_RENDER || (a.imH == a.R && a.imW == a.C)) return fwd_launch_k<1, FROM_SG, WRITE_ENV, DO_RENDER>(a, st);
   return fwd_launch_k<2, FROM_SG, WRITE_ENV, DO_RENDER>(a, st);
 }
@@ -157,6 +180,9 @@ static inline int check_pool(int R, int C, int imH, int imW, const char* who) {
 
 static inline void set_dims(Args& a, int bn, int K, int R, int C, int eh, int ew, int imH, int imW) {
   a.bn = bn; a.K = K; a.R = R; a.C = C; a.J = eh * ew; a.Jpad = sgr_dirs_padded(a.J); a.imH = imH; a.imW = imW;
+  a.eh = eh; a.ew = ew;
+  a.rows = reinterpret_cast<const float*>(a.dirs) + 4 * (size_t)a.Jpad;
+  a.cols = a.rows + 8 * (size_t)((eh + 1) / 2 * 2);
 }
 
 }  // namespace sgr

@@ -25,14 +25,33 @@ def direction_table(env_height: int, env_width: int) -> Tuple[np.ndarray, np.nda
 
 
 def packed_direction_table(env_height: int, env_width: int) -> np.ndarray:
-    """Device layout ``[Jpad,4] = (lx, ly, lz, omega)``, zero rows up to a multiple of 32."""
+    """Device layout (flat float32, see include/sgrender.h): ``[Jpad,4] = (lx, ly, lz, omega)`` with zero
+    rows up to a multiple of 32, then the separable form ``rows[ehp,8] = (s, c, omega, s^2, 2sc, c^2, 0, 0)``
+    and ``cols[ew,8] = (ca, sa, ca^2, 2 ca sa, sa^2, 0, 0, 0)`` of the same table."""
     ls, omega = direction_table(env_height, env_width)
     J = ls.shape[0]
     jpad = (J + 31) // 32 * 32
-    out = np.zeros((jpad, 4), dtype=np.float32)
-    out[:J, :3] = ls
-    out[:J, 3] = omega
-    return out
+    gen = np.zeros((jpad, 4), dtype=np.float32)
+    gen[:J, :3] = ls
+    gen[:J, 3] = omega
+    az = ((np.arange(env_width) + 0.5) / env_width - 0.5) * 2 * np.pi
+    el = ((np.arange(env_height) + 0.5) / env_height) * np.pi / 2.0
+    ehp = (env_height + 1) // 2 * 2
+    rows = np.zeros((ehp, 8), dtype=np.float64)
+    s, c = np.sin(el), np.cos(el)
+    rows[:env_height, 0], rows[:env_height, 1] = s, c
+    rows[:env_height, 2] = s * np.pi * np.pi / env_width / env_height
+    rows[:env_height, 3], rows[:env_height, 4], rows[:env_height, 5] = s * s, 2 * s * c, c * c
+    cols = np.zeros((env_width, 8), dtype=np.float64)
+    ca, sa = np.cos(az), np.sin(az)
+    cols[:, 0], cols[:, 1], cols[:, 2], cols[:, 3], cols[:, 4] = ca, sa, ca * ca, 2 * ca * sa, sa * sa
+    return np.concatenate([gen.reshape(-1), rows.astype(np.float32).reshape(-1), cols.astype(np.float32).reshape(-1)])
+
+
+def generic_table_view(packed: np.ndarray, env_height: int, env_width: int) -> np.ndarray:
+    """The ``[Jpad,4]`` generic part of :func:`packed_direction_table`."""
+    jpad = (env_height * env_width + 31) // 32 * 32
+    return packed[:4 * jpad].reshape(jpad, 4)
 
 
 def view_vectors(im_width: int, im_height: int, fov_deg: float = 57.0,

@@ -200,3 +200,147 @@ void emul_brdf_bwd(const float* g_diffuse, const float* g_spec, const float* alb
 }
 
 }  // extern "C"
+
+// ---- fast path (separable direction table), mirrors csrc/sgr_fast.inl -------------------------
+extern "C" {
+
+// rows [ehp,8] = (s, c, omega, s^2, 2sc, c^2, 0, 0);  cols [ew,8] = (ca, sa, ca^2, 2 ca sa, sa^2, ...)
+void emul_fast_fwd(const float* albedo, const float* normal, const float* rough, const float* axis, const float* lamb,
+                   const float* weight, const float* rows, const float* cols, const float* view, float* env,
+                   float* diffuse, float* spec, int bn, int K, int R, int C, int eh, int ew, int imH, int imW, float F0,
+                   int do_premap) {
+  const int RC = R * C, q = imH / R, J = eh * ew, HALF = ew / 2;
+  const size_t plane = (size_t)imH * imW;
+  std::vector<float> AX(K), AY(K), AZ(K), LP(K), w0(K), w1(K), w2(K);
+  for (int b = 0; b < bn; ++b)
+    for (int p = 0; p < RC; ++p) {
+      for (int k = 0; k < K; ++k) {
+        const size_t ab = ((size_t)(b * K + k) * 3) * RC + p;
+        float l = lamb[(size_t)(b * K + k) * RC + p];
+        float t0 = weight[ab], t1 = weight[ab + RC], t2 = weight[ab + 2 * (size_t)RC];
+        if (do_premap) { l = premap(l); t0 = premap(t0); t1 = premap(t1); t2 = premap(t2); }
+        const float lp = l * kLog2e;
+        LP[k] = lp; AX[k] = axis[ab] * lp; AY[k] = axis[ab + RC] * lp; AZ[k] = axis[ab + 2 * (size_t)RC] * lp;
+        w0[k] = t0; w1[k] = t1; w2[k] = t2;
+      }
+      const int r = p / C, c = p - r * C;
+      const float* al = albedo + (size_t)b * 3 * plane;
+      const float* no = normal + (size_t)b * 3 * plane;
+      const float* ro = rough + (size_t)b * plane;
+      const float a0 = pooled(al, r, c, imW, q), a1 = pooled(al + plane, r, c, imW, q), a2 = pooled(al + 2 * plane, r, c, imW, q);
+      const Frame f = make_frame(pooled(no, r, c, imW, q), pooled(no + plane, r, c, imW, q), pooled(no + 2 * plane, r, c, imW, q),
+                                 pooled(ro, r, c, imW, q), view[p], view[RC + p], view[2 * RC + p]);
+      const PixLocal ql = make_local(f, F0);
+      float d0 = 0, d1 = 0, d2 = 0, s0 = 0, s1 = 0, s2 = 0;
+      for (int e = 0; e < eh; ++e) {
+        const float* row = rows + 8 * e;
+        const float Cv = ql.vBz * row[1], Cn = ql.nBz * row[1], Cz = ql.Gzz * row[5];
+        for (int a = 0; a < HALF; ++a) {
+          const float* col = cols + 8 * a;
+          float acc[2][3] = {{0, 0, 0}, {0, 0, 0}};
+          for (int k = 0; k < K; ++k) {
+            const float U = fmaf(AY[k], col[1], AX[k] * col[0]);
+            const float Ck = fmaf(AZ[k], row[1], -LP[k]);
+            const float ep = fexp2(fmaf(row[0], U, Ck)), em = fexp2(fmaf(-row[0], U, Ck));
+            acc[0][0] = fmaf(w0[k], ep, acc[0][0]); acc[0][1] = fmaf(w1[k], ep, acc[0][1]); acc[0][2] = fmaf(w2[k], ep, acc[0][2]);
+            acc[1][0] = fmaf(w0[k], em, acc[1][0]); acc[1][1] = fmaf(w1[k], em, acc[1][1]); acc[1][2] = fmaf(w2[k], em, acc[1][2]);
+          }
+          const float Pv = fmaf(ql.vBy, col[1], ql.vBx * col[0]);
+          const float Pn = fmaf(ql.nBy, col[1], ql.nBx * col[0]);
+          const float Qa = fmaf(ql.Gyy, col[4], fmaf(ql.Gxy, col[3], ql.Gxx * col[2]));
+          const float Ra = fmaf(ql.Gyz, col[1], ql.Gxz * col[0]);
+          for (int sg = 0; sg < 2; ++sg) {
+            const int j = e * ew + a + sg * HALF;
+            if (env)
+              for (int ch = 0; ch < 3; ++ch) env[(((size_t)b * 3 + ch) * RC + p) * J + j] = acc[sg][ch];
+            const float ss = sg ? -row[0] : row[0], sc = sg ? -row[4] : row[4];
+            float ndl, sp;
+            brdf_local_dir(ql, fmaf(ss, Pv, Cv), fmaf(ss, Pn, Cn), fmaf(row[3], Qa, fmaf(sc, Ra, Cz)), ndl, sp);
+            const float wt = ndl * row[2], sw = sp * wt;
+            d0 = fmaf(wt, acc[sg][0], d0); d1 = fmaf(wt, acc[sg][1], d1); d2 = fmaf(wt, acc[sg][2], d2);
+            s0 = fmaf(sw, acc[sg][0], s0); s1 = fmaf(sw, acc[sg][1], s1); s2 = fmaf(sw, acc[sg][2], s2);
+          }
+        }
+      }
+      const size_t o = (size_t)b * 3 * RC + p;
+      diffuse[o] = (a0 * kInvPi) * d0; diffuse[o + RC] = (a1 * kInvPi) * d1; diffuse[o + 2 * (size_t)RC] = (a2 * kInvPi) * d2;
+      spec[o] = s0; spec[o + RC] = s1; spec[o + 2 * (size_t)RC] = s2;
+    }
+}
+
+void emul_fast_sg_bwd(const float* g_env, const float* g_diffuse, const float* g_spec, const float* albedo,
+                      const float* normal, const float* rough, const float* axis, const float* lamb, const float* weight,
+                      const float* rows, const float* cols, const float* view, float* g_axis, float* g_lamb,
+                      float* g_weight, int bn, int K, int R, int C, int eh, int ew, int imH, int imW, float F0,
+                      int do_premap) {
+  const int RC = R * C, q = imH / R, J = eh * ew, HALF = ew / 2;
+  const size_t plane = (size_t)imH * imW;
+  for (int b = 0; b < bn; ++b)
+    for (int p = 0; p < RC; ++p) {
+      const int r = p / C, c = p - r * C;
+      const float* al = albedo + (size_t)b * 3 * plane;
+      const float* no = normal + (size_t)b * 3 * plane;
+      const float* ro = rough + (size_t)b * plane;
+      const float a0 = pooled(al, r, c, imW, q), a1 = pooled(al + plane, r, c, imW, q), a2 = pooled(al + 2 * plane, r, c, imW, q);
+      const Frame f = make_frame(pooled(no, r, c, imW, q), pooled(no + plane, r, c, imW, q), pooled(no + 2 * plane, r, c, imW, q),
+                                 pooled(ro, r, c, imW, q), view[p], view[RC + p], view[2 * RC + p]);
+      const PixLocal ql = make_local(f, F0);
+      const size_t o = (size_t)b * 3 * RC + p;
+      const float gd0 = g_diffuse[o] * (a0 * kInvPi), gd1 = g_diffuse[o + RC] * (a1 * kInvPi), gd2 = g_diffuse[o + 2 * (size_t)RC] * (a2 * kInvPi);
+      const float gs0 = g_spec[o], gs1 = g_spec[o + RC], gs2 = g_spec[o + 2 * (size_t)RC];
+      for (int k = 0; k < K; ++k) {
+        const size_t ab = ((size_t)(b * K + k) * 3) * RC + p;
+        const size_t lb = (size_t)(b * K + k) * RC + p;
+        const float ax = axis[ab], ay = axis[ab + RC], az = axis[ab + 2 * (size_t)RC];
+        float l = lamb[lb];
+        float w0 = weight[ab], w1 = weight[ab + RC], w2 = weight[ab + 2 * (size_t)RC];
+        if (do_premap) { l = premap(l); w0 = premap(w0); w1 = premap(w1); w2 = premap(w2); }
+        const float lp = l * kLog2e;
+        float gax = 0, gay = 0, gaz = 0, glam = 0, gw0 = 0, gw1 = 0, gw2 = 0;
+        for (int e = 0; e < eh; ++e) {
+          const float* row = rows + 8 * e;
+          const float Cv = ql.vBz * row[1], Cn = ql.nBz * row[1], Cz = ql.Gzz * row[5];
+          const float czr = fmaf(az, row[1], -1.0f);
+          for (int a = 0; a < HALF; ++a) {
+            const float* col = cols + 8 * a;
+            const float Pv = fmaf(ql.vBy, col[1], ql.vBx * col[0]);
+            const float Pn = fmaf(ql.nBy, col[1], ql.nBx * col[0]);
+            const float Qa = fmaf(ql.Gyy, col[4], fmaf(ql.Gxy, col[3], ql.Gxx * col[2]));
+            const float Ra = fmaf(ql.Gyz, col[1], ql.Gxz * col[0]);
+            const float u = fmaf(ay, col[1], ax * col[0]);
+            float A = 0;
+            for (int sg = 0; sg < 2; ++sg) {
+              const int j = e * ew + a + sg * HALF;
+              const float ss = sg ? -row[0] : row[0], sc = sg ? -row[4] : row[4];
+              float c0 = 0, c1 = 0, c2 = 0;
+              if (g_env) {
+                c0 = g_env[(((size_t)b * 3 + 0) * RC + p) * J + j];
+                c1 = g_env[(((size_t)b * 3 + 1) * RC + p) * J + j];
+                c2 = g_env[(((size_t)b * 3 + 2) * RC + p) * J + j];
+              }
+              float ndl, sp;
+              brdf_local_dir(ql, fmaf(ss, Pv, Cv), fmaf(ss, Pn, Cn), fmaf(row[3], Qa, fmaf(sc, Ra, Cz)), ndl, sp);
+              const float wt = ndl * row[2];
+              c0 = fmaf(wt, fmaf(gs0, sp, gd0), c0); c1 = fmaf(wt, fmaf(gs1, sp, gd1), c1); c2 = fmaf(wt, fmaf(gs2, sp, gd2), c2);
+              const float t = fmaf(ss, u, czr);
+              const float ex = fexp2(lp * t);
+              gw0 = fmaf(c0, ex, gw0); gw1 = fmaf(c1, ex, gw1); gw2 = fmaf(c2, ex, gw2);
+              const float T = fmaf(c2, w2, fmaf(c1, w1, c0 * w0)) * ex;
+              glam = fmaf(T, t, glam);
+              A = fmaf(ss, T, A);
+              gaz = fmaf(row[1], T, gaz);
+            }
+            gax = fmaf(col[0], A, gax);
+            gay = fmaf(col[1], A, gay);
+          }
+        }
+        const float lam = lp * kLn2;
+        g_axis[ab] = lam * gax; g_axis[ab + RC] = lam * gay; g_axis[ab + 2 * (size_t)RC] = lam * gaz;
+        if (do_premap) { glam *= premap_grad(lam); gw0 *= premap_grad(w0); gw1 *= premap_grad(w1); gw2 *= premap_grad(w2); }
+        g_lamb[lb] = glam;
+        g_weight[ab] = gw0; g_weight[ab + RC] = gw1; g_weight[ab + 2 * (size_t)RC] = gw2;
+      }
+    }
+}
+
+}  // extern "C"

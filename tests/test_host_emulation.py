@@ -52,6 +52,50 @@ def _forward(emul, z, cfg):
     return x, dirs, view, env, d, s
 
 
+def _sep_tables(eh, ew):
+    packed = tables.packed_direction_table(eh, ew)
+    jpad = (eh * ew + 31) // 32 * 32
+    ehp = (eh + 1) // 2 * 2
+    rows = np.ascontiguousarray(packed[4 * jpad:4 * jpad + 8 * ehp])
+    cols = np.ascontiguousarray(packed[4 * jpad + 8 * ehp:])
+    return rows, cols
+
+
+FAST_CASES = ["g1_q4_k12", "g3_edges"]          # envWidth 16: the separable fast path applies
+
+
+@pytest.mark.parametrize("name", FAST_CASES)
+def test_fast_path_math_vs_golden(emul, name):
+    """csrc/sgr_fast.inl's arithmetic (separable table, folded lambda, local-frame microfacet terms,
+    A/Z form of the axis gradient) against the reference outputs."""
+    from conftest import load_golden
+    z, cfg = load_golden(name)
+    x = _inputs(z)
+    bn, K, R, C, eh, ew = cfg["bn"], cfg["K"], cfg["R"], cfg["C"], cfg["eh"], cfg["ew"]
+    rows, cols = _sep_tables(eh, ew)
+    view = tables.view_vectors(C, R, cfg["fov"])
+    env = np.empty((bn, 3, R, C, eh, ew), np.float32)
+    d = np.empty((bn, 3, R, C), np.float32)
+    s = np.empty((bn, 3, R, C), np.float32)
+    emul.emul_fast_fwd(_p(x["albedo"]), _p(x["normal"]), _p(x["rough"]), _p(x["axis"]), _p(x["lamb"]), _p(x["weight"]),
+                       _p(rows), _p(cols), _p(view), _p(env), _p(d), _p(s), bn, K, R, C, eh, ew, cfg["imH"], cfg["imW"],
+                       ctypes.c_float(cfg["F0"]), 1)
+    for k, got in (("env", env), ("diffuse", d), ("spec", s)):
+        e_ref = rel_l2(z["ref32_" + k], z["ref64_" + k])
+        assert rel_l2(got, z["ref32_" + k]) < 1e-4, (name, k, rel_l2(got, z["ref32_" + k]))
+        assert rel_max(got, z["ref32_" + k]) < 2e-4, (name, k, rel_max(got, z["ref32_" + k]))
+        assert rel_l2(got, z["ref64_" + k]) < max(3 * e_ref, 3e-5), (name, k, rel_l2(got, z["ref64_" + k]), e_ref)
+    ga, gl, gw = np.empty_like(x["axis"]), np.empty_like(x["lamb"]), np.empty_like(x["weight"])
+    ct_env, ct_d, ct_s = (np.ascontiguousarray(z[k]) for k in ("ct_env", "ct_d", "ct_s"))
+    emul.emul_fast_sg_bwd(_p(ct_env), _p(ct_d), _p(ct_s), _p(x["albedo"]), _p(x["normal"]), _p(x["rough"]), _p(x["axis"]),
+                          _p(x["lamb"]), _p(x["weight"]), _p(rows), _p(cols), _p(view), _p(ga), _p(gl), _p(gw),
+                          bn, K, R, C, eh, ew, cfg["imH"], cfg["imW"], ctypes.c_float(cfg["F0"]), 1)
+    for k, got in (("axis", ga), ("lamb", gl), ("weight", gw)):
+        e_ref = rel_l2(z["ref32_glin_" + k], z["ref64_glin_" + k])
+        e = rel_l2(got, z["ref64_glin_" + k])
+        assert e < max(3 * e_ref, 3e-5), (name, k, e, e_ref)
+
+
 def test_premap_accuracy(emul):
     """tan(pi/2*0.999*x) of the kernels vs float64 on the whole decoder range, incl. x == 1."""
     x = np.concatenate([np.linspace(0, 1, 200001), 1 - np.logspace(-7, -1, 4001), [0.0, 1.0]]).astype(np.float32)
@@ -131,6 +175,7 @@ def test_c_tables_match_numpy():
     lib = _lib.load()
     for eh, ew in [(8, 16), (16, 32), (4, 8), (3, 5)]:
         want = tables.packed_direction_table(eh, ew)
+        assert lib.sgr_dirs_floats(eh, ew) == want.size
         got = np.empty_like(want)
         assert lib.sgr_fill_direction_table(got.ctypes.data, eh, ew) == 0
         assert np.abs(got - want).max() <= 1.2e-7

@@ -1,0 +1,105 @@
+// Kernel-level timing of every C-ABI entry point (development tool; not product).
+//   hipcc -O2 tools/kbench.cpp -o tools/kbench -ldl ;  tools/kbench [lib.so] [bn] [reps]
+// Times each entry point with HIP events on one stream at BASELINE config 2 shapes
+// (240x320 -> 120x160, K=12, 8x16) and prints us per launch and algorithmic GB/s.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <functional>
+#include <vector>
+
+#include "../include/sgrender.h"
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+
+static float* dev_rand(size_t n, float lo, float hi, unsigned seed) {
+  std::vector<float> h(n);
+  unsigned s = seed * 2654435761u + 12345u;
+  for (size_t i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; h[i] = lo + (hi - lo) * ((s >> 8) * (1.0f / 16777216.0f)); }
+  float* d; CHECK(hipMalloc(&d, n * 4)); CHECK(hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice)); return d;
+}
+static float* dev_unit3(size_t groups, size_t plane, unsigned seed) {   // [groups,3,plane] unit vectors (z biased up)
+  std::vector<float> h(groups * 3 * plane);
+  unsigned s = seed * 747796405u + 1u;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) * (1.0f / 16777216.0f)) * 2.0f - 1.0f; };
+  for (size_t g = 0; g < groups; ++g)
+    for (size_t i = 0; i < plane; ++i) {
+      float x = rnd(), y = rnd(), z = fabsf(rnd()) + 0.5f; float n = sqrtf(x * x + y * y + z * z);
+      h[(g * 3 + 0) * plane + i] = x / n; h[(g * 3 + 1) * plane + i] = y / n; h[(g * 3 + 2) * plane + i] = z / n;
+    }
+  float* d; CHECK(hipMalloc(&d, h.size() * 4)); CHECK(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice)); return d;
+}
+static float* dev_empty(size_t n) { float* d; CHECK(hipMalloc(&d, n * 4)); CHECK(hipMemset(d, 0, n * 4)); return d; }
+
+int main(int argc, char** argv) {
+  const char* libpath = argc > 1 ? argv[1] : "inverserenderingofindoorscene_amd/libsgrender.so";
+  const int bn = argc > 2 ? atoi(argv[2]) : 16;
+  const int reps = argc > 3 ? atoi(argv[3]) : 20;
+  void* lib = dlopen(libpath, RTLD_NOW);
+  if (!lib) { printf("dlopen failed: %s\n", dlerror()); return 1; }
+#define SYM(name) auto name##_p = (decltype(&name))dlsym(lib, #name); if (!name##_p) { printf("missing %s\n", #name); return 1; }
+  SYM(sgr_fill_direction_table) SYM(sgr_fill_view_vectors) SYM(sgr_dirs_floats)
+  SYM(sgr_sg_to_env_fwd) SYM(sgr_render_env_fwd) SYM(sgr_fused_fwd) SYM(sgr_sg_to_env_bwd) SYM(sgr_fused_bwd_sg)
+  SYM(sgr_render_env_bwd_env) SYM(sgr_render_bwd_brdf) SYM(sgr_render_loss_fwd) SYM(sgr_render_loss_bwd) SYM(sgr_loss_workspace_floats)
+  const int imH = 240, imW = 320, R = 120, C = 160, K = 12, eh = 8, ew = 16, J = eh * ew, q = 4;
+  const size_t RC = (size_t)R * C, P = (size_t)bn * RC;
+  const float F0d = 0.05f;
+  // tables
+  const int nd = sgr_dirs_floats_p(eh, ew);
+  std::vector<float> hd(nd), hv(3 * RC);
+  sgr_fill_direction_table_p(hd.data(), eh, ew);
+  sgr_fill_view_vectors_p(hv.data(), R, C, 57.0f, nullptr);
+  float *dirs, *view; CHECK(hipMalloc(&dirs, nd * 4)); CHECK(hipMemcpy(dirs, hd.data(), nd * 4, hipMemcpyHostToDevice));
+  CHECK(hipMalloc(&view, 3 * RC * 4)); CHECK(hipMemcpy(view, hv.data(), 3 * RC * 4, hipMemcpyHostToDevice));
+  float* albedo = dev_rand((size_t)bn * 3 * imH * imW, 0, 1, 1);
+  float* normal = dev_unit3(bn, (size_t)imH * imW, 2);
+  float* rough = dev_rand((size_t)bn * imH * imW, -1, 1, 3);
+  float* axis = dev_unit3((size_t)bn * K, RC, 4);
+  float* lamb = dev_rand(P * K, 0, 1, 5);
+  float* weight = dev_rand(P * K * 3, 0, 1, 6);
+  float* im = dev_rand((size_t)bn * 3 * imH * imW, 0, 1, 7);
+  float* seg = dev_rand((size_t)bn * imH * imW, 0.5f, 1, 8);
+  float* env = dev_empty(P * 3 * J);
+  float* g_env = dev_rand(P * 3 * J, -1e-3f, 1e-3f, 9);
+  float* diffuse = dev_empty(P * 3); float* spec = dev_empty(P * 3);
+  float* g_d = dev_rand(P * 3, -1, 1, 10); float* g_s = dev_rand(P * 3, -1, 1, 11);
+  float* g_axis = dev_empty(P * K * 3); float* g_lamb = dev_empty(P * K); float* g_weight = dev_empty(P * K * 3);
+  float* g_alb = dev_empty((size_t)bn * 3 * imH * imW); float* g_nrm = dev_empty((size_t)bn * 3 * imH * imW); float* g_rgh = dev_empty((size_t)bn * imH * imW);
+  float* lam_t = dev_empty(P * K); float* w_t = dev_empty(P * K * 3);
+  float* im_s = dev_empty(P * 3); float* seg_s = dev_empty(P); float* rendered = dev_empty(P * 3); float* coef = dev_empty(bn * 2);
+  float* parts = dev_empty(2); float* ws = dev_empty(sgr_loss_workspace_floats_p(bn)); float* g_num = dev_rand(1, 1, 1, 12);
+  hipStream_t st; CHECK(hipStreamCreate(&st));
+  hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  const double Bbrdf = 7 * q * 4, Bsg = 7 * K * 4, Benv = 3 * J * 4, Bout = 24;
+
+  auto bench = [&](const char* name, double bytes_per_px, std::function<int()> fn) {
+    int rc = fn(); if (rc) { printf("%-34s FAILED rc=%d\n", name, rc); return; }
+    CHECK(hipStreamSynchronize(st));
+    for (int i = 0; i < 2; ++i) fn();
+    CHECK(hipEventRecord(e0, st));
+    for (int i = 0; i < reps; ++i) fn();
+    CHECK(hipEventRecord(e1, st)); CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / reps;
+    printf("%-34s %9.1f us   %7.1f GB/s algorithmic (%5.1f%% of 8 TB/s)   %7.1f Mshade/s\n", name, us,
+           bytes_per_px * P / us * 1e-3, bytes_per_px * P / us * 1e-3 / 80.0, P / us);
+  };
+  printf("# %s  bn=%d  P=%zu shaded px  reps=%d  SGR_GENERIC=%s\n", libpath, bn, P, reps, getenv("SGR_GENERIC") ? "1" : "0");
+  bench("sgr_fused_fwd (env written)", Bbrdf + Bsg + Benv + Bout, [&] { return sgr_fused_fwd_p(albedo, normal, rough, axis, lamb, weight, dirs, view, env, diffuse, spec, bn, K, R, C, eh, ew, imH, imW, F0d, 1, st); });
+  bench("sgr_fused_fwd (render only)", Bbrdf + Bsg + Bout, [&] { return sgr_fused_fwd_p(albedo, normal, rough, axis, lamb, weight, dirs, view, (float*)nullptr, diffuse, spec, bn, K, R, C, eh, ew, imH, imW, F0d, 1, st); });
+  bench("sgr_sg_to_env_fwd (+tan outputs)", Bsg + Benv + Bsg * 4.0 / 7.0, [&] { return sgr_sg_to_env_fwd_p(axis, lamb, weight, dirs, env, lam_t, w_t, bn, K, R, C, eh, ew, 1, st); });
+  bench("sgr_render_env_fwd", Bbrdf + Benv + Bout, [&] { return sgr_render_env_fwd_p(albedo, normal, rough, env, dirs, view, diffuse, spec, bn, R, C, eh, ew, imH, imW, F0d, st); });
+  bench("sgr_fused_bwd_sg (g_env + gD,gS)", Bbrdf + Bsg + Bout + Benv + Bsg, [&] { return sgr_fused_bwd_sg_p(g_env, g_d, g_s, albedo, normal, rough, axis, lamb, weight, dirs, view, g_axis, g_lamb, g_weight, bn, K, R, C, eh, ew, imH, imW, F0d, 1, st); });
+  bench("sgr_fused_bwd_sg (gD,gS only)", Bbrdf + Bsg + Bout + Bsg, [&] { return sgr_fused_bwd_sg_p((float*)nullptr, g_d, g_s, albedo, normal, rough, axis, lamb, weight, dirs, view, g_axis, g_lamb, g_weight, bn, K, R, C, eh, ew, imH, imW, F0d, 1, st); });
+  bench("sgr_sg_to_env_bwd", Bsg + Benv + Bsg, [&] { return sgr_sg_to_env_bwd_p(g_env, axis, lamb, weight, dirs, g_axis, g_lamb, g_weight, bn, K, R, C, eh, ew, 1, st); });
+  bench("sgr_render_env_bwd_env", Bbrdf + Bout + Benv, [&] { return sgr_render_env_bwd_env_p(g_d, g_s, albedo, normal, rough, dirs, view, env, bn, R, C, eh, ew, imH, imW, F0d, st); });
+  bench("sgr_render_bwd_brdf (env given)", 2 * Bbrdf + Bout + Benv, [&] { return sgr_render_bwd_brdf_p(g_d, g_s, albedo, normal, rough, g_env, (float*)nullptr, (float*)nullptr, (float*)nullptr, dirs, view, g_alb, g_nrm, g_rgh, bn, K, R, C, eh, ew, imH, imW, F0d, 1, st); });
+  bench("sgr_render_bwd_brdf (from SG)", 2 * Bbrdf + Bout + Bsg, [&] { return sgr_render_bwd_brdf_p(g_d, g_s, albedo, normal, rough, (float*)nullptr, axis, lamb, weight, dirs, view, g_alb, g_nrm, g_rgh, bn, K, R, C, eh, ew, imH, imW, F0d, 1, st); });
+  bench("sgr_render_loss_fwd (4 kernels)", 3 * 4 * q + 4 * q + 24 + 12 + 4 + 12 + 36, [&] { return sgr_render_loss_fwd_p(diffuse, spec, im, seg, im_s, seg_s, rendered, coef, parts, ws, bn, R, C, imH, imW, st); });
+  bench("sgr_render_loss_bwd", 24 + 12 + 4 + 24, [&] { return sgr_render_loss_bwd_p(g_num, diffuse, spec, im_s, seg_s, coef, g_d, g_s, bn, R, C, st); });
+  return 0;
+}
