@@ -132,6 +132,88 @@ __device__ __forceinline__ void tile_load_global(float* tile, const float* __res
   }
 }
 
+// ---- env tile via LDS-DMA (global_load_lds_dwordx4): no VGPR staging, loads stay in flight -------
+// One wave-instruction moves 64 x 16 B = 1 KB from per-lane global addresses to a LINEAR 1 KB of LDS,
+// so the tile is unpadded [3][64][TJ] and bank conflicts are avoided by an XOR swizzle of the 16-byte
+// slots within a row, applied on the SOURCE column (the lane that fills physical slot s of row r
+// fetches logical column s ^ swz(r)) and again by the reader.  swz(r) = (r / rows_per_256B) & (slots-1)
+// makes the 16 lanes of a ds_read_b128 group hit 16 different slots (conflict-free) and a 32-lane
+// ds_read_b64 group 2-way.
+template <int TJ> struct DmaTile {
+  static constexpr int kSlots = TJ / 4;                 // 16-byte slots per row
+  static constexpr int kRowsPerInstr = kWave / kSlots;
+  static constexpr int kInstrPerColour = kWave / kRowsPerInstr;
+  static constexpr int kInstr = 3 * kInstrPerColour;    // DMA instructions per tile
+  static constexpr int kFloats = 3 * kWave * TJ;
+  static constexpr int kRowsPerBankRow = 64 / TJ;
+  __device__ static __forceinline__ int swz(int row) { return (row / kRowsPerBankRow) & (kSlots - 1); }
+};
+
+typedef void __attribute__((address_space(3))) * LdsPtr;
+
+// Buffer resource over one image's env tensor ([3,RC,J] floats): DMA addresses are then
+// {SGPR descriptor, SGPR byte offset, one 32-bit VGPR byte offset} -- no 64-bit per-lane pointers --
+// and reads past the image return 0 (hardware bounds check).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t env_rsrc(const float* img, int RC, int J) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(img), 0, (int)((size_t)3 * RC * J * 4), 0x00020000);
+}
+
+// Issue the DMA for tile (p0.., j0..j0+TJ) of the image behind `rsrc`.  Requires j0 + TJ <= J.
+template <int TJ>
+__device__ __forceinline__ void tile_dma_issue(float* tile, __amdgpu_buffer_rsrc_t rsrc, int p0, int RC, int J, int j0, int lane) {
+  using D = DmaTile<TJ>;
+  const int lrow = lane / D::kSlots, slot = lane % D::kSlots;
+#pragma unroll
+  for (int it = 0; it < D::kInstrPerColour; ++it) {
+    const int row = it * D::kRowsPerInstr + lrow;
+    const int col4 = slot ^ D::swz(row);
+    const int voff = (row * J + col4 * 4) * 4;                           // the lane's byte offset (32-bit)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int soff = (int)((((size_t)c * RC + p0) * J + j0) * 4);      // wave-uniform byte offset
+      float* dst = tile + (c * kWave + it * D::kRowsPerInstr) * TJ;      // wave-uniform, + lane*16 B implicitly
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)dst, 16, voff, soff, 0, 0);
+    }
+  }
+}
+// The lane's own row of the DMA tile: directions (jjA, jjA+1) and (jjB, jjB+1) of all three colours.
+// The reads are inline asm on purpose: for a ds_read the compiler can see, it drains EVERY outstanding
+// LDS-DMA first (s_waitcnt vmcnt(0)), which would serialise the prefetch of the next row with the
+// consumption of this one.  Ordering is ours: the caller has waited (counted vmcnt) for this tile,
+// and nothing uses the outputs before the lgkmcnt(0) below.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+  return (unsigned)(unsigned long)((const float __attribute__((address_space(3)))*)p);
+}
+template <int TJ>
+__device__ __forceinline__ void tile_dma_read_pairs(const float* tile, int lane, int jjA, int jjB, float (&g)[2][3][2]) {
+  using D = DmaTile<TJ>;
+  const unsigned rowb = lds_addr(tile) + (unsigned)(lane * TJ * 4);
+  const unsigned aA = rowb + (unsigned)((((jjA >> 2) ^ D::swz(lane)) * 4 + (jjA & 3)) * 4);
+  const unsigned aB = rowb + (unsigned)((((jjB >> 2) ^ D::swz(lane)) * 4 + (jjB & 3)) * 4);
+  f32x2 r[2][3];
+  asm volatile("ds_read_b64 %0, %1" : "=v"(r[0][0]) : "v"(aA) : "memory");
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r[0][1]) : "v"(aA), "n"(1 * kWave * TJ * 4) : "memory");
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r[0][2]) : "v"(aA), "n"(2 * kWave * TJ * 4) : "memory");
+  asm volatile("ds_read_b64 %0, %1" : "=v"(r[1][0]) : "v"(aB) : "memory");
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r[1][1]) : "v"(aB), "n"(1 * kWave * TJ * 4) : "memory");
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r[1][2]) : "v"(aB), "n"(2 * kWave * TJ * 4) : "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      g[sg][c][0] = r[sg][c].x;
+      g[sg][c][1] = r[sg][c].y;
+    }
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt();
+template <> __device__ __forceinline__ void wait_vmcnt<0>() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vmcnt<6>() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vmcnt<12>() { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vmcnt<24>() { asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); }
+
 // ---- pooled BRDF-map fetch ---------------------------------------------------------------
 // POOL == 1: maps are already on the env grid.  POOL == 2: 2x2 average (the integer-ratio
 // case of F.adaptive_avg_pool2d, models.py:465-469), read as two 8-byte loads per plane.

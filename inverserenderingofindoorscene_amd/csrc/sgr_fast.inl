@@ -53,10 +53,10 @@ __device__ __forceinline__ void load_lobes(const Args& a, const Pix& x, int kg, 
 }
 
 // ============================== forward ==========================================================
-template <int KP, int POOL, int EW, bool WRITE_ENV, bool DO_RENDER>
+template <int KP, int POOL, int EW, int TJ, bool WRITE_ENV, bool DO_RENDER>
 __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
-  constexpr int TJ = 32;
-  constexpr int RPC = TJ / EW;      // table rows per 32-direction chunk (2 for EW=16, 1 for EW=32)
+  static_assert(TJ % EW == 0, "a tile holds whole table rows");
+  constexpr int RPC = TJ / EW;      // table rows per tile (TJ=32: 2 for EW=16, 1 for EW=32)
   constexpr int HALF = EW / 2;
   constexpr int NQ = HALF / 4;      // azimuth quads per half row
   __shared__ __attribute__((aligned(16))) float tile[WRITE_ENV ? Tile<TJ>::kFloats : 4];
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
   float d0 = 0.f, d1 = 0.f, d2 = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
   const SepTable rows = as_sep_table(a.rows), cols = as_sep_table(a.cols);
   const size_t img = (size_t)b * 3 * RC * a.J;
-  const int ehp = (a.eh + 1) & ~1;
+  const int ehp = RPC == 2 ? ((a.eh + 1) & ~1) : a.eh;
 
   for (int e0 = 0; e0 < ehp; e0 += RPC) {
     float sr[RPC], om[RPC], s2r[RPC], scr[RPC];
@@ -183,13 +183,16 @@ __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
 // ============================== backward w.r.t. the SG parameters ================================
 // g[c,j] = gEnv[c,j] (+) omega_j ndl_j (gD_c A_c/pi + gS_c spec_j);  per lobe, with T = (g . w) E:
 //   dL/dw_c = sum g_c E,   dL/dlam = sum T t,   dL/da = lam (ca A, sa A, sum T c_e),  A_a = sum_e (+-s_e) T
+// The env cotangent arrives one table row (EW directions) at a time by LDS-DMA, double-buffered for
+// EW = 16 (2 x 12 KB): the next row's 12 DMA instructions are in flight while this row is consumed.
 template <int KP, int POOL, int EW, bool HAS_GENV, bool HAS_RENDER>
 __global__ __launch_bounds__(kWave, 2) void sg_bwd_fast_kernel(const Args a) {
-  constexpr int TJ = 32;
-  constexpr int RPC = TJ / EW;
+  constexpr int TJ = EW;
   constexpr int HALF = EW / 2;
   constexpr int NP = HALF / 2;      // azimuth pairs per half row
-  __shared__ __attribute__((aligned(16))) float tile[HAS_GENV ? Tile<TJ>::kFloats : 4];
+  constexpr int NBUF = (EW == 16) ? 2 : 1;
+  using D = DmaTile<TJ>;
+  __shared__ __attribute__((aligned(16))) float tile[HAS_GENV ? NBUF * D::kFloats : 4];
 
   const Pix x = locate(a);
   const int lane = x.lane, b = x.b, p = x.p;
@@ -211,8 +214,8 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_fast_kernel(const Args a) {
     gs2 = (a.g_spec + o + 2 * (size_t)RC)[up];
   }
   const SepTable rows = as_sep_table(a.rows), cols = as_sep_table(a.cols);
-  const size_t img = (size_t)b * 3 * RC * a.J;
-  const int ehp = (a.eh + 1) & ~1;
+  __amdgpu_buffer_rsrc_t gimg = env_rsrc(HAS_GENV ? a.g_env + (size_t)b * 3 * RC * a.J : a.view, RC, a.J);
+  const int eh = a.eh;
 
   for (int kg = 0; kg < K; kg += KP) {
     Lobes<KP> L;
@@ -221,37 +224,37 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_fast_kernel(const Args a) {
 #pragma unroll
     for (int k = 0; k < KP; ++k) gax[k] = gay[k] = gaz[k] = glam[k] = gw0[k] = gw1[k] = gw2[k] = 0.0f;
 
-    for (int e0 = 0; e0 < ehp; e0 += RPC) {
+    if (HAS_GENV) tile_dma_issue<TJ>(tile, gimg, x.p0, RC, a.J, 0, lane);
+
+    for (int e = 0; e < eh; ++e) {
+      const float* cur = tile + (NBUF == 2 ? (e & 1) * D::kFloats : 0);
       if (HAS_GENV) {
-        tile_load_global<TJ, true>(tile, a.g_env + img, x.p0, RC, a.J, e0 * EW, lane);
-        __syncthreads();
-      }
-      float sr[RPC], cr[RPC], om[RPC], s2r[RPC], scr[RPC], Cv[RPC], Cn[RPC], Cz[RPC];
-#pragma unroll
-      for (int r = 0; r < RPC; ++r) {
-        const f32x8 row = rows[e0 + r];
-        sr[r] = row[0]; cr[r] = row[1]; om[r] = row[2]; s2r[r] = row[3]; scr[r] = row[4];
-        if (HAS_RENDER) {
-          Cv[r] = q.vBz * row[1];
-          Cn[r] = q.nBz * row[1];
-          Cz[r] = q.Gzz * row[5];
+        if (NBUF == 2 && e + 1 < eh) {
+          tile_dma_issue<TJ>(tile + ((e + 1) & 1) * D::kFloats, gimg, x.p0, RC, a.J, (e + 1) * EW, lane);
+          wait_vmcnt<D::kInstr>();     // row e has landed; row e+1 stays in flight
+        } else {
+          wait_vmcnt<0>();
         }
+      }
+      const f32x8 row = rows[e];
+      const float sr = row[0], cr = row[1], om = row[2], s2r = row[3], scr = row[4];
+      float Cv = 0.f, Cn = 0.f, Cz = 0.f;
+      if (HAS_RENDER) {
+        Cv = q.vBz * cr;
+        Cn = q.nBz * cr;
+        Cz = q.Gzz * row[5];
       }
 #pragma unroll 1
       for (int ap = 0; ap < NP; ++ap) {
-        float g[RPC][2][3][2];   // [row][sign][colour][azimuth in pair]
-#pragma unroll
-        for (int r = 0; r < RPC; ++r)
+        float g[2][3][2];   // [sign][colour][azimuth in pair]
+        if (HAS_GENV) {
+          tile_dma_read_pairs<TJ>(cur, lane, ap * 2, HALF + ap * 2, g);
+        } else {
 #pragma unroll
           for (int sg = 0; sg < 2; ++sg)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              float2 v = make_float2(0.f, 0.f);
-              if (HAS_GENV)
-                v = *reinterpret_cast<const float2*>(tile + (c * kWave + lane) * Tile<TJ>::kStride + r * EW + sg * HALF + ap * 2);
-              g[r][sg][c][0] = v.x;
-              g[r][sg][c][1] = v.y;
-            }
+            for (int c = 0; c < 3; ++c) g[sg][c][0] = g[sg][c][1] = 0.0f;
+        }
         float ca[2], sa[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -263,53 +266,47 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_fast_kernel(const Args a) {
             const float Qa = fmaf(q.Gyy, col[4], fmaf(q.Gxy, col[3], q.Gxx * col[2]));
             const float Ra = fmaf(q.Gyz, col[1], q.Gxz * col[0]);
 #pragma unroll
-            for (int r = 0; r < RPC; ++r)
-#pragma unroll
-              for (int sg = 0; sg < 2; ++sg) {
-                const float ss = sg ? -sr[r] : sr[r];
-                const float sc = sg ? -scr[r] : scr[r];
-                float ndl, sp;
-                brdf_local_dir(q, fmaf(ss, Pv, Cv[r]), fmaf(ss, Pn, Cn[r]), fmaf(s2r[r], Qa, fmaf(sc, Ra, Cz[r])), ndl, sp);
-                const float wt = ndl * om[r];
-                g[r][sg][0][i] = fmaf(wt, fmaf(gs0, sp, gd0), g[r][sg][0][i]);
-                g[r][sg][1][i] = fmaf(wt, fmaf(gs1, sp, gd1), g[r][sg][1][i]);
-                g[r][sg][2][i] = fmaf(wt, fmaf(gs2, sp, gd2), g[r][sg][2][i]);
-              }
+            for (int sg = 0; sg < 2; ++sg) {
+              const float ss = sg ? -sr : sr;
+              const float sc = sg ? -scr : scr;
+              float ndl, sp;
+              brdf_local_dir(q, fmaf(ss, Pv, Cv), fmaf(ss, Pn, Cn), fmaf(s2r, Qa, fmaf(sc, Ra, Cz)), ndl, sp);
+              const float wt = ndl * om;
+              g[sg][0][i] = fmaf(wt, fmaf(gs0, sp, gd0), g[sg][0][i]);
+              g[sg][1][i] = fmaf(wt, fmaf(gs1, sp, gd1), g[sg][1][i]);
+              g[sg][2][i] = fmaf(wt, fmaf(gs2, sp, gd2), g[sg][2][i]);
+            }
           }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < KP; ++k) {
-          float czr[RPC];
-#pragma unroll
-          for (int r = 0; r < RPC; ++r) czr[r] = fmaf(L.az[k], cr[r], -1.0f);
+          const float czr = fmaf(L.az[k], cr, -1.0f);
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
             const float u = fmaf(L.ay[k], sa[i], L.ax[k] * ca[i]);
             float A = 0.0f;
 #pragma unroll
-            for (int r = 0; r < RPC; ++r)
-#pragma unroll
-              for (int sg = 0; sg < 2; ++sg) {
-                const float ss = sg ? -sr[r] : sr[r];
-                const float t = fmaf(ss, u, czr[r]);
-                const float ex = fexp2(L.lp[k] * t);
-                const float c0 = g[r][sg][0][i], c1 = g[r][sg][1][i], c2 = g[r][sg][2][i];
-                gw0[k] = fmaf(c0, ex, gw0[k]);
-                gw1[k] = fmaf(c1, ex, gw1[k]);
-                gw2[k] = fmaf(c2, ex, gw2[k]);
-                const float T = fmaf(c2, L.w2[k], fmaf(c1, L.w1[k], c0 * L.w0[k])) * ex;
-                glam[k] = fmaf(T, t, glam[k]);
-                A = fmaf(ss, T, A);
-                gaz[k] = fmaf(cr[r], T, gaz[k]);
-              }
+            for (int sg = 0; sg < 2; ++sg) {
+              const float ss = sg ? -sr : sr;
+              const float t = fmaf(ss, u, czr);
+              const float ex = fexp2(L.lp[k] * t);
+              const float c0 = g[sg][0][i], c1 = g[sg][1][i], c2 = g[sg][2][i];
+              gw0[k] = fmaf(c0, ex, gw0[k]);
+              gw1[k] = fmaf(c1, ex, gw1[k]);
+              gw2[k] = fmaf(c2, ex, gw2[k]);
+              const float T = fmaf(c2, L.w2[k], fmaf(c1, L.w1[k], c0 * L.w0[k])) * ex;
+              glam[k] = fmaf(T, t, glam[k]);
+              A = fmaf(ss, T, A);
+              gaz[k] = fmaf(cr, T, gaz[k]);
+            }
             gax[k] = fmaf(ca[i], A, gax[k]);
             gay[k] = fmaf(sa[i], A, gay[k]);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (HAS_GENV) __syncthreads();
+      if (HAS_GENV && NBUF == 1 && e + 1 < eh) tile_dma_issue<TJ>(tile, gimg, x.p0, RC, a.J, (e + 1) * EW, lane);
     }
 
     if (x.active) {
@@ -335,6 +332,84 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_fast_kernel(const Args a) {
         }
       }
     }
+  }
+}
+
+// ============================== forwardEnv alone (env image read) =================================
+// The un-fused drop-in call renderingLayer.forwardEnv (models.py:461-522): HBM-bound (1672 B/px in,
+// ~45 VALU slots per direction), so the env rows stream in by double-buffered LDS-DMA exactly like the
+// cotangent rows of the backward pass.
+template <int POOL, int EW>
+__global__ __launch_bounds__(kWave, 4) void render_fast_kernel(const Args a) {
+  constexpr int TJ = EW;
+  constexpr int HALF = EW / 2;
+  constexpr int NP = HALF / 2;
+  constexpr int NBUF = (EW == 16) ? 2 : 1;
+  using D = DmaTile<TJ>;
+  __shared__ __attribute__((aligned(16))) float tile[NBUF * D::kFloats];
+
+  const Pix x = locate(a);
+  const int lane = x.lane, b = x.b, p = x.p;
+  const int RC = a.R * a.C;
+  float alb[3];
+  const Frame f = load_frame<POOL>(a, x, alb);
+  const PixLocal q = make_local(f, a.F0);
+  const SepTable rows = as_sep_table(a.rows), cols = as_sep_table(a.cols);
+  __amdgpu_buffer_rsrc_t eimg = env_rsrc(a.env_in + (size_t)b * 3 * RC * a.J, RC, a.J);
+  const int eh = a.eh;
+  float d0 = 0.f, d1 = 0.f, d2 = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
+
+  tile_dma_issue<TJ>(tile, eimg, x.p0, RC, a.J, 0, lane);
+  for (int e = 0; e < eh; ++e) {
+    const float* cur = tile + (NBUF == 2 ? (e & 1) * D::kFloats : 0);
+    if (NBUF == 2 && e + 1 < eh) {
+      tile_dma_issue<TJ>(tile + ((e + 1) & 1) * D::kFloats, eimg, x.p0, RC, a.J, (e + 1) * EW, lane);
+      wait_vmcnt<D::kInstr>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    const f32x8 row = rows[e];
+    const float sr = row[0], om = row[2], s2r = row[3], scr = row[4];
+    const float Cv = q.vBz * row[1], Cn = q.nBz * row[1], Cz = q.Gzz * row[5];
+#pragma unroll 2
+    for (int ap = 0; ap < NP; ++ap) {
+      float g[2][3][2];
+      tile_dma_read_pairs<TJ>(cur, lane, ap * 2, HALF + ap * 2, g);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const f32x8 col = cols[ap * 2 + i];
+        const float Pv = fmaf(q.vBy, col[1], q.vBx * col[0]);
+        const float Pn = fmaf(q.nBy, col[1], q.nBx * col[0]);
+        const float Qa = fmaf(q.Gyy, col[4], fmaf(q.Gxy, col[3], q.Gxx * col[2]));
+        const float Ra = fmaf(q.Gyz, col[1], q.Gxz * col[0]);
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg) {
+          const float ss = sg ? -sr : sr;
+          const float sc = sg ? -scr : scr;
+          float ndl, sp;
+          brdf_local_dir(q, fmaf(ss, Pv, Cv), fmaf(ss, Pn, Cn), fmaf(s2r, Qa, fmaf(sc, Ra, Cz)), ndl, sp);
+          const float wt = ndl * om;
+          const float sw = sp * wt;
+          d0 = fmaf(wt, g[sg][0][i], d0);
+          d1 = fmaf(wt, g[sg][1][i], d1);
+          d2 = fmaf(wt, g[sg][2][i], d2);
+          s0 = fmaf(sw, g[sg][0][i], s0);
+          s1 = fmaf(sw, g[sg][1][i], s1);
+          s2 = fmaf(sw, g[sg][2][i], s2);
+        }
+      }
+    }
+    if (NBUF == 1 && e + 1 < eh) tile_dma_issue<TJ>(tile, eimg, x.p0, RC, a.J, (e + 1) * EW, lane);
+  }
+  if (x.active) {
+    const size_t o = (size_t)b * 3 * RC;
+    const unsigned up = (unsigned)p;
+    (a.diffuse + o)[up] = (alb[0] * kInvPi) * d0;
+    (a.diffuse + o + RC)[up] = (alb[1] * kInvPi) * d1;
+    (a.diffuse + o + 2 * (size_t)RC)[up] = (alb[2] * kInvPi) * d2;
+    (a.spec + o)[up] = s0;
+    (a.spec + o + RC)[up] = s1;
+    (a.spec + o + 2 * (size_t)RC)[up] = s2;
   }
 }
 

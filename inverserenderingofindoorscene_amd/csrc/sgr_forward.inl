@@ -148,25 +148,50 @@ static int fwd_launch_k(const Args& a, hipStream_t st) {
 }
 
 // fast path (separable table, EW in {16,32}, K <= 24)
-template <int KP, int EW, bool WRITE_ENV, bool DO_RENDER>
+template <int KP, int EW, int TJ, bool WRITE_ENV, bool DO_RENDER>
 static int fwd_fast_launch_pool(const Args& a, hipStream_t st) {
   const dim3 grid = wave_grid(a.bn, a.R, a.C), block(kWave);
   if (!DO_RENDER || (a.imH == a.R && a.imW == a.C))
-    hipLaunchKernelGGL((fwd_fast_kernel<KP, 1, EW, WRITE_ENV, DO_RENDER>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((fwd_fast_kernel<KP, 1, EW, TJ, WRITE_ENV, DO_RENDER>), grid, block, 0, st, a);
   else
-    hipLaunchKernelGGL((fwd_fast_kernel<KP, 2, EW, WRITE_ENV, DO_RENDER>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((fwd_fast_kernel<KP, 2, EW, TJ, WRITE_ENV, DO_RENDER>), grid, block, 0, st, a);
   return (int)hipGetLastError();
+}
+// tile width for EW = 16: 32 directions (two table rows, full 128-byte lines, 27 KB LDS) or 16 (one
+// row, 64-byte segments, 15 KB LDS -> twice the resident waves).  Tuning knob: SGR_FWD_TJ.
+static inline int fwd_tile_width() {
+  static const int tj = [] { const char* e = getenv("SGR_FWD_TJ"); return (e && atoi(e) == 16) ? 16 : 32; }();
+  return tj;
 }
 template <bool WRITE_ENV, bool DO_RENDER>
 static int fwd_fast_launch(const Args& a, hipStream_t st) {
-  if (a.ew == 16) return a.K <= 12 ? fwd_fast_launch_pool<12, 16, WRITE_ENV, DO_RENDER>(a, st)
-                                   : fwd_fast_launch_pool<24, 16, WRITE_ENV, DO_RENDER>(a, st);
-  return a.K <= 12 ? fwd_fast_launch_pool<12, 32, WRITE_ENV, DO_RENDER>(a, st)
-                   : fwd_fast_launch_pool<24, 32, WRITE_ENV, DO_RENDER>(a, st);
+  if (a.ew == 16) {
+    if (WRITE_ENV && fwd_tile_width() == 16)
+      return a.K <= 12 ? fwd_fast_launch_pool<12, 16, 16, WRITE_ENV, DO_RENDER>(a, st)
+                       : fwd_fast_launch_pool<24, 16, 16, WRITE_ENV, DO_RENDER>(a, st);
+    return a.K <= 12 ? fwd_fast_launch_pool<12, 16, 32, WRITE_ENV, DO_RENDER>(a, st)
+                     : fwd_fast_launch_pool<24, 16, 32, WRITE_ENV, DO_RENDER>(a, st);
+  }
+  return a.K <= 12 ? fwd_fast_launch_pool<12, 32, 32, WRITE_ENV, DO_RENDER>(a, st)
+                   : fwd_fast_launch_pool<24, 32, 32, WRITE_ENV, DO_RENDER>(a, st);
+}
+
+static int render_fast_launch(const Args& a, hipStream_t st) {
+  const dim3 grid = wave_grid(a.bn, a.R, a.C), block(kWave);
+  const bool p1 = (a.imH == a.R && a.imW == a.C);
+  if (a.ew == 16) {
+    if (p1) hipLaunchKernelGGL((render_fast_kernel<1, 16>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((render_fast_kernel<2, 16>), grid, block, 0, st, a);
+  } else {
+    if (p1) hipLaunchKernelGGL((render_fast_kernel<1, 32>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((render_fast_kernel<2, 32>), grid, block, 0, st, a);
+  }
+  return (int)hipGetLastError();
 }
 
 template <bool FROM_SG, bool WRITE_ENV, bool DO_RENDER>
 static int fwd_launch(const Args& a, hipStream_t st) {
+  if (!FROM_SG && DO_RENDER && fast_ok(a) && !getenv("SGR_GENERIC")) return render_fast_launch(a, st);
   if (FROM_SG && fast_ok(a) && a.K <= 24 && !getenv("SGR_GENERIC")) return fwd_fast_launch<WRITE_ENV, DO_RENDER>(a, st);
   if (!DO_RENDER || (a.imH == a.R && a.imW == a.C)) return fwd_launch_k<1, FROM_SG, WRITE_ENV, DO_RENDER>(a, st);
   return fwd_launch_k<2, FROM_SG, WRITE_ENV, DO_RENDER>(a, st);

@@ -63,6 +63,14 @@ SGR_HD float fmul_rn(float a, float b) {
   return r;
 #endif
 }
+SGR_HD float fadd_rn(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __fadd_rn(a, b);
+#else
+  volatile float r = a + b;
+  return r;
+#endif
+}
 SGR_HD float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 SGR_HD float clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 
@@ -120,7 +128,11 @@ struct Frame {
 SGR_HD Frame make_frame(float pnx, float pny, float pnz, float prho, float vx, float vy, float vz) {
   Frame f;
   // N / sqrt(clamp(|N|^2, 1e-6, 1))                                   models.py:467-468
-  const float nn = pnx * pnx + pny * pny + pnz * pnz;
+  // |N|^2 is evaluated exactly as torch.sum(N*N, dim=1) does in fp32 -- three rounded products,
+  // added left to right, no FMA -- because the two-sided clamp makes the normal's gradient
+  // discontinuous at |N|^2 == 1 and unit input normals (ratio-1 maps) sit right on that kink: the
+  // side of the kink has to be decided with the reference's own rounding.
+  const float nn = fadd_rn(fadd_rn(fmul_rn(pnx, pnx), fmul_rn(pny, pny)), fmul_rn(pnz, pnz));
   const float inv = frsq(clampf(nn, 1e-6f, 1.0f));
   f.nx = pnx * inv; f.ny = pny * inv; f.nz = pnz * inv;
   // camy = normalize(up - (up.N) N), up = (0,1,0)                     models.py:477-478
@@ -345,7 +357,7 @@ SGR_HD void frame_bwd(float pnx, float pny, float pnz, float prho, const Frame& 
   }
   // N = pooled / sqrt(clamp(|pooled|^2, 1e-6, 1))
   {
-    const float nn = pnx * pnx + pny * pny + pnz * pnz;
+    const float nn = fadd_rn(fadd_rn(fmul_rn(pnx, pnx), fmul_rn(pny, pny)), fmul_rn(pnz, pnz));   // as in make_frame
     const float sc = clampf(nn, 1e-6f, 1.0f);
     const float inv = frsq(sc);
     const float pn[3] = {pnx, pny, pnz};

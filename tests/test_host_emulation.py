@@ -165,8 +165,10 @@ def test_brdf_backward_math_vs_golden(emul, golden):
         ref64, ref32 = z["ref64_glin_" + k], z["ref32_glin_" + k]
         assert np.isfinite(got).all(), (name, k)
         e_ref = rel_l2(ref32[m], ref64[m])
-        e = rel_l2(got[m], ref64[m])
-        assert e < max(3 * e_ref, 2e-5), (name, k, e, e_ref)
+        assert rel_l2(got[m], ref32[m]) < 3e-4, (name, k, rel_l2(got[m], ref32[m]))    # incl. the |N|^2 clamp kink
+        if e_ref < 1e-3:
+            e = rel_l2(got[m], ref64[m])
+            assert e < max(3 * e_ref, 2e-5), (name, k, e, e_ref)
 
 
 def test_c_tables_match_numpy():

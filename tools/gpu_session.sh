@@ -6,6 +6,7 @@ export TMPDIR=/tmp
 LIB=inverserenderingofindoorscene_amd/libsgrender.so
 echo "== pytest gpu"; timeout 900 python -m pytest tests -q -m gpu > gpurun_out/pytest_gpu.txt 2>&1; tail -25 gpurun_out/pytest_gpu.txt
 echo "== kbench fast"; timeout 300 ./tools/kbench $LIB 16 20 > gpurun_out/kbench_fast.txt 2>&1; cat gpurun_out/kbench_fast.txt
+echo "== kbench fast TJ16"; SGR_FWD_TJ=16 timeout 300 ./tools/kbench $LIB 16 20 > gpurun_out/kbench_fast_tj16.txt 2>&1; head -4 gpurun_out/kbench_fast_tj16.txt
 echo "== kbench generic"; SGR_GENERIC=1 timeout 300 ./tools/kbench $LIB 16 10 > gpurun_out/kbench_generic.txt 2>&1; cat gpurun_out/kbench_generic.txt
 for v in inverserenderingofindoorscene_amd/variants/*.so; do
   [ -f "$v" ] || continue
