@@ -52,6 +52,44 @@ __device__ __forceinline__ void load_lobes(const Args& a, const Pix& x, int kg, 
   }
 }
 
+// One direction's (quadrature weight * ndl, spec): orthonormal-frame path when the whole wave is
+// non-degenerate (wave-uniform branch), Gram-matrix path otherwise.
+struct RowCtx {
+  float sr, cr, om, s2r, scr;   // s_e, c_e, omega_e, s_e^2, 2 s_e c_e
+  float Cv, Cn, Cz;             // general path: vBz c_e, nBz c_e, Gzz c_e^2
+  RowOrtho ro;
+};
+__device__ __forceinline__ RowCtx make_row_ctx(const PixLocal& q, const f32x8 row, bool with_brdf) {
+  RowCtx rc;
+  rc.sr = row[0]; rc.cr = row[1]; rc.om = row[2]; rc.s2r = row[3]; rc.scr = row[4];
+  rc.Cv = rc.Cn = rc.Cz = 0.0f;
+  rc.ro.nw = rc.ro.rowc = rc.ro.c1n2 = rc.ro.wt = rc.ro.Cv = 0.0f;
+  if (with_brdf) {
+    rc.Cv = q.vBz * row[1];
+    rc.Cn = q.nBz * row[1];
+    rc.Cz = q.Gzz * row[5];
+    rc.ro = make_row_ortho(q, row[1], row[2]);
+  }
+  return rc;
+}
+__device__ __forceinline__ void shade_dir(const PixLocal& q, bool ortho, const RowCtx& rc, int sg, const f32x8 col, float& wt,
+                                          float& sp) {
+  const float ss = sg ? -rc.sr : rc.sr;
+  const float Pv = fmaf(q.vBy, col[1], q.vBx * col[0]);
+  if (ortho) {
+    sp = brdf_ortho_dir(q, rc.ro, ss, col[0], col[1], Pv);
+    wt = rc.ro.wt;
+  } else {
+    const float sc = sg ? -rc.scr : rc.scr;
+    const float Pn = fmaf(q.nBy, col[1], q.nBx * col[0]);
+    const float Qa = fmaf(q.Gyy, col[4], fmaf(q.Gxy, col[3], q.Gxx * col[2]));
+    const float Ra = fmaf(q.Gyz, col[1], q.Gxz * col[0]);
+    float ndl;
+    brdf_local_dir(q, fmaf(ss, Pv, rc.Cv), fmaf(ss, Pn, rc.Cn), fmaf(rc.s2r, Qa, fmaf(sc, Ra, rc.Cz)), ndl, sp);
+    wt = ndl * rc.om;
+  }
+}
+
 // ============================== forward ==========================================================
 template <int KP, int POOL, int EW, int TJ, bool WRITE_ENV, bool DO_RENDER>
 __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
@@ -70,9 +108,11 @@ __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
 
   PixLocal q;
   float alb[3] = {0.f, 0.f, 0.f};
+  bool ortho = true;
   if (DO_RENDER) {
     const Frame f = load_frame<POOL>(a, x, alb);
     q = make_local(f, a.F0);
+    ortho = __all(frame_is_orthonormal(q));
   }
   float d0 = 0.f, d1 = 0.f, d2 = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
   const SepTable rows = as_sep_table(a.rows), cols = as_sep_table(a.cols);
@@ -80,19 +120,15 @@ __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
   const int ehp = RPC == 2 ? ((a.eh + 1) & ~1) : a.eh;
 
   for (int e0 = 0; e0 < ehp; e0 += RPC) {
-    float sr[RPC], om[RPC], s2r[RPC], scr[RPC];
-    float Ck[KP][RPC], Cv[RPC], Cn[RPC], Cz[RPC];
+    float sr[RPC], Ck[KP][RPC];
+    RowCtx rc[RPC];
 #pragma unroll
     for (int r = 0; r < RPC; ++r) {
       const f32x8 row = rows[e0 + r];
-      sr[r] = row[0]; om[r] = row[2]; s2r[r] = row[3]; scr[r] = row[4];
+      sr[r] = row[0];
 #pragma unroll
       for (int k = 0; k < KP; ++k) Ck[k][r] = fmaf(L.az[k], row[1], -L.lp[k]);
-      if (DO_RENDER) {
-        Cv[r] = q.vBz * row[1];
-        Cn[r] = q.nBz * row[1];
-        Cz[r] = q.Gzz * row[5];
-      }
+      rc[r] = make_row_ctx(q, row, DO_RENDER);
     }
 #pragma unroll 1
     for (int aq = 0; aq < NQ; ++aq) {
@@ -125,22 +161,12 @@ __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
           }
         }
         if (DO_RENDER) {
-          const float Pv = fmaf(q.vBy, col[1], q.vBx * col[0]);
-          const float Pn = fmaf(q.nBy, col[1], q.nBx * col[0]);
-          const float Qa = fmaf(q.Gyy, col[4], fmaf(q.Gxy, col[3], q.Gxx * col[2]));
-          const float Ra = fmaf(q.Gyz, col[1], q.Gxz * col[0]);
 #pragma unroll
           for (int r = 0; r < RPC; ++r) {
 #pragma unroll
             for (int sg = 0; sg < 2; ++sg) {
-              const float ss = sg ? -sr[r] : sr[r];
-              const float sc = sg ? -scr[r] : scr[r];
-              const float vdl = fmaf(ss, Pv, Cv[r]);
-              const float ndr = fmaf(ss, Pn, Cn[r]);
-              const float ll = fmaf(s2r[r], Qa, fmaf(sc, Ra, Cz[r]));
-              float ndl, sp;
-              brdf_local_dir(q, vdl, ndr, ll, ndl, sp);
-              const float wt = ndl * om[r];
+              float wt, sp;
+              shade_dir(q, ortho, rc[r], sg, col, wt, sp);
               const float sw = sp * wt;
               d0 = fmaf(wt, acc[r][sg][0][i], d0);
               d1 = fmaf(wt, acc[r][sg][1][i], d1);
@@ -199,11 +225,13 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_fast_kernel(const Args a) {
   const int RC = a.R * a.C, K = a.K;
 
   PixLocal q;
+  bool ortho = true;
   float gd0 = 0.f, gd1 = 0.f, gd2 = 0.f, gs0 = 0.f, gs1 = 0.f, gs2 = 0.f;
   if (HAS_RENDER) {
     float alb[3];
     const Frame f = load_frame<POOL>(a, x, alb);
     q = make_local(f, a.F0);
+    ortho = __all(frame_is_orthonormal(q));
     const size_t o = (size_t)b * 3 * RC;
     const unsigned up = (unsigned)p;
     gd0 = (a.g_diffuse + o)[up] * (alb[0] * kInvPi);
@@ -237,13 +265,8 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_fast_kernel(const Args a) {
         }
       }
       const f32x8 row = rows[e];
-      const float sr = row[0], cr = row[1], om = row[2], s2r = row[3], scr = row[4];
-      float Cv = 0.f, Cn = 0.f, Cz = 0.f;
-      if (HAS_RENDER) {
-        Cv = q.vBz * cr;
-        Cn = q.nBz * cr;
-        Cz = q.Gzz * row[5];
-      }
+      const float sr = row[0], cr = row[1];
+      const RowCtx rc = make_row_ctx(q, row, HAS_RENDER);
 #pragma unroll 1
       for (int ap = 0; ap < NP; ++ap) {
         float g[2][3][2];   // [sign][colour][azimuth in pair]
@@ -261,17 +284,10 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_fast_kernel(const Args a) {
           const f32x8 col = cols[ap * 2 + i];
           ca[i] = col[0]; sa[i] = col[1];
           if (HAS_RENDER) {
-            const float Pv = fmaf(q.vBy, col[1], q.vBx * col[0]);
-            const float Pn = fmaf(q.nBy, col[1], q.nBx * col[0]);
-            const float Qa = fmaf(q.Gyy, col[4], fmaf(q.Gxy, col[3], q.Gxx * col[2]));
-            const float Ra = fmaf(q.Gyz, col[1], q.Gxz * col[0]);
 #pragma unroll
             for (int sg = 0; sg < 2; ++sg) {
-              const float ss = sg ? -sr : sr;
-              const float sc = sg ? -scr : scr;
-              float ndl, sp;
-              brdf_local_dir(q, fmaf(ss, Pv, Cv), fmaf(ss, Pn, Cn), fmaf(s2r, Qa, fmaf(sc, Ra, Cz)), ndl, sp);
-              const float wt = ndl * om;
+              float wt, sp;
+              shade_dir(q, ortho, rc, sg, col, wt, sp);
               g[sg][0][i] = fmaf(wt, fmaf(gs0, sp, gd0), g[sg][0][i]);
               g[sg][1][i] = fmaf(wt, fmaf(gs1, sp, gd1), g[sg][1][i]);
               g[sg][2][i] = fmaf(wt, fmaf(gs2, sp, gd2), g[sg][2][i]);
@@ -354,6 +370,7 @@ __global__ __launch_bounds__(kWave, 4) void render_fast_kernel(const Args a) {
   float alb[3];
   const Frame f = load_frame<POOL>(a, x, alb);
   const PixLocal q = make_local(f, a.F0);
+  const bool ortho = __all(frame_is_orthonormal(q));
   const SepTable rows = as_sep_table(a.rows), cols = as_sep_table(a.cols);
   __amdgpu_buffer_rsrc_t eimg = env_rsrc(a.env_in + (size_t)b * 3 * RC * a.J, RC, a.J);
   const int eh = a.eh;
@@ -368,9 +385,7 @@ __global__ __launch_bounds__(kWave, 4) void render_fast_kernel(const Args a) {
     } else {
       wait_vmcnt<0>();
     }
-    const f32x8 row = rows[e];
-    const float sr = row[0], om = row[2], s2r = row[3], scr = row[4];
-    const float Cv = q.vBz * row[1], Cn = q.nBz * row[1], Cz = q.Gzz * row[5];
+    const RowCtx rc = make_row_ctx(q, rows[e], true);
 #pragma unroll 2
     for (int ap = 0; ap < NP; ++ap) {
       float g[2][3][2];
@@ -378,17 +393,10 @@ __global__ __launch_bounds__(kWave, 4) void render_fast_kernel(const Args a) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const f32x8 col = cols[ap * 2 + i];
-        const float Pv = fmaf(q.vBy, col[1], q.vBx * col[0]);
-        const float Pn = fmaf(q.nBy, col[1], q.nBx * col[0]);
-        const float Qa = fmaf(q.Gyy, col[4], fmaf(q.Gxy, col[3], q.Gxx * col[2]));
-        const float Ra = fmaf(q.Gyz, col[1], q.Gxz * col[0]);
 #pragma unroll
         for (int sg = 0; sg < 2; ++sg) {
-          const float ss = sg ? -sr : sr;
-          const float sc = sg ? -scr : scr;
-          float ndl, sp;
-          brdf_local_dir(q, fmaf(ss, Pv, Cv), fmaf(ss, Pn, Cn), fmaf(s2r, Qa, fmaf(sc, Ra, Cz)), ndl, sp);
-          const float wt = ndl * om;
+          float wt, sp;
+          shade_dir(q, ortho, rc, sg, col, wt, sp);
           const float sw = sp * wt;
           d0 = fmaf(wt, g[sg][0][i], d0);
           d1 = fmaf(wt, g[sg][1][i], d1);

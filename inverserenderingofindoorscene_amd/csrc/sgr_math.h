@@ -55,9 +55,13 @@ SGR_HD float frsq(float x) {
   return 1.0f / sqrtf(x);
 #endif
 }
+// Individually rounded multiply / add.  On the device these are inline asm: HIP's __fmul_rn/__fadd_rn
+// are plain a*b / a+b, which -ffp-contract=fast is free to fuse into an FMA.
 SGR_HD float fmul_rn(float a, float b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return __fmul_rn(a, b);
+  float r;
+  asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 #else
   volatile float r = a * b;           // keep the compiler from contracting / reassociating
   return r;
@@ -65,7 +69,9 @@ SGR_HD float fmul_rn(float a, float b) {
 }
 SGR_HD float fadd_rn(float a, float b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return __fadd_rn(a, b);
+  float r;
+  asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 #else
   volatile float r = a + b;
   return r;
@@ -236,6 +242,49 @@ SGR_HD void brdf_local_dir(const PixLocal& q, float vdl, float ndl_raw, float ll
   const float nom2 = fmaf(ndl, q.omk, q.k);
   const float nom = clampf((nom0 * nom0) * (q.c1 * nom2), 1e-6f, kFourPi);
   sp = fmaf(q.fb, pw, q.fa) * frcp(nom);
+}
+
+// Orthonormal frame (every non-degenerate pixel: |N| = 1, N not parallel to up): N.l = c_e and the
+// numerically delicate GGX term is evaluated without cancellation.  With w = v + l in local
+// coordinates (tx, ty, nw):  |w|^2 = tx^2 + ty^2 + nw^2,  N.h = nw/|w|,  and
+//     nom0 = 1 + ndh^2 (alpha^2 - 1) = ( tx^2 + ty^2 + [nw<0] nw^2 + alpha^2 max(nw,0)^2 ) / |w|^2
+// is a sum of non-negative terms, where the reference's fp32 form (models.py:504) subtracts two
+// numbers that agree to 7 digits when the half vector is near the normal and alpha is small.  Same
+// function, smaller error than the reference's own against fp64.
+SGR_HD bool frame_is_orthonormal(const PixLocal& q) {
+  const float tol = 2e-6f;
+  return fabsf(q.Gxx - 1.0f) < tol && fabsf(q.Gyy - 1.0f) < tol && fabsf(q.Gzz - 1.0f) < tol &&
+         fabsf(q.Gxy) < tol && fabsf(q.Gxz) < tol && fabsf(q.Gyz) < tol;
+}
+struct RowOrtho {           // per (pixel, table row) constants of the orthonormal path
+  float nw;                 // N.(v + l) = vBz + c_e
+  float rowc;               // [nw<0] nw^2 + alpha^2 max(nw,0)^2
+  float c1n2;               // 4 pi nom1 nom2,  nom2 = c_e (1-k) + k   (ndl = c_e)
+  float wt;                 // ndl * omega = c_e * omega_e
+  float Cv;                 // vBz * c_e
+};
+SGR_HD RowOrtho make_row_ortho(const PixLocal& q, float c_e, float omega_e) {
+  RowOrtho r;
+  r.nw = q.vBz + c_e;
+  const float neg = fminf(r.nw, 0.0f), pos = fmaxf(r.nw, 0.0f);
+  r.rowc = fmaf(neg, neg, (q.alpha2m1 + 1.0f) * pos * pos);
+  r.c1n2 = q.c1 * fmaf(c_e, q.omk, q.k);
+  r.wt = c_e * omega_e;
+  r.Cv = q.vBz * c_e;
+  return r;
+}
+// direction (+-s_e ca_a, +-s_e sa_a, c_e): ss = +-s_e, Pv = vBx ca + vBy sa.   Returns spec.
+SGR_HD float brdf_ortho_dir(const PixLocal& q, const RowOrtho& r, float ss, float ca, float sa, float Pv) {
+  const float tx = fmaf(ss, ca, q.vBx), ty = fmaf(ss, sa, q.vBy);
+  const float T2 = fmaf(tx, tx, ty * ty);
+  const float hh4 = fmaf(r.nw, r.nw, T2);
+  const float Hm = fmaxf(hh4, 4e-6f);
+  const float r4 = frsq(Hm);
+  const float vdh = (q.vv + fmaf(ss, Pv, r.Cv)) * r4;
+  const float pw = fexp2((-5.55472f * vdh - 6.98316f) * vdh);
+  const float nom0 = ((T2 + (Hm - hh4)) + r.rowc) * (r4 * r4);
+  const float nom = clampf((nom0 * nom0) * r.c1n2, 1e-6f, kFourPi);
+  return fmaf(q.fb, pw, q.fa) * frcp(nom);
 }
 
 // ---- adjoints of the shading frame and of one quadrature direction --------------------------

@@ -202,6 +202,27 @@ void emul_brdf_bwd(const float* g_diffuse, const float* g_spec, const float* alb
 }  // extern "C"
 
 // ---- fast path (separable direction table), mirrors csrc/sgr_fast.inl -------------------------
+namespace {
+// mirrors shade_dir() of csrc/sgr_fast.inl (the kernels take the orthonormal path per wave, here per pixel)
+inline void emul_shade(const PixLocal& ql, bool ortho, const float* row, const float* col, int sg, float Cv, float Cn, float Cz,
+                       float& wt, float& sp) {
+  const float ss = sg ? -row[0] : row[0];
+  const float Pv = fmaf(ql.vBy, col[1], ql.vBx * col[0]);
+  if (ortho) {
+    const RowOrtho ro = make_row_ortho(ql, row[1], row[2]);
+    sp = brdf_ortho_dir(ql, ro, ss, col[0], col[1], Pv);
+    wt = ro.wt;
+  } else {
+    const float sc = sg ? -row[4] : row[4];
+    const float Pn = fmaf(ql.nBy, col[1], ql.nBx * col[0]);
+    const float Qa = fmaf(ql.Gyy, col[4], fmaf(ql.Gxy, col[3], ql.Gxx * col[2]));
+    const float Ra = fmaf(ql.Gyz, col[1], ql.Gxz * col[0]);
+    float ndl;
+    brdf_local_dir(ql, fmaf(ss, Pv, Cv), fmaf(ss, Pn, Cn), fmaf(row[3], Qa, fmaf(sc, Ra, Cz)), ndl, sp);
+    wt = ndl * row[2];
+  }
+}
+}  // namespace
 extern "C" {
 
 // rows [ehp,8] = (s, c, omega, s^2, 2sc, c^2, 0, 0);  cols [ew,8] = (ca, sa, ca^2, 2 ca sa, sa^2, ...)
@@ -231,6 +252,7 @@ void emul_fast_fwd(const float* albedo, const float* normal, const float* rough,
       const Frame f = make_frame(pooled(no, r, c, imW, q), pooled(no + plane, r, c, imW, q), pooled(no + 2 * plane, r, c, imW, q),
                                  pooled(ro, r, c, imW, q), view[p], view[RC + p], view[2 * RC + p]);
       const PixLocal ql = make_local(f, F0);
+      const bool ortho = frame_is_orthonormal(ql);
       float d0 = 0, d1 = 0, d2 = 0, s0 = 0, s1 = 0, s2 = 0;
       for (int e = 0; e < eh; ++e) {
         const float* row = rows + 8 * e;
@@ -245,18 +267,13 @@ void emul_fast_fwd(const float* albedo, const float* normal, const float* rough,
             acc[0][0] = fmaf(w0[k], ep, acc[0][0]); acc[0][1] = fmaf(w1[k], ep, acc[0][1]); acc[0][2] = fmaf(w2[k], ep, acc[0][2]);
             acc[1][0] = fmaf(w0[k], em, acc[1][0]); acc[1][1] = fmaf(w1[k], em, acc[1][1]); acc[1][2] = fmaf(w2[k], em, acc[1][2]);
           }
-          const float Pv = fmaf(ql.vBy, col[1], ql.vBx * col[0]);
-          const float Pn = fmaf(ql.nBy, col[1], ql.nBx * col[0]);
-          const float Qa = fmaf(ql.Gyy, col[4], fmaf(ql.Gxy, col[3], ql.Gxx * col[2]));
-          const float Ra = fmaf(ql.Gyz, col[1], ql.Gxz * col[0]);
           for (int sg = 0; sg < 2; ++sg) {
             const int j = e * ew + a + sg * HALF;
             if (env)
               for (int ch = 0; ch < 3; ++ch) env[(((size_t)b * 3 + ch) * RC + p) * J + j] = acc[sg][ch];
-            const float ss = sg ? -row[0] : row[0], sc = sg ? -row[4] : row[4];
-            float ndl, sp;
-            brdf_local_dir(ql, fmaf(ss, Pv, Cv), fmaf(ss, Pn, Cn), fmaf(row[3], Qa, fmaf(sc, Ra, Cz)), ndl, sp);
-            const float wt = ndl * row[2], sw = sp * wt;
+            float wt, sp;
+            emul_shade(ql, ortho, row, col, sg, Cv, Cn, Cz, wt, sp);
+            const float sw = sp * wt;
             d0 = fmaf(wt, acc[sg][0], d0); d1 = fmaf(wt, acc[sg][1], d1); d2 = fmaf(wt, acc[sg][2], d2);
             s0 = fmaf(sw, acc[sg][0], s0); s1 = fmaf(sw, acc[sg][1], s1); s2 = fmaf(sw, acc[sg][2], s2);
           }
@@ -285,6 +302,7 @@ void emul_fast_sg_bwd(const float* g_env, const float* g_diffuse, const float* g
       const Frame f = make_frame(pooled(no, r, c, imW, q), pooled(no + plane, r, c, imW, q), pooled(no + 2 * plane, r, c, imW, q),
                                  pooled(ro, r, c, imW, q), view[p], view[RC + p], view[2 * RC + p]);
       const PixLocal ql = make_local(f, F0);
+      const bool ortho = frame_is_orthonormal(ql);
       const size_t o = (size_t)b * 3 * RC + p;
       const float gd0 = g_diffuse[o] * (a0 * kInvPi), gd1 = g_diffuse[o + RC] * (a1 * kInvPi), gd2 = g_diffuse[o + 2 * (size_t)RC] * (a2 * kInvPi);
       const float gs0 = g_spec[o], gs1 = g_spec[o + RC], gs2 = g_spec[o + 2 * (size_t)RC];
@@ -303,24 +321,19 @@ void emul_fast_sg_bwd(const float* g_env, const float* g_diffuse, const float* g
           const float czr = fmaf(az, row[1], -1.0f);
           for (int a = 0; a < HALF; ++a) {
             const float* col = cols + 8 * a;
-            const float Pv = fmaf(ql.vBy, col[1], ql.vBx * col[0]);
-            const float Pn = fmaf(ql.nBy, col[1], ql.nBx * col[0]);
-            const float Qa = fmaf(ql.Gyy, col[4], fmaf(ql.Gxy, col[3], ql.Gxx * col[2]));
-            const float Ra = fmaf(ql.Gyz, col[1], ql.Gxz * col[0]);
             const float u = fmaf(ay, col[1], ax * col[0]);
             float A = 0;
             for (int sg = 0; sg < 2; ++sg) {
               const int j = e * ew + a + sg * HALF;
-              const float ss = sg ? -row[0] : row[0], sc = sg ? -row[4] : row[4];
+              const float ss = sg ? -row[0] : row[0];
               float c0 = 0, c1 = 0, c2 = 0;
               if (g_env) {
                 c0 = g_env[(((size_t)b * 3 + 0) * RC + p) * J + j];
                 c1 = g_env[(((size_t)b * 3 + 1) * RC + p) * J + j];
                 c2 = g_env[(((size_t)b * 3 + 2) * RC + p) * J + j];
               }
-              float ndl, sp;
-              brdf_local_dir(ql, fmaf(ss, Pv, Cv), fmaf(ss, Pn, Cn), fmaf(row[3], Qa, fmaf(sc, Ra, Cz)), ndl, sp);
-              const float wt = ndl * row[2];
+              float wt, sp;
+              emul_shade(ql, ortho, row, col, sg, Cv, Cn, Cz, wt, sp);
               c0 = fmaf(wt, fmaf(gs0, sp, gd0), c0); c1 = fmaf(wt, fmaf(gs1, sp, gd1), c1); c2 = fmaf(wt, fmaf(gs2, sp, gd2), c2);
               const float t = fmaf(ss, u, czr);
               const float ex = fexp2(lp * t);

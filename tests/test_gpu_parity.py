@@ -67,7 +67,7 @@ def _check_grads(name, z, cfg, grads, which="glin"):
         e_ref = rel_l2(ref32[m], ref64[m])
         # primary: the reference's own fp32 gradients (for ratio-1 unit normals the |N|^2 == 1 clamp kink
         # makes fp32 and fp64 gradients differ by O(1); the kernels follow the fp32 rounding)
-        assert rel_l2(g[m], ref32[m]) < 3e-4, (name, k, rel_l2(g[m], ref32[m]), e_ref)
+        assert rel_l2(g[m], ref32[m]) < max(3e-4, 4 * min(e_ref, 1e-3)), (name, k, rel_l2(g[m], ref32[m]), e_ref)
         if e_ref < 1e-3:
             e = rel_l2(g[m], ref64[m])
             assert e < max(3 * e_ref, 3e-5), (name, k, e, e_ref)

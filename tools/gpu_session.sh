@@ -16,3 +16,5 @@ echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 
 echo "== bench"; timeout 600 python bench.py --steps 20 --warmup 3 > gpurun_out/bench.txt 2>&1; tail -2 gpurun_out/bench.txt
 echo "== rocprof"; cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/rocprof.txt 2>&1; cd $GRAFT_REPO_ROOT
 for f in $(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); do cp $f gpurun_out/kernel_stats.csv; head -12 $f; done
+echo "== pmc traffic"; bash tools/pmc_traffic.sh
+echo "== trainlight example"; timeout 300 python examples/train_light_synthetic.py --batch 16 --steps 8 > gpurun_out/trainlight.txt 2>&1; tail -4 gpurun_out/trainlight.txt
