@@ -47,11 +47,14 @@ extern "C" int sgr_fill_direction_table(float* out, int eh, int ew) {
     o[0] = (float)sd; o[1] = (float)cd; o[2] = (float)(sd * M_PI * M_PI / (double)ew / (double)eh);
     o[3] = (float)(sd * sd); o[4] = (float)(2.0 * sd * cd); o[5] = (float)(cd * cd);
   }
-  for (int a = 0; a < ew; ++a) {
+  // cols: first half row only (the second half is its negation): [ew/2][2] = (ca, sa), then at float
+  // offset ew: [ew/2][4] = (ca^2, 2 ca sa, sa^2, 0)
+  for (int a = 0; a < ew / 2; ++a) {
     const double az = ((((double)a + 0.5) / (double)ew) - 0.5) * 2.0 * M_PI;
     const double cad = cos(az), sad = sin(az);
-    float* o = cols + 8 * (size_t)a;
-    o[0] = (float)cad; o[1] = (float)sad; o[2] = (float)(cad * cad); o[3] = (float)(2.0 * cad * sad); o[4] = (float)(sad * sad);
+    cols[2 * a] = (float)cad; cols[2 * a + 1] = (float)sad;
+    float* o = cols + ew + 4 * (size_t)a;
+    o[0] = (float)(cad * cad); o[1] = (float)(2.0 * cad * sad); o[2] = (float)(sad * sad);
   }
   for (int e = 0; e < eh; ++e) {
     const double el = (((double)e + 0.5) / (double)eh) * M_PI / 2.0;

@@ -12,6 +12,10 @@
 #include "sgr_common.h"
 #include "sgr_launch.h"
 
+#ifndef SGR_DIR_BARRIER
+#define SGR_DIR_BARRIER 1   // scheduling fence between azimuths (A/B switch)
+#endif
+
 namespace sgr {
 
 template <int KP>
@@ -54,6 +58,13 @@ __device__ __forceinline__ void load_lobes(const Args& a, const Pix& x, int kg, 
 
 // One direction's (quadrature weight * ndl, spec): orthonormal-frame path when the whole wave is
 // non-degenerate (wave-uniform branch), Gram-matrix path otherwise.
+// Per-azimuth terms built from these are row-invariant too; same LICM fence as for the lobe axes.
+__device__ __forceinline__ void fence_row_invariants(PixLocal& q) {
+  asm volatile("" : "+v"(q.vBx)); asm volatile("" : "+v"(q.vBy));
+  asm volatile("" : "+v"(q.nBx)); asm volatile("" : "+v"(q.nBy));
+  asm volatile("" : "+v"(q.Gxx)); asm volatile("" : "+v"(q.Gxy)); asm volatile("" : "+v"(q.Gyy));
+  asm volatile("" : "+v"(q.Gxz)); asm volatile("" : "+v"(q.Gyz));
+}
 struct RowCtx {
   float sr, cr, om, s2r, scr;   // s_e, c_e, omega_e, s_e^2, 2 s_e c_e
   float Cv, Cn, Cz;             // general path: vBz c_e, nBz c_e, Gzz c_e^2
@@ -72,18 +83,20 @@ __device__ __forceinline__ RowCtx make_row_ctx(const PixLocal& q, const f32x8 ro
   }
   return rc;
 }
-__device__ __forceinline__ void shade_dir(const PixLocal& q, bool ortho, const RowCtx& rc, int sg, const f32x8 col, float& wt,
-                                          float& sp) {
+typedef const f32x4 __attribute__((address_space(4))) * XTable;   // per azimuth (ca^2, 2 ca sa, sa^2, 0)
+__device__ __forceinline__ void shade_dir(const PixLocal& q, bool ortho, const RowCtx& rc, int sg, float ca, float sa, XTable xt,
+                                          int a, float& wt, float& sp) {
   const float ss = sg ? -rc.sr : rc.sr;
-  const float Pv = fmaf(q.vBy, col[1], q.vBx * col[0]);
+  const float Pv = fmaf(q.vBy, sa, q.vBx * ca);
   if (ortho) {
-    sp = brdf_ortho_dir(q, rc.ro, ss, col[0], col[1], Pv);
+    sp = brdf_ortho_dir(q, rc.ro, ss, ca, sa, Pv);
     wt = rc.ro.wt;
   } else {
     const float sc = sg ? -rc.scr : rc.scr;
-    const float Pn = fmaf(q.nBy, col[1], q.nBx * col[0]);
-    const float Qa = fmaf(q.Gyy, col[4], fmaf(q.Gxy, col[3], q.Gxx * col[2]));
-    const float Ra = fmaf(q.Gyz, col[1], q.Gxz * col[0]);
+    const float Pn = fmaf(q.nBy, sa, q.nBx * ca);
+    const f32x4 ex = xt[a];
+    const float Qa = fmaf(q.Gyy, ex[2], fmaf(q.Gxy, ex[1], q.Gxx * ex[0]));
+    const float Ra = fmaf(q.Gyz, sa, q.Gxz * ca);
     float ndl;
     brdf_local_dir(q, fmaf(ss, Pv, rc.Cv), fmaf(ss, Pn, rc.Cn), fmaf(rc.s2r, Qa, fmaf(sc, Ra, rc.Cz)), ndl, sp);
     wt = ndl * rc.om;
@@ -115,11 +128,18 @@ __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
     ortho = __all(frame_is_orthonormal(q));
   }
   float d0 = 0.f, d1 = 0.f, d2 = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
-  const SepTable rows = as_sep_table(a.rows), cols = as_sep_table(a.cols);
+  const SepTable rows = as_sep_table(a.rows);
+  const SepTable cst = as_sep_table(a.cols);                                   // [(EW/2)/4] x 4 x (ca, sa)
+  const XTable xt = (XTable)(a.cols + EW);                                     // extras, general path only
   const size_t img = (size_t)b * 3 * RC * a.J;
   const int ehp = RPC == 2 ? ((a.eh + 1) & ~1) : a.eh;
 
   for (int e0 = 0; e0 < ehp; e0 += RPC) {
+    // U_ka = ax ca_a + ay sa_a does not depend on the row: keep LICM from hoisting all KP*EW/2 of them out
+    // of the row loop (they would not fit in registers) by making the axes opaque once per row.
+#pragma unroll
+    for (int k = 0; k < KP; ++k) { asm volatile("" : "+v"(L.ax[k])); asm volatile("" : "+v"(L.ay[k])); }
+    if (DO_RENDER) fence_row_invariants(q);
     float sr[RPC], Ck[KP][RPC];
     RowCtx rc[RPC];
 #pragma unroll
@@ -132,6 +152,7 @@ __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
     }
 #pragma unroll 1
     for (int aq = 0; aq < NQ; ++aq) {
+      const f32x8 cs = cst[aq];  // (ca, sa) of the quad's four azimuths: one scalar load per quad
       float acc[RPC][2][3][4];   // [row][sign][colour][azimuth in quad]
 #pragma unroll
       for (int r = 0; r < RPC; ++r)
@@ -144,10 +165,10 @@ __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
 
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const f32x8 col = cols[aq * 4 + i];
+        const float ca = cs[2 * i], sa = cs[2 * i + 1];
 #pragma unroll
         for (int k = 0; k < KP; ++k) {
-          const float U = fmaf(L.ay[k], col[1], L.ax[k] * col[0]);
+          const float U = fmaf(L.ay[k], sa, L.ax[k] * ca);
 #pragma unroll
           for (int r = 0; r < RPC; ++r) {
             const float ep = fexp2(fmaf(sr[r], U, Ck[k][r]));
@@ -166,7 +187,7 @@ __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
 #pragma unroll
             for (int sg = 0; sg < 2; ++sg) {
               float wt, sp;
-              shade_dir(q, ortho, rc[r], sg, col, wt, sp);
+              shade_dir(q, ortho, rc[r], sg, ca, sa, xt, aq * 4 + i, wt, sp);
               const float sw = sp * wt;
               d0 = fmaf(wt, acc[r][sg][0][i], d0);
               d1 = fmaf(wt, acc[r][sg][1][i], d1);
@@ -177,7 +198,9 @@ __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
             }
           }
         }
+#if SGR_DIR_BARRIER
         __builtin_amdgcn_sched_barrier(0);
+#endif
       }
       if (WRITE_ENV) {
 #pragma unroll
@@ -241,7 +264,9 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_fast_kernel(const Args a) {
     gs1 = (a.g_spec + o + RC)[up];
     gs2 = (a.g_spec + o + 2 * (size_t)RC)[up];
   }
-  const SepTable rows = as_sep_table(a.rows), cols = as_sep_table(a.cols);
+  const SepTable rows = as_sep_table(a.rows);
+  const XTable cst = (XTable)(a.cols);                                         // [(EW/2)/2] x 2 x (ca, sa)
+  const XTable xt = (XTable)(a.cols + EW);
   __amdgpu_buffer_rsrc_t gimg = env_rsrc(HAS_GENV ? a.g_env + (size_t)b * 3 * RC * a.J : a.view, RC, a.J);
   const int eh = a.eh;
 
@@ -264,11 +289,15 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_fast_kernel(const Args a) {
           wait_vmcnt<0>();
         }
       }
+#pragma unroll
+      for (int k = 0; k < KP; ++k) { asm volatile("" : "+v"(L.ax[k])); asm volatile("" : "+v"(L.ay[k])); }   // no LICM of u_ka
+      if (HAS_RENDER) fence_row_invariants(q);
       const f32x8 row = rows[e];
       const float sr = row[0], cr = row[1];
       const RowCtx rc = make_row_ctx(q, row, HAS_RENDER);
 #pragma unroll 1
       for (int ap = 0; ap < NP; ++ap) {
+        const f32x4 cs = cst[ap];   // (ca, sa) of the pair's two azimuths
         float g[2][3][2];   // [sign][colour][azimuth in pair]
         if (HAS_GENV) {
           tile_dma_read_pairs<TJ>(cur, lane, ap * 2, HALF + ap * 2, g);
@@ -281,13 +310,12 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_fast_kernel(const Args a) {
         float ca[2], sa[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const f32x8 col = cols[ap * 2 + i];
-          ca[i] = col[0]; sa[i] = col[1];
+          ca[i] = cs[2 * i]; sa[i] = cs[2 * i + 1];
           if (HAS_RENDER) {
 #pragma unroll
             for (int sg = 0; sg < 2; ++sg) {
               float wt, sp;
-              shade_dir(q, ortho, rc, sg, col, wt, sp);
+              shade_dir(q, ortho, rc, sg, ca[i], sa[i], xt, ap * 2 + i, wt, sp);
               g[sg][0][i] = fmaf(wt, fmaf(gs0, sp, gd0), g[sg][0][i]);
               g[sg][1][i] = fmaf(wt, fmaf(gs1, sp, gd1), g[sg][1][i]);
               g[sg][2][i] = fmaf(wt, fmaf(gs2, sp, gd2), g[sg][2][i]);
@@ -369,9 +397,11 @@ __global__ __launch_bounds__(kWave, 4) void render_fast_kernel(const Args a) {
   const int RC = a.R * a.C;
   float alb[3];
   const Frame f = load_frame<POOL>(a, x, alb);
-  const PixLocal q = make_local(f, a.F0);
+  PixLocal q = make_local(f, a.F0);
   const bool ortho = __all(frame_is_orthonormal(q));
-  const SepTable rows = as_sep_table(a.rows), cols = as_sep_table(a.cols);
+  const SepTable rows = as_sep_table(a.rows);
+  const XTable cst = (XTable)(a.cols);
+  const XTable xt = (XTable)(a.cols + EW);
   __amdgpu_buffer_rsrc_t eimg = env_rsrc(a.env_in + (size_t)b * 3 * RC * a.J, RC, a.J);
   const int eh = a.eh;
   float d0 = 0.f, d1 = 0.f, d2 = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
@@ -385,18 +415,19 @@ __global__ __launch_bounds__(kWave, 4) void render_fast_kernel(const Args a) {
     } else {
       wait_vmcnt<0>();
     }
+    fence_row_invariants(q);
     const RowCtx rc = make_row_ctx(q, rows[e], true);
-#pragma unroll 2
+#pragma unroll 1
     for (int ap = 0; ap < NP; ++ap) {
+      const f32x4 cs = cst[ap];
       float g[2][3][2];
       tile_dma_read_pairs<TJ>(cur, lane, ap * 2, HALF + ap * 2, g);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const f32x8 col = cols[ap * 2 + i];
 #pragma unroll
         for (int sg = 0; sg < 2; ++sg) {
           float wt, sp;
-          shade_dir(q, ortho, rc, sg, col, wt, sp);
+          shade_dir(q, ortho, rc, sg, cs[2 * i], cs[2 * i + 1], xt, ap * 2 + i, wt, sp);
           const float sw = sp * wt;
           d0 = fmaf(wt, g[sg][0][i], d0);
           d1 = fmaf(wt, g[sg][1][i], d1);

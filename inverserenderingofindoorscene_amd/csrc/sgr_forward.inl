@@ -160,7 +160,7 @@ static int fwd_fast_launch_pool(const Args& a, hipStream_t st) {
 // tile width for EW = 16: 32 directions (two table rows, full 128-byte lines, 27 KB LDS) or 16 (one
 // row, 64-byte segments, 15 KB LDS -> twice the resident waves).  Tuning knob: SGR_FWD_TJ.
 static inline int fwd_tile_width() {
-  static const int tj = [] { const char* e = getenv("SGR_FWD_TJ"); return (e && atoi(e) == 16) ? 16 : 32; }();
+  static const int tj = [] { const char* e = getenv("SGR_FWD_TJ"); return (e && atoi(e) == 32) ? 32 : 16; }();   // 16 measured faster
   return tj;
 }
 template <bool WRITE_ENV, bool DO_RENDER>

@@ -27,7 +27,7 @@ def direction_table(env_height: int, env_width: int) -> Tuple[np.ndarray, np.nda
 def packed_direction_table(env_height: int, env_width: int) -> np.ndarray:
     """Device layout (flat float32, see include/sgrender.h): ``[Jpad,4] = (lx, ly, lz, omega)`` with zero
     rows up to a multiple of 32, then the separable form ``rows[ehp,8] = (s, c, omega, s^2, 2sc, c^2, 0, 0)``
-    and ``cols[ew,8] = (ca, sa, ca^2, 2 ca sa, sa^2, 0, 0, 0)`` of the same table."""
+    and the azimuth factors of the first half row (``(ca, sa)`` pairs, then ``(ca^2, 2 ca sa, sa^2, 0)``)."""
     ls, omega = direction_table(env_height, env_width)
     J = ls.shape[0]
     jpad = (J + 31) // 32 * 32
@@ -42,10 +42,16 @@ def packed_direction_table(env_height: int, env_width: int) -> np.ndarray:
     rows[:env_height, 0], rows[:env_height, 1] = s, c
     rows[:env_height, 2] = s * np.pi * np.pi / env_width / env_height
     rows[:env_height, 3], rows[:env_height, 4], rows[:env_height, 5] = s * s, 2 * s * c, c * c
-    cols = np.zeros((env_width, 8), dtype=np.float64)
-    ca, sa = np.cos(az), np.sin(az)
-    cols[:, 0], cols[:, 1], cols[:, 2], cols[:, 3], cols[:, 4] = ca, sa, ca * ca, 2 * ca * sa, sa * sa
-    return np.concatenate([gen.reshape(-1), rows.astype(np.float32).reshape(-1), cols.astype(np.float32).reshape(-1)])
+    # cols (8*ew floats reserved): first half row only (the second half is its negation):
+    #   [ew/2][2] = (ca, sa), then at float offset ew: [ew/2][4] = (ca^2, 2 ca sa, sa^2, 0)
+    half = env_width // 2
+    ca, sa = np.cos(az[:half]), np.sin(az[:half])
+    cols = np.zeros(8 * env_width, dtype=np.float64)
+    cols[0:2 * half:2], cols[1:2 * half:2] = ca, sa
+    ext = np.zeros((half, 4))
+    ext[:, 0], ext[:, 1], ext[:, 2] = ca * ca, 2 * ca * sa, sa * sa
+    cols[env_width:env_width + 4 * half] = ext.reshape(-1)
+    return np.concatenate([gen.reshape(-1), rows.astype(np.float32).reshape(-1), cols.astype(np.float32)])
 
 
 def generic_table_view(packed: np.ndarray, env_height: int, env_width: int) -> np.ndarray:

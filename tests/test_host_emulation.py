@@ -57,8 +57,12 @@ def _sep_tables(eh, ew):
     jpad = (eh * ew + 31) // 32 * 32
     ehp = (eh + 1) // 2 * 2
     rows = np.ascontiguousarray(packed[4 * jpad:4 * jpad + 8 * ehp])
-    cols = np.ascontiguousarray(packed[4 * jpad + 8 * ehp:])
-    return rows, cols
+    raw = packed[4 * jpad + 8 * ehp:]
+    half = ew // 2
+    cols = np.zeros((half, 8), np.float32)          # emulation layout: (ca, sa, ca^2, 2 ca sa, sa^2, 0, 0, 0) per azimuth
+    cols[:, 0:2] = raw[:2 * half].reshape(half, 2)
+    cols[:, 2:5] = raw[ew:ew + 4 * half].reshape(half, 4)[:, :3]
+    return rows, np.ascontiguousarray(cols.reshape(-1))
 
 
 FAST_CASES = ["g1_q4_k12", "g3_edges"]          # envWidth 16: the separable fast path applies
