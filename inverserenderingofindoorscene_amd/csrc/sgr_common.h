@@ -18,16 +18,6 @@ namespace sgr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Measured on gfx950 (tools/microbench2.hip): a VALU instruction with an SGPR (or literal) source
-// issues in ~4.1 cycles per wave64 against 2.2-2.7 with VGPR-only sources.  Wave-uniform factors
-// used by thousands of FMAs (s_e, c_e, ca_a, sa_a, polynomial constants) are therefore copied into
-// VGPRs once per row / azimuth group instead of being used as scalar operands.
-__device__ __forceinline__ float to_vgpr(float s) {
-  float v;
-  asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
-  return v;
-}
-
 #ifndef SGR_NT
 #define SGR_NT 1   // non-temporal hint on the streamed env tiles (A/B switch)
 #endif

@@ -72,7 +72,7 @@ struct RowCtx {
 };
 __device__ __forceinline__ RowCtx make_row_ctx(const PixLocal& q, const f32x8 row, bool with_brdf) {
   RowCtx rc;
-  rc.sr = to_vgpr(row[0]); rc.cr = to_vgpr(row[1]); rc.om = row[2]; rc.s2r = row[3]; rc.scr = row[4];
+  rc.sr = row[0]; rc.cr = row[1]; rc.om = row[2]; rc.s2r = row[3]; rc.scr = row[4];
   rc.Cv = rc.Cn = rc.Cz = 0.0f;
   rc.ro.nw = rc.ro.rowc = rc.ro.c1n2 = rc.ro.wt = rc.ro.Cv = 0.0f;
   if (with_brdf) {
@@ -84,17 +84,12 @@ __device__ __forceinline__ RowCtx make_row_ctx(const PixLocal& q, const f32x8 ro
   return rc;
 }
 typedef const f32x4 __attribute__((address_space(4))) * XTable;   // per azimuth (ca^2, 2 ca sa, sa^2, 0)
-__device__ __forceinline__ ShadeConsts shade_consts_vgpr() {
-  const ShadeConsts c = shade_consts();
-  return ShadeConsts{to_vgpr(c.fa), to_vgpr(c.fb2), to_vgpr(c.hmin), to_vgpr(c.nmin), to_vgpr(c.nmax)};
-}
-// ca, sa, rc.sr are VGPR copies of the wave-uniform table entries (see to_vgpr()).
-__device__ __forceinline__ void shade_dir(const PixLocal& q, bool ortho, const RowCtx& rc, const ShadeConsts& kc, int sg, float ca,
-                                          float sa, XTable xt, int a, float& wt, float& sp) {
+__device__ __forceinline__ void shade_dir(const PixLocal& q, bool ortho, const RowCtx& rc, int sg, float ca, float sa, XTable xt,
+                                          int a, float& wt, float& sp) {
   const float ss = sg ? -rc.sr : rc.sr;
   const float Pv = fmaf(q.vBy, sa, q.vBx * ca);
   if (ortho) {
-    sp = brdf_ortho_dir(q, rc.ro, kc, ss, ca, sa, Pv);
+    sp = brdf_ortho_dir(q, rc.ro, ss, ca, sa, Pv);
     wt = rc.ro.wt;
   } else {
     const float sc = sg ? -rc.scr : rc.scr;
@@ -133,7 +128,6 @@ __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
     ortho = __all(frame_is_orthonormal(q));
   }
   float d0 = 0.f, d1 = 0.f, d2 = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
-  const ShadeConsts kc = shade_consts_vgpr();
   const SepTable rows = as_sep_table(a.rows);
   const SepTable cst = as_sep_table(a.cols);                                   // [(EW/2)/4] x 4 x (ca, sa)
   const XTable xt = (XTable)(a.cols + EW);                                     // extras, general path only
@@ -151,10 +145,10 @@ __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
 #pragma unroll
     for (int r = 0; r < RPC; ++r) {
       const f32x8 row = rows[e0 + r];
-      rc[r] = make_row_ctx(q, row, DO_RENDER);
-      sr[r] = rc[r].sr;
+      sr[r] = row[0];
 #pragma unroll
-      for (int k = 0; k < KP; ++k) Ck[k][r] = fmaf(L.az[k], rc[r].cr, -L.lp[k]);
+      for (int k = 0; k < KP; ++k) Ck[k][r] = fmaf(L.az[k], row[1], -L.lp[k]);
+      rc[r] = make_row_ctx(q, row, DO_RENDER);
     }
 #pragma unroll 1
     for (int aq = 0; aq < NQ; ++aq) {
@@ -171,7 +165,7 @@ __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
 
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float ca = to_vgpr(cs[2 * i]), sa = to_vgpr(cs[2 * i + 1]);
+        const float ca = cs[2 * i], sa = cs[2 * i + 1];
 #pragma unroll
         for (int k = 0; k < KP; ++k) {
           const float U = fmaf(L.ay[k], sa, L.ax[k] * ca);
@@ -193,7 +187,7 @@ __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
 #pragma unroll
             for (int sg = 0; sg < 2; ++sg) {
               float wt, sp;
-              shade_dir(q, ortho, rc[r], kc, sg, ca, sa, xt, aq * 4 + i, wt, sp);
+              shade_dir(q, ortho, rc[r], sg, ca, sa, xt, aq * 4 + i, wt, sp);
               const float sw = sp * wt;
               d0 = fmaf(wt, acc[r][sg][0][i], d0);
               d1 = fmaf(wt, acc[r][sg][1][i], d1);
@@ -270,7 +264,6 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_fast_kernel(const Args a) {
     gs1 = (a.g_spec + o + RC)[up];
     gs2 = (a.g_spec + o + 2 * (size_t)RC)[up];
   }
-  const ShadeConsts kc = shade_consts_vgpr();
   const SepTable rows = as_sep_table(a.rows);
   const XTable cst = (XTable)(a.cols);                                         // [(EW/2)/2] x 2 x (ca, sa)
   const XTable xt = (XTable)(a.cols + EW);
@@ -300,8 +293,8 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_fast_kernel(const Args a) {
       for (int k = 0; k < KP; ++k) { asm volatile("" : "+v"(L.ax[k])); asm volatile("" : "+v"(L.ay[k])); }   // no LICM of u_ka
       if (HAS_RENDER) fence_row_invariants(q);
       const f32x8 row = rows[e];
+      const float sr = row[0], cr = row[1];
       const RowCtx rc = make_row_ctx(q, row, HAS_RENDER);
-      const float sr = rc.sr, cr = rc.cr;
 #pragma unroll 1
       for (int ap = 0; ap < NP; ++ap) {
         const f32x4 cs = cst[ap];   // (ca, sa) of the pair's two azimuths
@@ -317,12 +310,12 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_fast_kernel(const Args a) {
         float ca[2], sa[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          ca[i] = to_vgpr(cs[2 * i]); sa[i] = to_vgpr(cs[2 * i + 1]);
+          ca[i] = cs[2 * i]; sa[i] = cs[2 * i + 1];
           if (HAS_RENDER) {
 #pragma unroll
             for (int sg = 0; sg < 2; ++sg) {
               float wt, sp;
-              shade_dir(q, ortho, rc, kc, sg, ca[i], sa[i], xt, ap * 2 + i, wt, sp);
+              shade_dir(q, ortho, rc, sg, ca[i], sa[i], xt, ap * 2 + i, wt, sp);
               g[sg][0][i] = fmaf(wt, fmaf(gs0, sp, gd0), g[sg][0][i]);
               g[sg][1][i] = fmaf(wt, fmaf(gs1, sp, gd1), g[sg][1][i]);
               g[sg][2][i] = fmaf(wt, fmaf(gs2, sp, gd2), g[sg][2][i]);
@@ -406,7 +399,6 @@ __global__ __launch_bounds__(kWave, 4) void render_fast_kernel(const Args a) {
   const Frame f = load_frame<POOL>(a, x, alb);
   PixLocal q = make_local(f, a.F0);
   const bool ortho = __all(frame_is_orthonormal(q));
-  const ShadeConsts kc = shade_consts_vgpr();
   const SepTable rows = as_sep_table(a.rows);
   const XTable cst = (XTable)(a.cols);
   const XTable xt = (XTable)(a.cols + EW);
@@ -428,7 +420,6 @@ __global__ __launch_bounds__(kWave, 4) void render_fast_kernel(const Args a) {
 #pragma unroll 1
     for (int ap = 0; ap < NP; ++ap) {
       const f32x4 cs = cst[ap];
-      const float cav[2] = {to_vgpr(cs[0]), to_vgpr(cs[2])}, sav[2] = {to_vgpr(cs[1]), to_vgpr(cs[3])};
       float g[2][3][2];
       tile_dma_read_pairs<TJ>(cur, lane, ap * 2, HALF + ap * 2, g);
 #pragma unroll
@@ -436,7 +427,7 @@ __global__ __launch_bounds__(kWave, 4) void render_fast_kernel(const Args a) {
 #pragma unroll
         for (int sg = 0; sg < 2; ++sg) {
           float wt, sp;
-          shade_dir(q, ortho, rc, kc, sg, cav[i], sav[i], xt, ap * 2 + i, wt, sp);
+          shade_dir(q, ortho, rc, sg, cs[2 * i], cs[2 * i + 1], xt, ap * 2 + i, wt, sp);
           const float sw = sp * wt;
           d0 = fmaf(wt, g[sg][0][i], d0);
           d1 = fmaf(wt, g[sg][1][i], d1);

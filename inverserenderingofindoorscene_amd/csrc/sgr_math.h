@@ -274,19 +274,16 @@ SGR_HD RowOrtho make_row_ortho(const PixLocal& q, float c_e, float omega_e) {
   return r;
 }
 // direction (+-s_e ca_a, +-s_e sa_a, c_e): ss = +-s_e, Pv = vBx ca + vBy sa.   Returns spec.
-// `kc` holds the scalar constants; on the device they are VGPR copies (see to_vgpr()).
-struct ShadeConsts { float fa, fb2, hmin, nmin, nmax; };   // -5.55472, -6.98316, 4e-6, 1e-6, 4 pi
-SGR_HD ShadeConsts shade_consts() { return ShadeConsts{-5.55472f, -6.98316f, 4e-6f, 1e-6f, kFourPi}; }
-SGR_HD float brdf_ortho_dir(const PixLocal& q, const RowOrtho& r, const ShadeConsts& kc, float ss, float ca, float sa, float Pv) {
+SGR_HD float brdf_ortho_dir(const PixLocal& q, const RowOrtho& r, float ss, float ca, float sa, float Pv) {
   const float tx = fmaf(ss, ca, q.vBx), ty = fmaf(ss, sa, q.vBy);
   const float T2 = fmaf(tx, tx, ty * ty);
   const float hh4 = fmaf(r.nw, r.nw, T2);
-  const float Hm = fmaxf(hh4, kc.hmin);
+  const float Hm = fmaxf(hh4, 4e-6f);
   const float r4 = frsq(Hm);
   const float vdh = (q.vv + fmaf(ss, Pv, r.Cv)) * r4;
-  const float pw = fexp2(fmaf(kc.fa, vdh, kc.fb2) * vdh);
+  const float pw = fexp2((-5.55472f * vdh - 6.98316f) * vdh);
   const float nom0 = ((T2 + (Hm - hh4)) + r.rowc) * (r4 * r4);
-  const float nom = fminf(fmaxf((nom0 * nom0) * r.c1n2, kc.nmin), kc.nmax);
+  const float nom = clampf((nom0 * nom0) * r.c1n2, 1e-6f, kFourPi);
   return fmaf(q.fb, pw, q.fa) * frcp(nom);
 }
 

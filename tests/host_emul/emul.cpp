@@ -210,7 +210,7 @@ inline void emul_shade(const PixLocal& ql, bool ortho, const float* row, const f
   const float Pv = fmaf(ql.vBy, col[1], ql.vBx * col[0]);
   if (ortho) {
     const RowOrtho ro = make_row_ortho(ql, row[1], row[2]);
-    sp = brdf_ortho_dir(ql, ro, shade_consts(), ss, col[0], col[1], Pv);
+    sp = brdf_ortho_dir(ql, ro, ss, col[0], col[1], Pv);
     wt = ro.wt;
   } else {
     const float sc = sg ? -row[4] : row[4];
