@@ -123,6 +123,26 @@ def main() -> None:
     fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
     bwd_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
 
+    # informational: the same step with the render loss in the loop (LSregressDiffSpec + masked L2 kernels,
+    # all-reduce of [num, den] when sharded) -- wrapperBRDFLight.py:170-207 around the layer
+    def step_with_loss():
+        env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=need_env)
+        err, _ = pkg.render_loss(d, s, x["im"], x["seg"], R, C)
+        if need_env:
+            torch.autograd.backward([err, env], [None, ct_env])
+        else:
+            err.backward()
+        for k in ("axis", "lamb", "weight"):
+            x[k].grad = None
+
+    step_with_loss()
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step_with_loss()
+    barrier()
+    loss_step_ms = (time.perf_counter() - t1) / args.steps * 1e3
+
     if rank == 0:
         P = bn * R * C                      # shaded (env-grid) pixels per GPU per step
         img_px = bn * imH * imW
@@ -162,6 +182,7 @@ def main() -> None:
                                    "+ fused bwd (SG grads), trainLight mode",
                        "shaded_px_per_step_per_gpu": P, "image_px_per_step_per_gpu": img_px, "q": q,
                        "Mshade_per_s": round(world * P / (dt / args.steps) / 1e6, 1),
+                       "ms_per_step_with_render_loss": round(loss_step_ms, 4),
                        "parallelism": f"batch-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(dom[3], 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(dom[3] / HBM_PEAK_GBPS, 4), "traffic": traffic,
