@@ -52,6 +52,8 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=16, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-env", action="store_true", help="render-only variant (env image never materialised)")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 5),
+                    help="BASELINE.json configs index: 2 = headline (default); 5 = 480x640, SGNum 24, 16x32 stress (batch 4)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -73,6 +75,8 @@ def main() -> None:
 
     _lib.load()
     bn, imH, imW, R, C, K, eh, ew = args.batch, 240, 320, 120, 160, 12, 8, 16
+    if args.config == 5:      # BASELINE configs[4]: env grid 240x320 assumed
+        bn, imH, imW, R, C, K, eh, ew = (4 if args.batch == 16 else args.batch), 480, 640, 240, 320, 24, 16, 32
     J, q = eh * ew, (imH // R) * (imW // C)
     need_env = not args.no_env
 
@@ -165,7 +169,7 @@ def main() -> None:
             except Exception:
                 traffic = None
         out = {
-            "metric": "Mpix/s shaded (fwd+bwd), 240x320x12-SG render layer",
+            "metric": "Mpix/s shaded (fwd+bwd), 240x320x12-SG render layer" if args.config == 2 else "Mpix/s shaded (fwd+bwd), 480x640x24-SG 16x32 render layer (stress config)",
             "value": round(value, 1),
             "unit": "Mpix/s",
             "n_gpus": world,
@@ -177,9 +181,9 @@ def main() -> None:
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1] per GPU: batch {bn} x 240x320 BRDF maps -> 120x160 env grid, "
-                                   f"SGNum=12, 8x16 directions; fused fwd ({'env image written' if need_env else 'render only'}) "
-                                   "+ fused bwd (SG grads), trainLight mode",
+            "config": {"workload": f"BASELINE configs[{1 if args.config == 2 else 4}] per GPU: batch {bn} x {imH}x{imW} BRDF maps -> "
+                                   f"{R}x{C} env grid, SGNum={K}, {eh}x{ew} directions; fused fwd "
+                                   f"({'env image written' if need_env else 'render only'}) + fused bwd (SG grads), trainLight mode",
                        "shaded_px_per_step_per_gpu": P, "image_px_per_step_per_gpu": img_px, "q": q,
                        "Mshade_per_s": round(world * P / (dt / args.steps) / 1e6, 1),
                        "ms_per_step_with_render_loss": round(loss_step_ms, 4),
@@ -192,8 +196,8 @@ def main() -> None:
                         "sg_bwd_fast_kernel": {"ms": round(bwd_ms, 4), "GBps": round(bwd_gbps, 1), "frac": round(bwd_gbps / HBM_PEAK_GBPS, 4),
                                           "bytes": bwd_bytes}},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(O, imH, imW, R, C, K, eh, ew)
+        if world == 1 and not args.no_cpu_baseline and args.config == 2:
+            out["cpu_baseline"] = cpu_baseline(O, 240, 320, 120, 160, 12, 8, 16) if args.config == 2 else None
         print(json.dumps(out), flush=True)
 
     if world > 1:

@@ -206,10 +206,14 @@ static int sgbwd_launch_k(const Args& a, hipStream_t st) {
 template <int EW, bool HAS_GENV, bool HAS_RENDER>
 static int sgbwd_fast_launch_pool(const Args& a, hipStream_t st) {
   const dim3 grid = wave_grid(a.bn, a.R, a.C), block(kWave);
-  if (!HAS_RENDER || (a.imH == a.R && a.imW == a.C))
-    hipLaunchKernelGGL((sg_bwd_fast_kernel<12, 1, EW, HAS_GENV, HAS_RENDER>), grid, block, 0, st, a);
-  else
-    hipLaunchKernelGGL((sg_bwd_fast_kernel<12, 2, EW, HAS_GENV, HAS_RENDER>), grid, block, 0, st, a);
+  const bool p1 = (!HAS_RENDER || (a.imH == a.R && a.imW == a.C));
+  if (a.K <= 6) {   // fewer lobes in registers -> higher occupancy
+    if (p1) hipLaunchKernelGGL((sg_bwd_fast_kernel<6, 1, EW, HAS_GENV, HAS_RENDER>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((sg_bwd_fast_kernel<6, 2, EW, HAS_GENV, HAS_RENDER>), grid, block, 0, st, a);
+  } else {
+    if (p1) hipLaunchKernelGGL((sg_bwd_fast_kernel<12, 1, EW, HAS_GENV, HAS_RENDER>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((sg_bwd_fast_kernel<12, 2, EW, HAS_GENV, HAS_RENDER>), grid, block, 0, st, a);
+  }
   return (int)hipGetLastError();
 }
 

@@ -71,6 +71,29 @@ __device__ __forceinline__ void tile_store_global(const float* tile, float* __re
   const unsigned lane_off = (unsigned)(lrow * J + col);
   const int rows_valid = RC - p0;
   const bool col_ok = (j0 + col) < J;
+  if (TJ == 16 && VEC) {
+    // 16-wide tiles: all 12 LDS reads in flight at once (48 VGPRs), one wait, then 12 stores
+    float4 v[3][Tile<TJ>::kIts];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int it = 0; it < Tile<TJ>::kIts; ++it)
+        v[c][it] = *reinterpret_cast<const float4*>(tile + (c * kWave + it * Tile<TJ>::kRowsPerIt + lrow) * Tile<TJ>::kStride + col);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float* cbase = env_img + ((size_t)c * RC + p0) * J + j0;   // wave-uniform
+#pragma unroll
+      for (int it = 0; it < Tile<TJ>::kIts; ++it) {
+        const int row = it * Tile<TJ>::kRowsPerIt + lrow;
+        float* dst = cbase + (size_t)(it * Tile<TJ>::kRowsPerIt) * J;   // uniform
+        if (row < rows_valid && col_ok) {
+          f32x4 nv = {v[c][it].x, v[c][it].y, v[c][it].z, v[c][it].w};
+          stream_store(nv, reinterpret_cast<f32x4*>(dst + lane_off));
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll 1   // one colour (<= 32 VGPRs of payload) in flight at a time
   for (int c = 0; c < 3; ++c) {
     float* cbase = env_img + ((size_t)c * RC + p0) * J + j0;   // wave-uniform

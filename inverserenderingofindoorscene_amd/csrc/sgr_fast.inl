@@ -12,6 +12,9 @@
 #include "sgr_common.h"
 #include "sgr_launch.h"
 
+#ifndef SGR_FWD_DIRECT
+#define SGR_FWD_DIRECT 0
+#endif
 #ifndef SGR_DIR_BARRIER
 #define SGR_DIR_BARRIER 1   // scheduling fence between azimuths (A/B switch)
 #endif
@@ -203,14 +206,30 @@ __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
 #endif
       }
       if (WRITE_ENV) {
+#if SGR_FWD_DIRECT
+        // experiment: per-lane 16-byte stores straight from registers (no LDS transpose)
+        if (x.active) {
+#pragma unroll
+          for (int r = 0; r < RPC; ++r)
+#pragma unroll
+            for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                float* base = a.env_out + img + (size_t)c * RC * a.J + (size_t)((e0 + r) * EW + sg * HALF + aq * 4);   // uniform
+                f32x4 nv = {acc[r][sg][c][0], acc[r][sg][c][1], acc[r][sg][c][2], acc[r][sg][c][3]};
+                *reinterpret_cast<f32x4*>(base + (unsigned)(p * a.J)) = nv;
+              }
+        }
+#else
 #pragma unroll
         for (int r = 0; r < RPC; ++r)
 #pragma unroll
           for (int sg = 0; sg < 2; ++sg)
             tile_row_write<TJ>(tile, lane, r * EW + sg * HALF + aq * 4, acc[r][sg][0], acc[r][sg][1], acc[r][sg][2]);
+#endif
       }
     }
-    if (WRITE_ENV) {
+    if (WRITE_ENV && !SGR_FWD_DIRECT) {
       __syncthreads();
       tile_store_global<TJ, true>(tile, a.env_out + img, x.p0, RC, a.J, e0 * EW, lane);
       __syncthreads();

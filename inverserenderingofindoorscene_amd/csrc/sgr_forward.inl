@@ -166,9 +166,12 @@ static inline int fwd_tile_width() {
 template <bool WRITE_ENV, bool DO_RENDER>
 static int fwd_fast_launch(const Args& a, hipStream_t st) {
   if (a.ew == 16) {
-    if (WRITE_ENV && fwd_tile_width() == 16)
+    if (WRITE_ENV && fwd_tile_width() == 16) {
+      if (a.K <= 6) return fwd_fast_launch_pool<6, 16, 16, WRITE_ENV, DO_RENDER>(a, st);
       return a.K <= 12 ? fwd_fast_launch_pool<12, 16, 16, WRITE_ENV, DO_RENDER>(a, st)
                        : fwd_fast_launch_pool<24, 16, 16, WRITE_ENV, DO_RENDER>(a, st);
+    }
+    if (a.K <= 6) return fwd_fast_launch_pool<6, 16, 32, WRITE_ENV, DO_RENDER>(a, st);
     return a.K <= 12 ? fwd_fast_launch_pool<12, 16, 32, WRITE_ENV, DO_RENDER>(a, st)
                      : fwd_fast_launch_pool<24, 16, 32, WRITE_ENV, DO_RENDER>(a, st);
   }

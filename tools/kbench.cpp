@@ -45,7 +45,8 @@ int main(int argc, char** argv) {
   SYM(sgr_fill_direction_table) SYM(sgr_fill_view_vectors) SYM(sgr_dirs_floats)
   SYM(sgr_sg_to_env_fwd) SYM(sgr_render_env_fwd) SYM(sgr_fused_fwd) SYM(sgr_sg_to_env_bwd) SYM(sgr_fused_bwd_sg)
   SYM(sgr_render_env_bwd_env) SYM(sgr_render_bwd_brdf) SYM(sgr_render_loss_fwd) SYM(sgr_render_loss_bwd) SYM(sgr_loss_workspace_floats)
-  const int imH = 240, imW = 320, R = 120, C = 160, K = 12, eh = 8, ew = 16, J = eh * ew, q = 4;
+  const int K = argc > 4 ? atoi(argv[4]) : 12;
+  const int imH = 240, imW = 320, R = 120, C = 160, eh = 8, ew = 16, J = eh * ew, q = 4;
   const size_t RC = (size_t)R * C, P = (size_t)bn * RC;
   const float F0d = 0.05f;
   // tables
@@ -88,7 +89,7 @@ int main(int argc, char** argv) {
     printf("%-34s %9.1f us   %7.1f GB/s algorithmic (%5.1f%% of 8 TB/s)   %7.1f Mshade/s\n", name, us,
            bytes_per_px * P / us * 1e-3, bytes_per_px * P / us * 1e-3 / 80.0, P / us);
   };
-  printf("# %s  bn=%d  P=%zu shaded px  reps=%d  SGR_GENERIC=%s\n", libpath, bn, P, reps, getenv("SGR_GENERIC") ? "1" : "0");
+  printf("# %s  bn=%d  K=%d  P=%zu shaded px  reps=%d  SGR_GENERIC=%s\n", libpath, bn, K, P, reps, getenv("SGR_GENERIC") ? "1" : "0");
   bench("sgr_fused_fwd (env written)", Bbrdf + Bsg + Benv + Bout, [&] { return sgr_fused_fwd_p(albedo, normal, rough, axis, lamb, weight, dirs, view, env, diffuse, spec, bn, K, R, C, eh, ew, imH, imW, F0d, 1, st); });
   bench("sgr_fused_fwd (render only)", Bbrdf + Bsg + Bout, [&] { return sgr_fused_fwd_p(albedo, normal, rough, axis, lamb, weight, dirs, view, (float*)nullptr, diffuse, spec, bn, K, R, C, eh, ew, imH, imW, F0d, 1, st); });
   bench("sgr_sg_to_env_fwd (+tan outputs)", Bsg + Benv + Bsg * 4.0 / 7.0, [&] { return sgr_sg_to_env_fwd_p(axis, lamb, weight, dirs, env, lam_t, w_t, bn, K, R, C, eh, ew, 1, st); });
