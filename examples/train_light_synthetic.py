@@ -8,7 +8,7 @@ its step (trainLight.py:203-244 -> wrapperBRDFLight.py:158-207) around synthetic
   * the light network is replaced by three learnable tensors pushed through decoderLight's output
     activations (models.py:336-346): 1.01*tanh -> unit axes, 0.5*(x+1) clamped to [0,1] for lamb/weight;
   * step = zero_grad -> fused render layer (env image + diffuse + specular) -> render loss (HIP) +
-    log-L2 reconstruction loss (torch ops; a "next" row of SURVEY.md 8f) -> backward -> Adam.
+    log-L2 reconstruction loss (HIP streaming kernels) -> backward -> Adam.
 
     python examples/train_light_synthetic.py --batch 16 --steps 20
 """
@@ -33,8 +33,8 @@ def decoder_heads(t_axis, t_lamb, t_weight):
     return a, lam, w
 
 
-def recon_loss(env_pred, env_gt, seg, env_ind, R, C, offset=1.0):
-    """wrapperBRDFLight.py:171-188 with torch ops + sgr.LSregress."""
+def recon_loss_torch(env_pred, env_gt, seg, env_ind, R, C, offset=1.0):
+    """wrapperBRDFLight.py:171-188 with torch ops + sgr.LSregress (kept for comparison with sgr.recon_loss)."""
     eh, ew = env_pred.shape[4], env_pred.shape[5]
     seg_s = F.adaptive_avg_pool2d(seg, (R, C))
     not_dark = (env_gt.mean(5).mean(4).mean(1, keepdim=True) > 0.001).float()
@@ -75,7 +75,7 @@ def train(bn=16, steps=10, imH=240, imW=320, R=120, C=160, K=12, eh=8, ew=16, re
         axis, lam, w = decoder_heads(*params)
         env, diffuse, spec = layer.forwardSG(batch["albedo"], batch["normal"], batch["rough"], axis, lam, w, need_env=True)
         render_err, _ = sgr.render_loss(diffuse, spec, batch["im"], batch["seg"], R, C)
-        recon_err = recon_loss(env, batch["env_gt"], batch["seg"], batch["env_ind"], R, C)
+        recon_err = sgr.recon_loss(env, batch["env_gt"], batch["seg"], batch["env_ind"], R, C)
         total = renW * render_err + recW * recon_err                   # trainLight.py:237
         total.backward()
         opt.step()

@@ -156,6 +156,27 @@ int sgr_lsregress_coef(const float* pred, const float* gt, float* coef, float* w
 int sgr_lsregress_diffspec_coef(const float* diffuse, const float* spec, const float* im, float* coef,
                                 float* workspace, int bn, int n, void* stream);
 
+/* ---- reconstruction loss ------------------------------------------------ */
+
+int sgr_recon_workspace_floats(int bn, int R, int C);
+
+/* Log-L2 env reconstruction loss of wrapperBRDFLight.py:172-188 for this rank's shard (two HBM streaming
+ * passes over the predicted and the ground-truth env images):
+ *   mask[b,p] = seg_small[b,p] * env_ind[b] * [mean_{c,j} env_gt > 0.001]                         (:172-174)
+ *   coef[b]   = clamp(<env mask, env_gt mask> / max(<env mask, env mask>, 1e-5), 1e-3, 1e3)       (models.LSregress)
+ *   parts[0]  = sum mask (log(coef env + offset) - log(env_gt + offset))^2,  parts[1] = sum mask  (:179,183-187)
+ * The caller forms reconstErr = parts[0] / max(parts[1], 1e-5) / 3 / (eh*ew) (after summing parts over ranks).
+ *   env, env_gt [bn,3,R,C,eh,ew]   seg_small [bn,1,R,C]   env_ind [bn]
+ *   out: mask [bn,R*C], coef [bn], parts [2] */
+int sgr_recon_loss_fwd(const float* env, const float* env_gt, const float* seg_small, const float* env_ind,
+                       float* mask, float* coef, float* parts, float* workspace,
+                       int bn, int R, int C, int eh, int ew, float offset, void* stream);
+
+/* g_env = *g_num * d parts[0] / d env  (coef is a constant, models.py:13);  g_env [bn,3,R,C,eh,ew] out. */
+int sgr_recon_loss_bwd(const float* g_num, const float* env, const float* env_gt, const float* mask,
+                       const float* coef, float* g_env,
+                       int bn, int R, int C, int eh, int ew, float offset, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,7 +24,7 @@ import torch.nn.functional as F
 from . import _lib
 from .layers import _ptr, _require_hip, _stream
 
-__all__ = ["LSregress", "LSregressDiffSpec", "render_loss", "combine_loss_parts"]
+__all__ = ["LSregress", "LSregressDiffSpec", "render_loss", "recon_loss", "combine_loss_parts"]
 
 
 def _workspace(bn: int, dev) -> torch.Tensor:
@@ -143,3 +143,61 @@ def render_loss(diffuse, spec, im, seg, envRow: int, envCol: int, group=None) ->
         seg = F.adaptive_avg_pool2d(seg, (envRow, envCol))
     num, den, rendered = _RenderLossParts.apply(diffuse, spec, im, seg, envRow, envCol)
     return combine_loss_parts(num, den, group), rendered
+
+
+class _ReconLossParts(torch.autograd.Function):
+    """sgr_recon_loss_fwd / sgr_recon_loss_bwd: ``(num, den_raw, coef)`` of this rank's shard."""
+
+    @staticmethod
+    def forward(ctx, env, env_gt, seg_small, env_ind, offset: float):
+        dev = _require_hip(env, env_gt, seg_small, env_ind)
+        e, g = env.contiguous(), env_gt.contiguous()
+        if e.dim() != 6 or e.shape != g.shape or e.shape[1] != 3:
+            raise RuntimeError("sgrender: envmapsPred / envmaps must both be [bn,3,envRow,envCol,envHeight,envWidth]")
+        bn, _, R, C, eh, ew = e.shape
+        sm = seg_small.contiguous().reshape(bn, R * C)
+        ind = env_ind.contiguous().reshape(bn)
+        mask = torch.empty((bn, R * C), device=dev, dtype=torch.float32)
+        coef = torch.empty(bn, device=dev, dtype=torch.float32)
+        parts = torch.empty(2, device=dev, dtype=torch.float32)
+        ws = torch.empty(_lib.load().sgr_recon_workspace_floats(bn, R, C), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.call("sgr_recon_loss_fwd", _ptr(e), _ptr(g), _ptr(sm), _ptr(ind), _ptr(mask), _ptr(coef), _ptr(parts),
+                      _ptr(ws), bn, R, C, eh, ew, float(offset), _stream(dev))
+        ctx.save_for_backward(e, g, mask, coef)
+        ctx.offset = float(offset)
+        num, den = parts[0], parts[1]
+        ctx.mark_non_differentiable(den, coef)
+        return num, den, coef
+
+    @staticmethod
+    def backward(ctx, g_num, _g_den, _g_coef):
+        e, g, mask, coef = ctx.saved_tensors
+        dev = e.device
+        bn, _, R, C, eh, ew = e.shape
+        g_num = g_num.contiguous().reshape(1).to(torch.float32)
+        g_env = torch.empty_like(e)
+        with torch.cuda.device(dev):
+            _lib.call("sgr_recon_loss_bwd", _ptr(g_num), _ptr(e), _ptr(g), _ptr(mask), _ptr(coef), _ptr(g_env),
+                      bn, R, C, eh, ew, ctx.offset, _stream(dev))
+        return g_env, None, None, None, None
+
+
+def recon_loss(envmapsPredImage, envmapsBatch, segBRDFBatch, envmapsIndBatch, envRow: int, envCol: int, offset: float = 1.0,
+               group=None, return_scaled: bool = False):
+    """``reconstErr`` of wrapperBRDFLight.py:171-188 (log-L2 between the LSregress-scaled predicted env image
+    and the ground truth, masked by the pooled object mask, the per-image env indicator and the
+    not-dark test), computed by two streaming HIP passes; ``pixelNum`` stays on the device and the
+    ``[num, den]`` pair is all-reduced when the batch is sharded.
+
+    With ``return_scaled=True`` also returns ``envmapsPredScaledImage`` (= pred * coef, a torch broadcast
+    multiply -- the reference returns it for logging)."""
+    seg_s = segBRDFBatch
+    if tuple(seg_s.shape[2:]) != (envRow, envCol):
+        seg_s = F.adaptive_avg_pool2d(segBRDFBatch, (envRow, envCol))
+    num, den, coef = _ReconLossParts.apply(envmapsPredImage, envmapsBatch, seg_s, envmapsIndBatch, offset)
+    eh, ew = envmapsPredImage.shape[4], envmapsPredImage.shape[5]
+    err = combine_loss_parts(num, den, group, divisor=3.0 * eh * ew)
+    if return_scaled:
+        return err, envmapsPredImage * coef.reshape(-1, 1, 1, 1, 1, 1)
+    return err

@@ -97,3 +97,37 @@ def test_render_loss_full_size_and_determinism(sgr):
     eo, ro, _, _ = O.render_loss(d.double(), s.double(), inp["im"].double(), inp["seg"].double(), R, C)
     assert abs(e1.item() - eo.item()) < 1e-5 * eo.item()
     assert rel_max(r1.cpu(), ro) < 1e-5
+
+
+def test_recon_loss_vs_golden(sgr, golden):
+    """sgr.recon_loss (wrapperBRDFLight.py:171-188) against the reference's value and gradient."""
+    from oracle import sg_oracle as O
+    name, z, cfg = golden
+    R, C = cfg["R"], cfg["C"]
+    env = _t(z, "ref32_env").requires_grad_(True)
+    ind = torch.ones(cfg["bn"], 1, 1, 1, device="cuda")
+    err, scaled = sgr.recon_loss(env, _t(z, "in_env_gt"), _t(z, "in_seg"), ind, R, C, return_scaled=True)
+    ref = float(z["ref32_recon_err"][0])
+    assert abs(err.item() - ref) < 2e-5 * max(1.0, abs(ref)), (name, err.item(), ref)
+    assert rel_l2(scaled.detach().cpu(), z["ref32_env_scaled"]) < 1e-5, name
+    (g,) = torch.autograd.grad(err, [env])
+    eo = torch.from_numpy(z["ref32_env"]).double().requires_grad_(True)
+    co, _, _, _ = O.recon_loss(eo, torch.from_numpy(z["in_env_gt"]).double(), torch.from_numpy(z["in_seg"]).double(),
+                               torch.ones(cfg["bn"], 1, 1, 1, dtype=torch.float64), R, C)
+    (go,) = torch.autograd.grad(co, [eo])
+    assert rel_l2(g.cpu(), go) < 1e-4, (name, rel_l2(g.cpu(), go))
+
+
+def test_recon_loss_masks_and_dark_envs(sgr):
+    """env_ind == 0 images and all-dark ground-truth cells drop out of both sums; odd J takes the scalar path."""
+    from oracle import sg_oracle as O
+    bn, R, C, eh, ew = 3, 5, 7, 3, 5
+    g = torch.Generator().manual_seed(3)
+    env = torch.rand(bn, 3, R, C, eh, ew, generator=g) * 2
+    gt = torch.rand(bn, 3, R, C, eh, ew, generator=g) * 2
+    gt[0, :, 1:3, 2:5] = 0.0                       # dark cells
+    seg = (torch.rand(bn, 1, R, C, generator=g) < 0.7).float()
+    ind = torch.tensor([1.0, 0.0, 1.0]).reshape(bn, 1, 1, 1)
+    err = sgr.recon_loss(env.cuda(), gt.cuda(), seg.cuda(), ind.cuda(), R, C)
+    eo, _, _, _ = O.recon_loss(env.double(), gt.double(), seg.double(), ind.double(), R, C)
+    assert abs(err.item() - eo.item()) < 1e-5 * max(1.0, eo.item())
