@@ -68,9 +68,12 @@ def train(bn=16, steps=10, imH=240, imW=320, R=120, C=160, K=12, eh=8, ew=16, re
     opt = torch.optim.Adam(params, lr=lr, betas=(0.5, 0.999))        # trainLight.py:178-181
     layer = sgr.renderingLayer(imWidth=C, imHeight=R, envWidth=ew, envHeight=eh)
     hist = []
-    torch.cuda.synchronize()
+    warmup = min(3, max(steps - 1, 0))
     t0 = time.perf_counter()
     for it in range(steps):
+        if it == warmup:               # the first steps pay module load / allocator growth
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
         opt.zero_grad()
         axis, lam, w = decoder_heads(*params)
         env, diffuse, spec = layer.forwardSG(batch["albedo"], batch["normal"], batch["rough"], axis, lam, w, need_env=True)
@@ -81,7 +84,7 @@ def train(bn=16, steps=10, imH=240, imW=320, R=120, C=160, K=12, eh=8, ew=16, re
         opt.step()
         hist.append((total.detach(), render_err.detach(), recon_err.detach()))
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    dt = (time.perf_counter() - t0) / max(steps - warmup, 1)
     hist = [(a.item(), b.item(), c.item()) for a, b, c in hist]
     if verbose:
         for i, (a, b, c) in enumerate(hist):
