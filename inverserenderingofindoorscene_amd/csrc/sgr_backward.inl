@@ -217,8 +217,25 @@ static int sgbwd_fast_launch_pool(const Args& a, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
+// lobes split over two waves (envWidth 16, more than 6 lobes)
+template <bool HAS_GENV, bool HAS_RENDER>
+static int sgbwd_split_launch(const Args& a, hipStream_t st) {
+  const dim3 grid = wave_grid(a.bn, a.R, a.C), block(2 * kWave);
+  if (!HAS_RENDER || (a.imH == a.R && a.imW == a.C))
+    hipLaunchKernelGGL((sg_bwd_split_kernel<6, 1, HAS_GENV, HAS_RENDER>), grid, block, 0, st, a);
+  else
+    hipLaunchKernelGGL((sg_bwd_split_kernel<6, 2, HAS_GENV, HAS_RENDER>), grid, block, 0, st, a);
+  return (int)hipGetLastError();
+}
+static inline bool bwd_split_enabled() {
+  static const bool on = [] { const char* e = getenv("SGR_BWD_SPLIT"); return !(e && atoi(e) == 0); }();
+  return on;
+}
+
 template <bool HAS_GENV, bool HAS_RENDER>
 static int sgbwd_launch(const Args& a, hipStream_t st) {
+  if (fast_ok(a) && a.ew == 16 && a.K > 6 && (HAS_GENV || HAS_RENDER) && bwd_split_enabled() && !getenv("SGR_GENERIC"))
+    return sgbwd_split_launch<HAS_GENV, HAS_RENDER>(a, st);
   if (fast_ok(a) && !getenv("SGR_GENERIC"))
     return a.ew == 16 ? sgbwd_fast_launch_pool<16, HAS_GENV, HAS_RENDER>(a, st) : sgbwd_fast_launch_pool<32, HAS_GENV, HAS_RENDER>(a, st);
   if (!HAS_RENDER || (a.imH == a.R && a.imW == a.C)) return sgbwd_launch_k<1, HAS_GENV, HAS_RENDER>(a, st);

@@ -231,6 +231,53 @@ __device__ __forceinline__ void tile_dma_read_pairs(const float* tile, int lane,
       g[sg][c][1] = r[sg][c].y;
     }
 }
+
+// write-back companion of tile_dma_read_pairs (same swizzled addresses), also inline asm
+template <int TJ>
+__device__ __forceinline__ void tile_dma_write_pairs(float* tile, int lane, int jjA, int jjB, const float (&g)[2][3][2]) {
+  using D = DmaTile<TJ>;
+  const unsigned rowb = lds_addr(tile) + (unsigned)(lane * TJ * 4);
+  const unsigned aA = rowb + (unsigned)((((jjA >> 2) ^ D::swz(lane)) * 4 + (jjA & 3)) * 4);
+  const unsigned aB = rowb + (unsigned)((((jjB >> 2) ^ D::swz(lane)) * 4 + (jjB & 3)) * 4);
+  f32x2 r[2][3];
+#pragma unroll
+  for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) r[sg][c] = f32x2{g[sg][c][0], g[sg][c][1]};
+  asm volatile("ds_write_b64 %0, %1" :: "v"(aA), "v"(r[0][0]) : "memory");
+  asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(aA), "v"(r[0][1]), "n"(1 * kWave * TJ * 4) : "memory");
+  asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(aA), "v"(r[0][2]), "n"(2 * kWave * TJ * 4) : "memory");
+  asm volatile("ds_write_b64 %0, %1" :: "v"(aB), "v"(r[1][0]) : "memory");
+  asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(aB), "v"(r[1][1]), "n"(1 * kWave * TJ * 4) : "memory");
+  asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(aB), "v"(r[1][2]), "n"(2 * kWave * TJ * 4) : "memory");
+}
+// DMA of one half of a tile's instructions (multi-wave workgroups split the issue): `part` of `nparts`
+template <int TJ>
+__device__ __forceinline__ void tile_dma_issue_part(float* tile, __amdgpu_buffer_rsrc_t rsrc, int p0, int RC, int J, int j0,
+                                                    int lane, int part, int nparts) {
+  using D = DmaTile<TJ>;
+  const int lrow = lane / D::kSlots, slot = lane % D::kSlots;
+  const int per = D::kInstrPerColour / nparts;
+#pragma unroll
+  for (int i = 0; i < D::kInstrPerColour / 2; ++i) {      // nparts == 2 in all callers
+    const int it = part * per + i;
+    const int row = it * D::kRowsPerInstr + lrow;
+    const int col4 = slot ^ D::swz(row);
+    const int voff = (row * J + col4 * 4) * 4;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int soff = (int)((((size_t)c * RC + p0) * J + j0) * 4);
+      float* dst = tile + (c * kWave + it * D::kRowsPerInstr) * TJ;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)dst, 16, voff, soff, 0, 0);
+    }
+  }
+}
+// workgroup barrier that does NOT drain outstanding LDS-DMA (unlike __syncthreads): LDS ops only
+__device__ __forceinline__ void barrier_lds_only() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
 template <int N> __device__ __forceinline__ void wait_vmcnt();
 template <> __device__ __forceinline__ void wait_vmcnt<0>() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <> __device__ __forceinline__ void wait_vmcnt<6>() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }

@@ -398,6 +398,179 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_fast_kernel(const Args a) {
   }
 }
 
+// ============================== backward, lobes split over two waves ==============================
+// Same math as sg_bwd_fast_kernel, but the 12 lobes of a 64-pixel group are split over the two waves of
+// a 128-thread workgroup (6 each): ~140 VGPRs per wave instead of ~250, i.e. 3 waves/SIMD instead of 2,
+// with the 24 KB double-buffered cotangent tile shared by both waves.  Per table row:
+//   1. each wave issues its half of the next row's DMA, waits for its half of this row (counted vmcnt),
+//      barrier;
+//   2. the quadrature's contribution to the cotangent is evaluated once -- each wave does half of the
+//      row's directions -- and added in place into the LDS tile; barrier;
+//   3. each wave consumes all 16 directions of the row for its own lobes; barrier (buffer reuse).
+template <int KPW, int POOL, bool HAS_GENV, bool HAS_RENDER>
+__global__ __launch_bounds__(2 * kWave, 3) void sg_bwd_split_kernel(const Args a) {
+  constexpr int EW = 16, TJ = 16, HALF = 8, NP = 4;
+  using D = DmaTile<TJ>;
+  __shared__ __attribute__((aligned(16))) float tile[(HAS_GENV ? 2 : 1) * D::kFloats];
+
+  const int wave = threadIdx.x >> 6;
+  Pix x;
+  x.lane = threadIdx.x & 63;
+  const int RC = a.R * a.C, K = a.K;
+  {
+    const int tiles = (RC + kWave - 1) / kWave;
+    x.b = blockIdx.x / tiles;
+    x.p0 = (blockIdx.x - x.b * tiles) * kWave;
+    x.active = (x.p0 + x.lane) < RC;
+    x.p = x.active ? (x.p0 + x.lane) : (RC - 1);
+  }
+  const int lane = x.lane, b = x.b, p = x.p;
+
+  PixLocal q;
+  bool ortho = true;
+  float gd0 = 0.f, gd1 = 0.f, gd2 = 0.f, gs0 = 0.f, gs1 = 0.f, gs2 = 0.f;
+  if (HAS_RENDER) {
+    float alb[3];
+    const Frame f = load_frame<POOL>(a, x, alb);
+    q = make_local(f, a.F0);
+    ortho = __all(frame_is_orthonormal(q));
+    const size_t o = (size_t)b * 3 * RC;
+    const unsigned up = (unsigned)p;
+    gd0 = (a.g_diffuse + o)[up] * (alb[0] * kInvPi);
+    gd1 = (a.g_diffuse + o + RC)[up] * (alb[1] * kInvPi);
+    gd2 = (a.g_diffuse + o + 2 * (size_t)RC)[up] * (alb[2] * kInvPi);
+    gs0 = (a.g_spec + o)[up];
+    gs1 = (a.g_spec + o + RC)[up];
+    gs2 = (a.g_spec + o + 2 * (size_t)RC)[up];
+  }
+  const SepTable rows = as_sep_table(a.rows);
+  const XTable cst = (XTable)(a.cols);
+  const XTable xt = (XTable)(a.cols + EW);
+  __amdgpu_buffer_rsrc_t gimg = env_rsrc(HAS_GENV ? a.g_env + (size_t)b * 3 * RC * a.J : a.view, RC, a.J);
+  const int eh = a.eh;
+
+  for (int kg = 0; kg < K; kg += 2 * KPW) {
+    Lobes<KPW> L;
+    load_lobes<KPW, false>(a, x, kg + wave * KPW, L, false);
+    float gax[KPW], gay[KPW], gaz[KPW], glam[KPW], gw0[KPW], gw1[KPW], gw2[KPW];
+#pragma unroll
+    for (int k = 0; k < KPW; ++k) gax[k] = gay[k] = gaz[k] = glam[k] = gw0[k] = gw1[k] = gw2[k] = 0.0f;
+
+    if (HAS_GENV) tile_dma_issue_part<TJ>(tile, gimg, x.p0, RC, a.J, 0, lane, wave, 2);
+
+    for (int e = 0; e < eh; ++e) {
+      float* cur = tile + (HAS_GENV ? (e & 1) * D::kFloats : 0);
+      if (HAS_GENV) {
+        if (e + 1 < eh) {
+          tile_dma_issue_part<TJ>(tile + ((e + 1) & 1) * D::kFloats, gimg, x.p0, RC, a.J, (e + 1) * EW, lane, wave, 2);
+          wait_vmcnt<6>();        // this wave's half of row e has landed; its half of row e+1 stays in flight
+        } else {
+          wait_vmcnt<0>();
+        }
+        barrier_lds_only();       // ... and so has the other wave's half
+      }
+#pragma unroll
+      for (int k = 0; k < KPW; ++k) { asm volatile("" : "+v"(L.ax[k])); asm volatile("" : "+v"(L.ay[k])); }   // no LICM of u_ka
+      if (HAS_RENDER) fence_row_invariants(q);
+      const f32x8 row = rows[e];
+      const float sr = row[0], cr = row[1];
+      const RowCtx rc = make_row_ctx(q, row, HAS_RENDER);
+
+      // ---- 2. quadrature contribution, this wave's half of the directions, added in place ------------
+      if (HAS_RENDER) {
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+          const int ap = wave * 2 + h;
+          const f32x4 cs = cst[ap];
+          float g[2][3][2];
+          if (HAS_GENV) {
+            tile_dma_read_pairs<TJ>(cur, lane, ap * 2, HALF + ap * 2, g);
+          } else {
+#pragma unroll
+            for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+              for (int c = 0; c < 3; ++c) g[sg][c][0] = g[sg][c][1] = 0.0f;
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int sg = 0; sg < 2; ++sg) {
+              float wt, sp;
+              shade_dir(q, ortho, rc, sg, cs[2 * i], cs[2 * i + 1], xt, ap * 2 + i, wt, sp);
+              g[sg][0][i] = fmaf(wt, fmaf(gs0, sp, gd0), g[sg][0][i]);
+              g[sg][1][i] = fmaf(wt, fmaf(gs1, sp, gd1), g[sg][1][i]);
+              g[sg][2][i] = fmaf(wt, fmaf(gs2, sp, gd2), g[sg][2][i]);
+            }
+          }
+          tile_dma_write_pairs<TJ>(cur, lane, ap * 2, HALF + ap * 2, g);
+        }
+        barrier_lds_only();
+      }
+
+      // ---- 3. all directions of the row, this wave's lobes ---------------------------------------------
+#pragma unroll 1
+      for (int ap = 0; ap < NP; ++ap) {
+        const f32x4 cs = cst[ap];
+        float g[2][3][2];
+        tile_dma_read_pairs<TJ>(cur, lane, ap * 2, HALF + ap * 2, g);
+        float ca[2] = {cs[0], cs[2]}, sa[2] = {cs[1], cs[3]};
+#pragma unroll
+        for (int k = 0; k < KPW; ++k) {
+          const float czr = fmaf(L.az[k], cr, -1.0f);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const float u = fmaf(L.ay[k], sa[i], L.ax[k] * ca[i]);
+            float A = 0.0f;
+#pragma unroll
+            for (int sg = 0; sg < 2; ++sg) {
+              const float ss = sg ? -sr : sr;
+              const float t = fmaf(ss, u, czr);
+              const float ex = fexp2(L.lp[k] * t);
+              const float c0 = g[sg][0][i], c1 = g[sg][1][i], c2 = g[sg][2][i];
+              gw0[k] = fmaf(c0, ex, gw0[k]);
+              gw1[k] = fmaf(c1, ex, gw1[k]);
+              gw2[k] = fmaf(c2, ex, gw2[k]);
+              const float T = fmaf(c2, L.w2[k], fmaf(c1, L.w1[k], c0 * L.w0[k])) * ex;
+              glam[k] = fmaf(T, t, glam[k]);
+              A = fmaf(ss, T, A);
+              gaz[k] = fmaf(cr, T, gaz[k]);
+            }
+            gax[k] = fmaf(ca[i], A, gax[k]);
+            gay[k] = fmaf(sa[i], A, gay[k]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      barrier_lds_only();   // both waves are done with `cur` before it is refilled / rewritten
+    }
+
+    if (x.active) {
+#pragma unroll
+      for (int k = 0; k < KPW; ++k) {
+        const int kk = kg + wave * KPW + k;
+        if (kk < K) {
+          const size_t ab = ((size_t)(b * K + kk) * 3) * RC;
+          const size_t lb = (size_t)(b * K + kk) * RC;
+          const unsigned up = (unsigned)p;
+          const float lam = L.lp[k] * kLn2;
+          (a.g_axis + ab)[up] = lam * gax[k];
+          (a.g_axis + ab + RC)[up] = lam * gay[k];
+          (a.g_axis + ab + 2 * (size_t)RC)[up] = lam * gaz[k];
+          float gl = glam[k], q0 = gw0[k], q1 = gw1[k], q2 = gw2[k];
+          if (a.premap) {
+            gl *= premap_grad(lam);
+            q0 *= premap_grad(L.w0[k]); q1 *= premap_grad(L.w1[k]); q2 *= premap_grad(L.w2[k]);
+          }
+          (a.g_lamb + lb)[up] = gl;
+          (a.g_weight + ab)[up] = q0;
+          (a.g_weight + ab + RC)[up] = q1;
+          (a.g_weight + ab + 2 * (size_t)RC)[up] = q2;
+        }
+      }
+    }
+  }
+}
+
 // ============================== forwardEnv alone (env image read) =================================
 // The un-fused drop-in call renderingLayer.forwardEnv (models.py:461-522): HBM-bound (1672 B/px in,
 // ~45 VALU slots per direction), so the env rows stream in by double-buffered LDS-DMA exactly like the
