@@ -156,6 +156,13 @@ int sgr_lsregress_coef(const float* pred, const float* gt, float* coef, float* w
 int sgr_lsregress_diffspec_coef(const float* diffuse, const float* spec, const float* im, float* coef,
                                 float* workspace, int bn, int n, void* stream);
 
+/* utils.predToShading (utils.py:156-195): per-cell cosine-weighted irradiance of the
+ * SG mixture, shading[b,c,r,cc] = max(sum_j env_c(l_j) cos(El_j) sin(El_j), 0) over an eh x ew hemisphere grid
+ * (the reference uses 16 x 32).  Needs ew in {16, 32}, K <= 24 (SGR_ERR_UNSUPPORTED otherwise).
+ *   axis [bn,K,3,R,C]  lamb [bn,K,R,C]  weight [bn,3K,R,C]  ->  shading [bn,3,R,C] */
+int sgr_sg_shading(const float* axis, const float* lamb, const float* weight, const float* dirs, float* shading,
+                   int bn, int K, int R, int C, int eh, int ew, int premap, void* stream);
+
 /* ---- reconstruction loss ------------------------------------------------ */
 
 int sgr_recon_workspace_floats(int bn, int R, int C);

@@ -1,8 +1,8 @@
 """MI355X-native SG x microfacet render layer (drop-in for the reference's models.renderingLayer /
 models.output2env call boundary; the compute lives in libsgrender.so, see include/sgrender.h)."""
 from ._lib import SgrenderError, SgrenderUnavailable  # noqa: F401
-from .layers import output2env, output_radiance, render_from_sg, renderingLayer, renderLayer  # noqa: F401
+from .layers import output2env, output_radiance, predToShading, render_from_sg, renderingLayer, renderLayer  # noqa: F401
 from .losses import LSregress, LSregressDiffSpec, combine_loss_parts, recon_loss, render_loss  # noqa: F401
 
-__all__ = ["output2env", "renderingLayer", "render_from_sg", "renderLayer", "output_radiance",
+__all__ = ["output2env", "renderingLayer", "render_from_sg", "renderLayer", "output_radiance", "predToShading",
            "LSregress", "LSregressDiffSpec", "render_loss", "recon_loss", "combine_loss_parts", "SgrenderError", "SgrenderUnavailable"]

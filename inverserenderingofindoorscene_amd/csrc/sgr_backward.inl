@@ -234,7 +234,7 @@ static inline bool bwd_split_enabled() {
 
 template <bool HAS_GENV, bool HAS_RENDER>
 static int sgbwd_launch(const Args& a, hipStream_t st) {
-  if (fast_ok(a) && a.ew == 16 && a.K > 6 && (HAS_GENV || HAS_RENDER) && bwd_split_enabled() && !getenv("SGR_GENERIC"))
+  if (fast_ok(a) && a.ew == 16 && a.K > 6 && HAS_GENV && bwd_split_enabled() && !getenv("SGR_GENERIC"))   // measured: only pays with the LDS tile
     return sgbwd_split_launch<HAS_GENV, HAS_RENDER>(a, st);
   if (fast_ok(a) && !getenv("SGR_GENERIC"))
     return a.ew == 16 ? sgbwd_fast_launch_pool<16, HAS_GENV, HAS_RENDER>(a, st) : sgbwd_fast_launch_pool<32, HAS_GENV, HAS_RENDER>(a, st);

@@ -644,6 +644,57 @@ __global__ __launch_bounds__(kWave, 4) void render_fast_kernel(const Args a) {
   }
 }
 
+// ============================== utils.predToShading (utils.py:156-195) ============================
+// shading_c = max( sum_j env_c(l_j) cos(El_j) sin(El_j), 0 ): the SG mixture integrated against the
+// cosine-weighted hemisphere measure (no microfacet terms, no env image) -- the forward inner loop with a
+// row-constant weight.
+template <int KP, int EW>
+__global__ __launch_bounds__(kWave, 2) void shading_fast_kernel(const Args a) {
+  constexpr int NQ = EW / 8;
+  const Pix x = locate(a);
+  const int b = x.b, p = x.p;
+  const int RC = a.R * a.C;
+  Lobes<KP> L;
+  load_lobes<KP, true>(a, x, 0, L, false);
+  const SepTable rows = as_sep_table(a.rows);
+  const SepTable cst = as_sep_table(a.cols);
+  float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+  for (int e = 0; e < a.eh; ++e) {
+#pragma unroll
+    for (int k = 0; k < KP; ++k) { asm volatile("" : "+v"(L.ax[k])); asm volatile("" : "+v"(L.ay[k])); }
+    const f32x8 row = rows[e];
+    const float sr = row[0];
+    float Ck[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) Ck[k] = fmaf(L.az[k], row[1], -L.lp[k]);
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+#pragma unroll 1
+    for (int aq = 0; aq < NQ; ++aq) {
+      const f32x8 cs = cst[aq];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+          const float U = fmaf(L.ay[k], cs[2 * i + 1], L.ax[k] * cs[2 * i]);
+          const float ee = fexp2(fmaf(sr, U, Ck[k])) + fexp2(fmaf(-sr, U, Ck[k]));
+          r0 = fmaf(L.w0[k], ee, r0);
+          r1 = fmaf(L.w1[k], ee, r1);
+          r2 = fmaf(L.w2[k], ee, r2);
+        }
+      }
+    }
+    const float wrow = 0.5f * row[4];      // cos(El) sin(El)
+    d0 = fmaf(wrow, r0, d0); d1 = fmaf(wrow, r1, d1); d2 = fmaf(wrow, r2, d2);
+  }
+  if (x.active) {
+    const size_t o = (size_t)b * 3 * RC;
+    const unsigned up = (unsigned)p;
+    (a.diffuse + o)[up] = fmaxf(d0, 0.0f);
+    (a.diffuse + o + RC)[up] = fmaxf(d1, 0.0f);
+    (a.diffuse + o + 2 * (size_t)RC)[up] = fmaxf(d2, 0.0f);
+  }
+}
+
 // fast path applies to the reference's direction grids
 static inline bool fast_ok(const Args& a) { return (a.ew == 16 || a.ew == 32); }
 

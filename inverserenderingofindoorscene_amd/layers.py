@@ -27,7 +27,7 @@ import torch.nn.functional as F
 
 from . import _lib, tables
 
-__all__ = ["output2env", "renderingLayer", "render_from_sg", "renderLayer", "output_radiance"]
+__all__ = ["output2env", "renderingLayer", "render_from_sg", "renderLayer", "output_radiance", "predToShading"]
 
 
 # --------------------------------------------------------------------------- #
@@ -382,6 +382,33 @@ def render_from_sg(albedo, normal, rough, axisOrig, lambOrig, weightOrig, need_e
     layer = renderingLayer(imWidth=C, imHeight=R, fov=fov, F0=F0, cameraPos=list(cameraPos),
                            envWidth=envWidth, envHeight=envHeight)
     return layer.forwardSG(albedo, normal, rough, axisOrig, lambOrig, weightOrig, need_env=need_env)
+
+
+def predToShading(pred, envWidth=32, envHeight=16, SGNum=12):
+    """GPU version of ``utils.predToShading`` (utils.py:156-195): cosine-weighted irradiance per env cell from
+    the packed ``[.., 7*SGNum, envRow, envCol]`` light prediction (axis 3K, lamb K, weight 3K channels, the
+    cascade hand-off layout of wrapperBRDFLight.py:167-168).
+
+    numpy in -> numpy ``[3,envRow,envCol]`` out, like the reference (which takes a batch-1 array);
+    a HIP tensor ``[bn,7K,R,C]`` in -> tensor ``[bn,3,R,C]`` out.  Forward only."""
+    is_np = isinstance(pred, np.ndarray)
+    t = torch.from_numpy(np.ascontiguousarray(pred, dtype=np.float32)).cuda() if is_np else pred
+    dev = _require_hip(t)
+    if t.dim() != 4 or t.shape[1] != 7 * SGNum:
+        raise RuntimeError(f"sgrender: pred must be [bn,{7 * SGNum},envRow,envCol], got {tuple(t.shape)}")
+    bn, _, R, C = t.shape
+    K = SGNum
+    axis = t[:, 0:3 * K].reshape(bn, K, 3, R, C).contiguous()
+    lamb = t[:, 3 * K:4 * K].contiguous()
+    weight = t[:, 4 * K:7 * K].contiguous()
+    out = torch.empty((bn, 3, R, C), device=dev, dtype=torch.float32)
+    d = _dirs(dev, envHeight, envWidth)
+    with torch.cuda.device(dev):
+        _lib.call("sgr_sg_shading", _ptr(axis), _ptr(lamb), _ptr(weight), _ptr(d), _ptr(out), bn, K, R, C,
+                  envHeight, envWidth, 1, _stream(dev))
+    if is_np:
+        return out[0].cpu().numpy() if bn == 1 else out.cpu().numpy()
+    return out
 
 
 # --------------------------------------------------------------------------- #
