@@ -157,15 +157,16 @@ def main() -> None:
         bwd_bytes = P * (bpp["bwd_sg"] if need_env else bpp["bwd_sg"] - 3 * J * 4)
         fwd_gbps = fwd_bytes / (fwd_ms * 1e-3) / 1e9
         bwd_gbps = bwd_bytes / (bwd_ms * 1e-3) / 1e9
-        dom = ("sg_bwd_fast_kernel", bwd_ms, bwd_bytes, bwd_gbps) if bwd_ms >= fwd_ms else ("fwd_fast_kernel", fwd_ms, fwd_bytes, fwd_gbps)
-        # HBM bytes per launch from the PMC passes (tools/pmc_traffic.sh -> profiles/traffic.json), if recorded
-        traffic = None
+        dom = ("sg_bwd", bwd_ms, bwd_bytes, bwd_gbps) if bwd_ms >= fwd_ms else ("fwd_fast", fwd_ms, fwd_bytes, fwd_gbps)
+        # HBM bytes per launch from the PMC passes (tools/pmc_traffic.sh -> profiles/traffic.json), if recorded;
+        # the entry is matched by kernel family (the backward is sg_bwd_split_kernel / sg_bwd_fast_kernel)
+        traffic, dom_name = None, dom[0] + "_kernel"
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.isfile(tpath):
             try:
                 for name, rec in json.load(open(tpath)).items():
-                    if dom[0] in name:
-                        traffic = rec["hbm_bytes"]
+                    if ("::" + dom[0]) in name:
+                        traffic, dom_name = rec["hbm_bytes"], name.split("::")[-1].split("<")[0]
             except Exception:
                 traffic = None
         out = {
@@ -188,12 +189,12 @@ def main() -> None:
                        "Mshade_per_s": round(world * P / (dt / args.steps) / 1e6, 1),
                        "ms_per_step_with_render_loss": round(loss_step_ms, 4),
                        "parallelism": f"batch-sharded x{world}"},
-            "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(dom[3], 1), "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(dom[3], 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(dom[3] / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": dom[2], "avg_launch_ms": round(dom[1], 4)},
-            "kernels": {"fwd_fast_kernel": {"ms": round(fwd_ms, 4), "GBps": round(fwd_gbps, 1), "frac": round(fwd_gbps / HBM_PEAK_GBPS, 4),
+            "kernels": {"forward (fwd_fast_kernel)": {"ms": round(fwd_ms, 4), "GBps": round(fwd_gbps, 1), "frac": round(fwd_gbps / HBM_PEAK_GBPS, 4),
                                        "bytes": fwd_bytes},
-                        "sg_bwd_fast_kernel": {"ms": round(bwd_ms, 4), "GBps": round(bwd_gbps, 1), "frac": round(bwd_gbps / HBM_PEAK_GBPS, 4),
+                        "backward (sg_bwd_split_kernel)": {"ms": round(bwd_ms, 4), "GBps": round(bwd_gbps, 1), "frac": round(bwd_gbps / HBM_PEAK_GBPS, 4),
                                           "bytes": bwd_bytes}},
         }
         if world == 1 and not args.no_cpu_baseline and args.config == 2:

@@ -161,16 +161,29 @@ __global__ __launch_bounds__(kLossThreads) void loss_stage_c(const float* __rest
 }
 
 // ---- stage D: batch totals [num, den_raw] (this rank's shard) ----------------------------------
-__global__ void loss_stage_d(const float* __restrict__ wsA, const float* __restrict__ wsC, float* __restrict__ parts, int bn) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(kLossThreads) void loss_stage_d(const float* __restrict__ wsA, const float* __restrict__ wsC,
+                                                              float* __restrict__ parts, int bn) {
+  // deterministic: thread t adds entries t, t+256, ... in double, then a fixed LDS tree
+  __shared__ double lds[kLossThreads * 2];
   double num = 0.0, den = 0.0;
-  for (int b = 0; b < bn; ++b)
-    for (int s = 0; s < kSplit; ++s) {
-      num += (double)wsC[(size_t)b * kSplit + s];
-      den += (double)wsA[((size_t)b * kSplit + s) * 6 + 5];
+  for (int i = threadIdx.x; i < bn * kSplit; i += kLossThreads) {
+    num += (double)wsC[i];
+    den += (double)wsA[(size_t)i * 6 + 5];
+  }
+  lds[threadIdx.x * 2] = num;
+  lds[threadIdx.x * 2 + 1] = den;
+  __syncthreads();
+  for (int s = kLossThreads / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      lds[threadIdx.x * 2] += lds[(threadIdx.x + s) * 2];
+      lds[threadIdx.x * 2 + 1] += lds[(threadIdx.x + s) * 2 + 1];
     }
-  parts[0] = (float)num;
-  parts[1] = (float)den;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    parts[0] = (float)lds[0];
+    parts[1] = (float)lds[1];
+  }
 }
 
 // ---- backward: d(num)/d{diffuse, spec} * g_num ------------------------------------------------
@@ -280,7 +293,7 @@ extern "C" int sgr_render_loss_fwd(const float* diffuse, const float* spec, cons
     hipLaunchKernelGGL((loss_stage_a<2>), grid, block, 0, st, diffuse, spec, im, seg, im_small, seg_small, wsA, R, C, imH, imW);
   hipLaunchKernelGGL(loss_stage_b, grid, block, 0, st, diffuse, spec, im_small, wsA, wsB, 3 * RC);
   hipLaunchKernelGGL(loss_stage_c, grid, block, 0, st, diffuse, spec, im_small, seg_small, wsA, wsB, coef, rendered, wsC, RC);
-  hipLaunchKernelGGL(loss_stage_d, dim3(1), dim3(64), 0, st, wsA, wsC, parts, bn);
+  hipLaunchKernelGGL(loss_stage_d, dim3(1), dim3(kLossThreads), 0, st, wsA, wsC, parts, bn);
   return sgr_check((int)hipGetLastError(), "sgr_render_loss_fwd");
 }
 
