@@ -165,6 +165,12 @@ def test_sg_only_grads_like_trainlight(sgr, golden):
     dict(bn=1, imH=12, imW=20, R=6, C=10, K=24, eh=16, ew=32),   # config-5-like lobes / directions
     dict(bn=1, imH=10, imW=13, R=4, C=5, K=7, eh=4, ew=8),       # non-integer pooling ratio -> pre-pool
     dict(bn=1, imH=8, imW=8, R=8, C=8, K=32, eh=2, ew=4),        # maximum lobes, J=8 < one tile
+    # dispatch branches of the separable-table fast kernels (envWidth 16 / 32)
+    dict(bn=2, imH=9, imW=13, R=9, C=13, K=12, eh=8, ew=16),     # ratio-1 maps, RC = 117 (ragged last wave)
+    dict(bn=1, imH=12, imW=16, R=6, C=8, K=5, eh=8, ew=16),      # K <= 6: 6-lobe register groups
+    dict(bn=1, imH=12, imW=16, R=6, C=8, K=7, eh=7, ew=16),      # K padded to 12, odd envHeight
+    dict(bn=1, imH=12, imW=16, R=6, C=8, K=24, eh=4, ew=16),     # forward 24 lobes in registers, backward 2 groups
+    dict(bn=1, imH=10, imW=12, R=5, C=6, K=12, eh=3, ew=32),     # envWidth 32, single-buffered DMA rows
 ])
 def test_shapes_vs_oracle(sgr, shape):
     from oracle import sg_oracle as O
