@@ -695,7 +695,11 @@ __global__ __launch_bounds__(kWave, 2) void shading_fast_kernel(const Args a) {
   }
 }
 
-// fast path applies to the reference's direction grids
-static inline bool fast_ok(const Args& a) { return (a.ew == 16 || a.ew == 32); }
+// fast path applies to the reference's direction grids; the LDS-DMA descriptors and the 32-bit lane offsets
+// address one image's env tensor with signed 32-bit byte offsets
+static inline bool fast_ok(const Args& a) {
+  const long long env_bytes = 3LL * a.R * a.C * a.J * 4;
+  return (a.ew == 16 || a.ew == 32) && env_bytes < (1LL << 31);
+}
 
 }  // namespace sgr

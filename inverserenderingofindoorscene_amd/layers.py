@@ -68,6 +68,8 @@ class _DeviceTables:
     device when ``isCuda`` (models.py:454-459) and never moved by ``.to()``; keying by device
     keeps that behaviour while making one object usable from several ranks / devices."""
 
+    MAX_ENTRIES = 64      # testReal.py builds a layer per image size: keep the cache bounded
+
     def __init__(self):
         self._cache: Dict[Tuple, torch.Tensor] = {}
 
@@ -75,6 +77,8 @@ class _DeviceTables:
         k = key + (str(dev),)
         t = self._cache.get(k)
         if t is None:
+            if len(self._cache) >= self.MAX_ENTRIES:
+                self._cache.pop(next(iter(self._cache)))      # oldest entry
             t = torch.from_numpy(np.ascontiguousarray(make())).to(dev)
             self._cache[k] = t
         return t
