@@ -79,6 +79,7 @@ __device__ __forceinline__ void tile_store_global(const float* tile, float* __re
 #pragma unroll
       for (int it = 0; it < Tile<TJ>::kIts; ++it)
         v[c][it] = *reinterpret_cast<const float4*>(tile + (c * kWave + it * Tile<TJ>::kRowsPerIt + lrow) * Tile<TJ>::kStride + col);
+    const bool full = rows_valid >= kWave && (j0 + TJ) <= J;   // wave-uniform: every lane stores (all but a ragged last tile)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       float* cbase = env_img + ((size_t)c * RC + p0) * J + j0;   // wave-uniform
@@ -86,8 +87,10 @@ __device__ __forceinline__ void tile_store_global(const float* tile, float* __re
       for (int it = 0; it < Tile<TJ>::kIts; ++it) {
         const int row = it * Tile<TJ>::kRowsPerIt + lrow;
         float* dst = cbase + (size_t)(it * Tile<TJ>::kRowsPerIt) * J;   // uniform
-        if (row < rows_valid && col_ok) {
-          f32x4 nv = {v[c][it].x, v[c][it].y, v[c][it].z, v[c][it].w};
+        f32x4 nv = {v[c][it].x, v[c][it].y, v[c][it].z, v[c][it].w};
+        if (full) {
+          stream_store(nv, reinterpret_cast<f32x4*>(dst + lane_off));
+        } else if (row < rows_valid && col_ok) {
           stream_store(nv, reinterpret_cast<f32x4*>(dst + lane_off));
         }
       }

@@ -10,6 +10,7 @@
 // Everything else (lanes <-> pixels, LDS-transposed env tiles) is as in sgr_common.h.
 #pragma once
 #include "sgr_common.h"
+#include <type_traits>
 #include "sgr_launch.h"
 
 #ifndef SGR_FWD_DIRECT
@@ -87,11 +88,12 @@ __device__ __forceinline__ RowCtx make_row_ctx(const PixLocal& q, const f32x8 ro
   return rc;
 }
 typedef const f32x4 __attribute__((address_space(4))) * XTable;   // per azimuth (ca^2, 2 ca sa, sa^2, 0)
-__device__ __forceinline__ void shade_dir(const PixLocal& q, bool ortho, const RowCtx& rc, int sg, float ca, float sa, XTable xt,
-                                          int a, float& wt, float& sp) {
+template <bool ORTHO>
+__device__ __forceinline__ void shade_dir(const PixLocal& q, const RowCtx& rc, int sg, float ca, float sa, XTable xt, int a, float& wt,
+                                          float& sp) {
   const float ss = sg ? -rc.sr : rc.sr;
   const float Pv = fmaf(q.vBy, sa, q.vBx * ca);
-  if (ortho) {
+  if (ORTHO) {
     sp = brdf_ortho_dir(q, rc.ro, ss, ca, sa, Pv);
     wt = rc.ro.wt;
   } else {
@@ -137,104 +139,108 @@ __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
   const size_t img = (size_t)b * 3 * RC * a.J;
   const int ehp = RPC == 2 ? ((a.eh + 1) & ~1) : a.eh;
 
+  // the wave-uniform frame test is hoisted out of the direction loops: two copies of the row loop
+  auto row_loop = [&](auto ortho_c) {
   for (int e0 = 0; e0 < ehp; e0 += RPC) {
-    // U_ka = ax ca_a + ay sa_a does not depend on the row: keep LICM from hoisting all KP*EW/2 of them out
-    // of the row loop (they would not fit in registers) by making the axes opaque once per row.
-#pragma unroll
-    for (int k = 0; k < KP; ++k) { asm volatile("" : "+v"(L.ax[k])); asm volatile("" : "+v"(L.ay[k])); }
-    if (DO_RENDER) fence_row_invariants(q);
-    float sr[RPC], Ck[KP][RPC];
-    RowCtx rc[RPC];
-#pragma unroll
-    for (int r = 0; r < RPC; ++r) {
-      const f32x8 row = rows[e0 + r];
-      sr[r] = row[0];
-#pragma unroll
-      for (int k = 0; k < KP; ++k) Ck[k][r] = fmaf(L.az[k], row[1], -L.lp[k]);
-      rc[r] = make_row_ctx(q, row, DO_RENDER);
-    }
-#pragma unroll 1
-    for (int aq = 0; aq < NQ; ++aq) {
-      const f32x8 cs = cst[aq];  // (ca, sa) of the quad's four azimuths: one scalar load per quad
-      float acc[RPC][2][3][4];   // [row][sign][colour][azimuth in quad]
-#pragma unroll
-      for (int r = 0; r < RPC; ++r)
-#pragma unroll
-        for (int sg = 0; sg < 2; ++sg)
-#pragma unroll
-          for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[r][sg][c][i] = 0.0f;
-
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float ca = cs[2 * i], sa = cs[2 * i + 1];
-#pragma unroll
-        for (int k = 0; k < KP; ++k) {
-          const float U = fmaf(L.ay[k], sa, L.ax[k] * ca);
-#pragma unroll
-          for (int r = 0; r < RPC; ++r) {
-            const float ep = fexp2(fmaf(sr[r], U, Ck[k][r]));
-            const float em = fexp2(fmaf(-sr[r], U, Ck[k][r]));
-            acc[r][0][0][i] = fmaf(L.w0[k], ep, acc[r][0][0][i]);
-            acc[r][0][1][i] = fmaf(L.w1[k], ep, acc[r][0][1][i]);
-            acc[r][0][2][i] = fmaf(L.w2[k], ep, acc[r][0][2][i]);
-            acc[r][1][0][i] = fmaf(L.w0[k], em, acc[r][1][0][i]);
-            acc[r][1][1][i] = fmaf(L.w1[k], em, acc[r][1][1][i]);
-            acc[r][1][2][i] = fmaf(L.w2[k], em, acc[r][1][2][i]);
-          }
-        }
-        if (DO_RENDER) {
-#pragma unroll
-          for (int r = 0; r < RPC; ++r) {
-#pragma unroll
-            for (int sg = 0; sg < 2; ++sg) {
-              float wt, sp;
-              shade_dir(q, ortho, rc[r], sg, ca, sa, xt, aq * 4 + i, wt, sp);
-              const float sw = sp * wt;
-              d0 = fmaf(wt, acc[r][sg][0][i], d0);
-              d1 = fmaf(wt, acc[r][sg][1][i], d1);
-              d2 = fmaf(wt, acc[r][sg][2][i], d2);
-              s0 = fmaf(sw, acc[r][sg][0][i], s0);
-              s1 = fmaf(sw, acc[r][sg][1][i], s1);
-              s2 = fmaf(sw, acc[r][sg][2][i], s2);
+      // U_ka = ax ca_a + ay sa_a does not depend on the row: keep LICM from hoisting all KP*EW/2 of them out
+      // of the row loop (they would not fit in registers) by making the axes opaque once per row.
+  #pragma unroll
+      for (int k = 0; k < KP; ++k) { asm volatile("" : "+v"(L.ax[k])); asm volatile("" : "+v"(L.ay[k])); }
+      if (DO_RENDER) fence_row_invariants(q);
+      float sr[RPC], Ck[KP][RPC];
+      RowCtx rc[RPC];
+  #pragma unroll
+      for (int r = 0; r < RPC; ++r) {
+        const f32x8 row = rows[e0 + r];
+        sr[r] = row[0];
+  #pragma unroll
+        for (int k = 0; k < KP; ++k) Ck[k][r] = fmaf(L.az[k], row[1], -L.lp[k]);
+        rc[r] = make_row_ctx(q, row, DO_RENDER);
+      }
+  #pragma unroll 1
+      for (int aq = 0; aq < NQ; ++aq) {
+        const f32x8 cs = cst[aq];  // (ca, sa) of the quad's four azimuths: one scalar load per quad
+        float acc[RPC][2][3][4];   // [row][sign][colour][azimuth in quad]
+  #pragma unroll
+        for (int r = 0; r < RPC; ++r)
+  #pragma unroll
+          for (int sg = 0; sg < 2; ++sg)
+  #pragma unroll
+            for (int c = 0; c < 3; ++c)
+  #pragma unroll
+              for (int i = 0; i < 4; ++i) acc[r][sg][c][i] = 0.0f;
+  
+  #pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float ca = cs[2 * i], sa = cs[2 * i + 1];
+  #pragma unroll
+          for (int k = 0; k < KP; ++k) {
+            const float U = fmaf(L.ay[k], sa, L.ax[k] * ca);
+  #pragma unroll
+            for (int r = 0; r < RPC; ++r) {
+              const float ep = fexp2(fmaf(sr[r], U, Ck[k][r]));
+              const float em = fexp2(fmaf(-sr[r], U, Ck[k][r]));
+              acc[r][0][0][i] = fmaf(L.w0[k], ep, acc[r][0][0][i]);
+              acc[r][0][1][i] = fmaf(L.w1[k], ep, acc[r][0][1][i]);
+              acc[r][0][2][i] = fmaf(L.w2[k], ep, acc[r][0][2][i]);
+              acc[r][1][0][i] = fmaf(L.w0[k], em, acc[r][1][0][i]);
+              acc[r][1][1][i] = fmaf(L.w1[k], em, acc[r][1][1][i]);
+              acc[r][1][2][i] = fmaf(L.w2[k], em, acc[r][1][2][i]);
             }
           }
-        }
-#if SGR_DIR_BARRIER
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-      }
-      if (WRITE_ENV) {
-#if SGR_FWD_DIRECT
-        // experiment: per-lane 16-byte stores straight from registers (no LDS transpose)
-        if (x.active) {
-#pragma unroll
-          for (int r = 0; r < RPC; ++r)
-#pragma unroll
-            for (int sg = 0; sg < 2; ++sg)
-#pragma unroll
-              for (int c = 0; c < 3; ++c) {
-                float* base = a.env_out + img + (size_t)c * RC * a.J + (size_t)((e0 + r) * EW + sg * HALF + aq * 4);   // uniform
-                f32x4 nv = {acc[r][sg][c][0], acc[r][sg][c][1], acc[r][sg][c][2], acc[r][sg][c][3]};
-                *reinterpret_cast<f32x4*>(base + (unsigned)(p * a.J)) = nv;
+          if (DO_RENDER) {
+  #pragma unroll
+            for (int r = 0; r < RPC; ++r) {
+  #pragma unroll
+              for (int sg = 0; sg < 2; ++sg) {
+                float wt, sp;
+                shade_dir<decltype(ortho_c)::value>(q, rc[r], sg, ca, sa, xt, aq * 4 + i, wt, sp);
+                const float sw = sp * wt;
+                d0 = fmaf(wt, acc[r][sg][0][i], d0);
+                d1 = fmaf(wt, acc[r][sg][1][i], d1);
+                d2 = fmaf(wt, acc[r][sg][2][i], d2);
+                s0 = fmaf(sw, acc[r][sg][0][i], s0);
+                s1 = fmaf(sw, acc[r][sg][1][i], s1);
+                s2 = fmaf(sw, acc[r][sg][2][i], s2);
               }
+            }
+          }
+  #if SGR_DIR_BARRIER
+          __builtin_amdgcn_sched_barrier(0);
+  #endif
         }
-#else
-#pragma unroll
-        for (int r = 0; r < RPC; ++r)
-#pragma unroll
-          for (int sg = 0; sg < 2; ++sg)
-            tile_row_write<TJ>(tile, lane, r * EW + sg * HALF + aq * 4, acc[r][sg][0], acc[r][sg][1], acc[r][sg][2]);
-#endif
+        if (WRITE_ENV) {
+  #if SGR_FWD_DIRECT
+          // experiment: per-lane 16-byte stores straight from registers (no LDS transpose)
+          if (x.active) {
+  #pragma unroll
+            for (int r = 0; r < RPC; ++r)
+  #pragma unroll
+              for (int sg = 0; sg < 2; ++sg)
+  #pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                  float* base = a.env_out + img + (size_t)c * RC * a.J + (size_t)((e0 + r) * EW + sg * HALF + aq * 4);   // uniform
+                  f32x4 nv = {acc[r][sg][c][0], acc[r][sg][c][1], acc[r][sg][c][2], acc[r][sg][c][3]};
+                  *reinterpret_cast<f32x4*>(base + (unsigned)(p * a.J)) = nv;
+                }
+          }
+  #else
+  #pragma unroll
+          for (int r = 0; r < RPC; ++r)
+  #pragma unroll
+            for (int sg = 0; sg < 2; ++sg)
+              tile_row_write<TJ>(tile, lane, r * EW + sg * HALF + aq * 4, acc[r][sg][0], acc[r][sg][1], acc[r][sg][2]);
+  #endif
+        }
+      }
+      if (WRITE_ENV && !SGR_FWD_DIRECT) {
+        __syncthreads();
+        tile_store_global<TJ, true>(tile, a.env_out + img, x.p0, RC, a.J, e0 * EW, lane);
+        __syncthreads();
       }
     }
-    if (WRITE_ENV && !SGR_FWD_DIRECT) {
-      __syncthreads();
-      tile_store_global<TJ, true>(tile, a.env_out + img, x.p0, RC, a.J, e0 * EW, lane);
-      __syncthreads();
-    }
-  }
+  };
+  if (ortho) row_loop(std::true_type{}); else row_loop(std::false_type{});
 
   if (DO_RENDER && x.active) {
     const size_t o = (size_t)b * 3 * RC;
@@ -298,79 +304,83 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_fast_kernel(const Args a) {
 
     if (HAS_GENV) tile_dma_issue<TJ>(tile, gimg, x.p0, RC, a.J, 0, lane);
 
+    // the wave-uniform frame test is hoisted out of the direction loops: two copies of the row loop
+    auto row_loop = [&](auto ortho_c) {
     for (int e = 0; e < eh; ++e) {
-      const float* cur = tile + (NBUF == 2 ? (e & 1) * D::kFloats : 0);
-      if (HAS_GENV) {
-        if (NBUF == 2 && e + 1 < eh) {
-          tile_dma_issue<TJ>(tile + ((e + 1) & 1) * D::kFloats, gimg, x.p0, RC, a.J, (e + 1) * EW, lane);
-          wait_vmcnt<D::kInstr>();     // row e has landed; row e+1 stays in flight
-        } else {
-          wait_vmcnt<0>();
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < KP; ++k) { asm volatile("" : "+v"(L.ax[k])); asm volatile("" : "+v"(L.ay[k])); }   // no LICM of u_ka
-      if (HAS_RENDER) fence_row_invariants(q);
-      const f32x8 row = rows[e];
-      const float sr = row[0], cr = row[1];
-      const RowCtx rc = make_row_ctx(q, row, HAS_RENDER);
-#pragma unroll 1
-      for (int ap = 0; ap < NP; ++ap) {
-        const f32x4 cs = cst[ap];   // (ca, sa) of the pair's two azimuths
-        float g[2][3][2];   // [sign][colour][azimuth in pair]
+        const float* cur = tile + (NBUF == 2 ? (e & 1) * D::kFloats : 0);
         if (HAS_GENV) {
-          tile_dma_read_pairs<TJ>(cur, lane, ap * 2, HALF + ap * 2, g);
-        } else {
-#pragma unroll
-          for (int sg = 0; sg < 2; ++sg)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) g[sg][c][0] = g[sg][c][1] = 0.0f;
-        }
-        float ca[2], sa[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          ca[i] = cs[2 * i]; sa[i] = cs[2 * i + 1];
-          if (HAS_RENDER) {
-#pragma unroll
-            for (int sg = 0; sg < 2; ++sg) {
-              float wt, sp;
-              shade_dir(q, ortho, rc, sg, ca[i], sa[i], xt, ap * 2 + i, wt, sp);
-              g[sg][0][i] = fmaf(wt, fmaf(gs0, sp, gd0), g[sg][0][i]);
-              g[sg][1][i] = fmaf(wt, fmaf(gs1, sp, gd1), g[sg][1][i]);
-              g[sg][2][i] = fmaf(wt, fmaf(gs2, sp, gd2), g[sg][2][i]);
-            }
+          if (NBUF == 2 && e + 1 < eh) {
+            tile_dma_issue<TJ>(tile + ((e + 1) & 1) * D::kFloats, gimg, x.p0, RC, a.J, (e + 1) * EW, lane);
+            wait_vmcnt<D::kInstr>();     // row e has landed; row e+1 stays in flight
+          } else {
+            wait_vmcnt<0>();
           }
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < KP; ++k) {
-          const float czr = fmaf(L.az[k], cr, -1.0f);
-#pragma unroll
+  #pragma unroll
+        for (int k = 0; k < KP; ++k) { asm volatile("" : "+v"(L.ax[k])); asm volatile("" : "+v"(L.ay[k])); }   // no LICM of u_ka
+        if (HAS_RENDER) fence_row_invariants(q);
+        const f32x8 row = rows[e];
+        const float sr = row[0], cr = row[1];
+        const RowCtx rc = make_row_ctx(q, row, HAS_RENDER);
+  #pragma unroll 1
+        for (int ap = 0; ap < NP; ++ap) {
+          const f32x4 cs = cst[ap];   // (ca, sa) of the pair's two azimuths
+          float g[2][3][2];   // [sign][colour][azimuth in pair]
+          if (HAS_GENV) {
+            tile_dma_read_pairs<TJ>(cur, lane, ap * 2, HALF + ap * 2, g);
+          } else {
+  #pragma unroll
+            for (int sg = 0; sg < 2; ++sg)
+  #pragma unroll
+              for (int c = 0; c < 3; ++c) g[sg][c][0] = g[sg][c][1] = 0.0f;
+          }
+          float ca[2], sa[2];
+  #pragma unroll
           for (int i = 0; i < 2; ++i) {
-            const float u = fmaf(L.ay[k], sa[i], L.ax[k] * ca[i]);
-            float A = 0.0f;
-#pragma unroll
-            for (int sg = 0; sg < 2; ++sg) {
-              const float ss = sg ? -sr : sr;
-              const float t = fmaf(ss, u, czr);
-              const float ex = fexp2(L.lp[k] * t);
-              const float c0 = g[sg][0][i], c1 = g[sg][1][i], c2 = g[sg][2][i];
-              gw0[k] = fmaf(c0, ex, gw0[k]);
-              gw1[k] = fmaf(c1, ex, gw1[k]);
-              gw2[k] = fmaf(c2, ex, gw2[k]);
-              const float T = fmaf(c2, L.w2[k], fmaf(c1, L.w1[k], c0 * L.w0[k])) * ex;
-              glam[k] = fmaf(T, t, glam[k]);
-              A = fmaf(ss, T, A);
-              gaz[k] = fmaf(cr, T, gaz[k]);
+            ca[i] = cs[2 * i]; sa[i] = cs[2 * i + 1];
+            if (HAS_RENDER) {
+  #pragma unroll
+              for (int sg = 0; sg < 2; ++sg) {
+                float wt, sp;
+                shade_dir<decltype(ortho_c)::value>(q, rc, sg, ca[i], sa[i], xt, ap * 2 + i, wt, sp);
+                g[sg][0][i] = fmaf(wt, fmaf(gs0, sp, gd0), g[sg][0][i]);
+                g[sg][1][i] = fmaf(wt, fmaf(gs1, sp, gd1), g[sg][1][i]);
+                g[sg][2][i] = fmaf(wt, fmaf(gs2, sp, gd2), g[sg][2][i]);
+              }
             }
-            gax[k] = fmaf(ca[i], A, gax[k]);
-            gay[k] = fmaf(sa[i], A, gay[k]);
           }
+          __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+          for (int k = 0; k < KP; ++k) {
+            const float czr = fmaf(L.az[k], cr, -1.0f);
+  #pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const float u = fmaf(L.ay[k], sa[i], L.ax[k] * ca[i]);
+              float A = 0.0f;
+  #pragma unroll
+              for (int sg = 0; sg < 2; ++sg) {
+                const float ss = sg ? -sr : sr;
+                const float t = fmaf(ss, u, czr);
+                const float ex = fexp2(L.lp[k] * t);
+                const float c0 = g[sg][0][i], c1 = g[sg][1][i], c2 = g[sg][2][i];
+                gw0[k] = fmaf(c0, ex, gw0[k]);
+                gw1[k] = fmaf(c1, ex, gw1[k]);
+                gw2[k] = fmaf(c2, ex, gw2[k]);
+                const float T = fmaf(c2, L.w2[k], fmaf(c1, L.w1[k], c0 * L.w0[k])) * ex;
+                glam[k] = fmaf(T, t, glam[k]);
+                A = fmaf(ss, T, A);
+                gaz[k] = fmaf(cr, T, gaz[k]);
+              }
+              gax[k] = fmaf(ca[i], A, gax[k]);
+              gay[k] = fmaf(sa[i], A, gay[k]);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if (HAS_GENV && NBUF == 1 && e + 1 < eh) tile_dma_issue<TJ>(tile, gimg, x.p0, RC, a.J, (e + 1) * EW, lane);
       }
-      if (HAS_GENV && NBUF == 1 && e + 1 < eh) tile_dma_issue<TJ>(tile, gimg, x.p0, RC, a.J, (e + 1) * EW, lane);
-    }
+    };
+    if (ortho) row_loop(std::true_type{}); else row_loop(std::false_type{});
 
     if (x.active) {
 #pragma unroll
@@ -458,91 +468,95 @@ __global__ __launch_bounds__(2 * kWave, 3) void sg_bwd_split_kernel(const Args a
 
     if (HAS_GENV) tile_dma_issue_part<TJ>(tile, gimg, x.p0, RC, a.J, 0, lane, wave, 2);
 
+    // the wave-uniform frame test is hoisted out of the direction loops: two copies of the row loop
+    auto row_loop = [&](auto ortho_c) {
     for (int e = 0; e < eh; ++e) {
-      float* cur = tile + (HAS_GENV ? (e & 1) * D::kFloats : 0);
-      if (HAS_GENV) {
-        if (e + 1 < eh) {
-          tile_dma_issue_part<TJ>(tile + ((e + 1) & 1) * D::kFloats, gimg, x.p0, RC, a.J, (e + 1) * EW, lane, wave, 2);
-          wait_vmcnt<6>();        // this wave's half of row e has landed; its half of row e+1 stays in flight
-        } else {
-          wait_vmcnt<0>();
+        float* cur = tile + (HAS_GENV ? (e & 1) * D::kFloats : 0);
+        if (HAS_GENV) {
+          if (e + 1 < eh) {
+            tile_dma_issue_part<TJ>(tile + ((e + 1) & 1) * D::kFloats, gimg, x.p0, RC, a.J, (e + 1) * EW, lane, wave, 2);
+            wait_vmcnt<6>();        // this wave's half of row e has landed; its half of row e+1 stays in flight
+          } else {
+            wait_vmcnt<0>();
+          }
+          barrier_lds_only();       // ... and so has the other wave's half
         }
-        barrier_lds_only();       // ... and so has the other wave's half
-      }
-#pragma unroll
-      for (int k = 0; k < KPW; ++k) { asm volatile("" : "+v"(L.ax[k])); asm volatile("" : "+v"(L.ay[k])); }   // no LICM of u_ka
-      if (HAS_RENDER) fence_row_invariants(q);
-      const f32x8 row = rows[e];
-      const float sr = row[0], cr = row[1];
-      const RowCtx rc = make_row_ctx(q, row, HAS_RENDER);
-
-      // ---- 2. quadrature contribution, this wave's half of the directions, added in place ------------
-      if (HAS_RENDER) {
-#pragma unroll 1
-        for (int h = 0; h < 2; ++h) {
-          const int ap = wave * 2 + h;
+  #pragma unroll
+        for (int k = 0; k < KPW; ++k) { asm volatile("" : "+v"(L.ax[k])); asm volatile("" : "+v"(L.ay[k])); }   // no LICM of u_ka
+        if (HAS_RENDER) fence_row_invariants(q);
+        const f32x8 row = rows[e];
+        const float sr = row[0], cr = row[1];
+        const RowCtx rc = make_row_ctx(q, row, HAS_RENDER);
+  
+        // ---- 2. quadrature contribution, this wave's half of the directions, added in place ------------
+        if (HAS_RENDER) {
+  #pragma unroll 1
+          for (int h = 0; h < 2; ++h) {
+            const int ap = wave * 2 + h;
+            const f32x4 cs = cst[ap];
+            float g[2][3][2];
+            if (HAS_GENV) {
+              tile_dma_read_pairs<TJ>(cur, lane, ap * 2, HALF + ap * 2, g);
+            } else {
+  #pragma unroll
+              for (int sg = 0; sg < 2; ++sg)
+  #pragma unroll
+                for (int c = 0; c < 3; ++c) g[sg][c][0] = g[sg][c][1] = 0.0f;
+            }
+  #pragma unroll
+            for (int i = 0; i < 2; ++i) {
+  #pragma unroll
+              for (int sg = 0; sg < 2; ++sg) {
+                float wt, sp;
+                shade_dir<decltype(ortho_c)::value>(q, rc, sg, cs[2 * i], cs[2 * i + 1], xt, ap * 2 + i, wt, sp);
+                g[sg][0][i] = fmaf(wt, fmaf(gs0, sp, gd0), g[sg][0][i]);
+                g[sg][1][i] = fmaf(wt, fmaf(gs1, sp, gd1), g[sg][1][i]);
+                g[sg][2][i] = fmaf(wt, fmaf(gs2, sp, gd2), g[sg][2][i]);
+              }
+            }
+            tile_dma_write_pairs<TJ>(cur, lane, ap * 2, HALF + ap * 2, g);
+          }
+          barrier_lds_only();
+        }
+  
+        // ---- 3. all directions of the row, this wave's lobes ---------------------------------------------
+  #pragma unroll 1
+        for (int ap = 0; ap < NP; ++ap) {
           const f32x4 cs = cst[ap];
           float g[2][3][2];
-          if (HAS_GENV) {
-            tile_dma_read_pairs<TJ>(cur, lane, ap * 2, HALF + ap * 2, g);
-          } else {
-#pragma unroll
-            for (int sg = 0; sg < 2; ++sg)
-#pragma unroll
-              for (int c = 0; c < 3; ++c) g[sg][c][0] = g[sg][c][1] = 0.0f;
-          }
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int sg = 0; sg < 2; ++sg) {
-              float wt, sp;
-              shade_dir(q, ortho, rc, sg, cs[2 * i], cs[2 * i + 1], xt, ap * 2 + i, wt, sp);
-              g[sg][0][i] = fmaf(wt, fmaf(gs0, sp, gd0), g[sg][0][i]);
-              g[sg][1][i] = fmaf(wt, fmaf(gs1, sp, gd1), g[sg][1][i]);
-              g[sg][2][i] = fmaf(wt, fmaf(gs2, sp, gd2), g[sg][2][i]);
+          tile_dma_read_pairs<TJ>(cur, lane, ap * 2, HALF + ap * 2, g);
+          float ca[2] = {cs[0], cs[2]}, sa[2] = {cs[1], cs[3]};
+  #pragma unroll
+          for (int k = 0; k < KPW; ++k) {
+            const float czr = fmaf(L.az[k], cr, -1.0f);
+  #pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const float u = fmaf(L.ay[k], sa[i], L.ax[k] * ca[i]);
+              float A = 0.0f;
+  #pragma unroll
+              for (int sg = 0; sg < 2; ++sg) {
+                const float ss = sg ? -sr : sr;
+                const float t = fmaf(ss, u, czr);
+                const float ex = fexp2(L.lp[k] * t);
+                const float c0 = g[sg][0][i], c1 = g[sg][1][i], c2 = g[sg][2][i];
+                gw0[k] = fmaf(c0, ex, gw0[k]);
+                gw1[k] = fmaf(c1, ex, gw1[k]);
+                gw2[k] = fmaf(c2, ex, gw2[k]);
+                const float T = fmaf(c2, L.w2[k], fmaf(c1, L.w1[k], c0 * L.w0[k])) * ex;
+                glam[k] = fmaf(T, t, glam[k]);
+                A = fmaf(ss, T, A);
+                gaz[k] = fmaf(cr, T, gaz[k]);
+              }
+              gax[k] = fmaf(ca[i], A, gax[k]);
+              gay[k] = fmaf(sa[i], A, gay[k]);
             }
           }
-          tile_dma_write_pairs<TJ>(cur, lane, ap * 2, HALF + ap * 2, g);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        barrier_lds_only();
+        barrier_lds_only();   // both waves are done with `cur` before it is refilled / rewritten
       }
-
-      // ---- 3. all directions of the row, this wave's lobes ---------------------------------------------
-#pragma unroll 1
-      for (int ap = 0; ap < NP; ++ap) {
-        const f32x4 cs = cst[ap];
-        float g[2][3][2];
-        tile_dma_read_pairs<TJ>(cur, lane, ap * 2, HALF + ap * 2, g);
-        float ca[2] = {cs[0], cs[2]}, sa[2] = {cs[1], cs[3]};
-#pragma unroll
-        for (int k = 0; k < KPW; ++k) {
-          const float czr = fmaf(L.az[k], cr, -1.0f);
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const float u = fmaf(L.ay[k], sa[i], L.ax[k] * ca[i]);
-            float A = 0.0f;
-#pragma unroll
-            for (int sg = 0; sg < 2; ++sg) {
-              const float ss = sg ? -sr : sr;
-              const float t = fmaf(ss, u, czr);
-              const float ex = fexp2(L.lp[k] * t);
-              const float c0 = g[sg][0][i], c1 = g[sg][1][i], c2 = g[sg][2][i];
-              gw0[k] = fmaf(c0, ex, gw0[k]);
-              gw1[k] = fmaf(c1, ex, gw1[k]);
-              gw2[k] = fmaf(c2, ex, gw2[k]);
-              const float T = fmaf(c2, L.w2[k], fmaf(c1, L.w1[k], c0 * L.w0[k])) * ex;
-              glam[k] = fmaf(T, t, glam[k]);
-              A = fmaf(ss, T, A);
-              gaz[k] = fmaf(cr, T, gaz[k]);
-            }
-            gax[k] = fmaf(ca[i], A, gax[k]);
-            gay[k] = fmaf(sa[i], A, gay[k]);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      barrier_lds_only();   // both waves are done with `cur` before it is refilled / rewritten
-    }
+    };
+    if (ortho) row_loop(std::true_type{}); else row_loop(std::false_type{});
 
     if (x.active) {
 #pragma unroll
@@ -599,39 +613,43 @@ __global__ __launch_bounds__(kWave, 4) void render_fast_kernel(const Args a) {
   float d0 = 0.f, d1 = 0.f, d2 = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
 
   tile_dma_issue<TJ>(tile, eimg, x.p0, RC, a.J, 0, lane);
+  // the wave-uniform frame test is hoisted out of the direction loops: two copies of the row loop
+  auto row_loop = [&](auto ortho_c) {
   for (int e = 0; e < eh; ++e) {
-    const float* cur = tile + (NBUF == 2 ? (e & 1) * D::kFloats : 0);
-    if (NBUF == 2 && e + 1 < eh) {
-      tile_dma_issue<TJ>(tile + ((e + 1) & 1) * D::kFloats, eimg, x.p0, RC, a.J, (e + 1) * EW, lane);
-      wait_vmcnt<D::kInstr>();
-    } else {
-      wait_vmcnt<0>();
-    }
-    fence_row_invariants(q);
-    const RowCtx rc = make_row_ctx(q, rows[e], true);
-#pragma unroll 1
-    for (int ap = 0; ap < NP; ++ap) {
-      const f32x4 cs = cst[ap];
-      float g[2][3][2];
-      tile_dma_read_pairs<TJ>(cur, lane, ap * 2, HALF + ap * 2, g);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int sg = 0; sg < 2; ++sg) {
-          float wt, sp;
-          shade_dir(q, ortho, rc, sg, cs[2 * i], cs[2 * i + 1], xt, ap * 2 + i, wt, sp);
-          const float sw = sp * wt;
-          d0 = fmaf(wt, g[sg][0][i], d0);
-          d1 = fmaf(wt, g[sg][1][i], d1);
-          d2 = fmaf(wt, g[sg][2][i], d2);
-          s0 = fmaf(sw, g[sg][0][i], s0);
-          s1 = fmaf(sw, g[sg][1][i], s1);
-          s2 = fmaf(sw, g[sg][2][i], s2);
+      const float* cur = tile + (NBUF == 2 ? (e & 1) * D::kFloats : 0);
+      if (NBUF == 2 && e + 1 < eh) {
+        tile_dma_issue<TJ>(tile + ((e + 1) & 1) * D::kFloats, eimg, x.p0, RC, a.J, (e + 1) * EW, lane);
+        wait_vmcnt<D::kInstr>();
+      } else {
+        wait_vmcnt<0>();
+      }
+      fence_row_invariants(q);
+      const RowCtx rc = make_row_ctx(q, rows[e], true);
+  #pragma unroll 1
+      for (int ap = 0; ap < NP; ++ap) {
+        const f32x4 cs = cst[ap];
+        float g[2][3][2];
+        tile_dma_read_pairs<TJ>(cur, lane, ap * 2, HALF + ap * 2, g);
+  #pragma unroll
+        for (int i = 0; i < 2; ++i) {
+  #pragma unroll
+          for (int sg = 0; sg < 2; ++sg) {
+            float wt, sp;
+            shade_dir<decltype(ortho_c)::value>(q, rc, sg, cs[2 * i], cs[2 * i + 1], xt, ap * 2 + i, wt, sp);
+            const float sw = sp * wt;
+            d0 = fmaf(wt, g[sg][0][i], d0);
+            d1 = fmaf(wt, g[sg][1][i], d1);
+            d2 = fmaf(wt, g[sg][2][i], d2);
+            s0 = fmaf(sw, g[sg][0][i], s0);
+            s1 = fmaf(sw, g[sg][1][i], s1);
+            s2 = fmaf(sw, g[sg][2][i], s2);
+          }
         }
       }
+      if (NBUF == 1 && e + 1 < eh) tile_dma_issue<TJ>(tile, eimg, x.p0, RC, a.J, (e + 1) * EW, lane);
     }
-    if (NBUF == 1 && e + 1 < eh) tile_dma_issue<TJ>(tile, eimg, x.p0, RC, a.J, (e + 1) * EW, lane);
-  }
+  };
+  if (ortho) row_loop(std::true_type{}); else row_loop(std::false_type{});
   if (x.active) {
     const size_t o = (size_t)b * 3 * RC;
     const unsigned up = (unsigned)p;
