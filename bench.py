@@ -65,6 +65,8 @@ def main() -> None:
         raise SystemExit("bench.py needs a GPU: the render layer has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:       # input generation is CPU work: do not oversubscribe the host with world x all-core thread pools
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)

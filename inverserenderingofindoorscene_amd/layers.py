@@ -383,9 +383,17 @@ def render_from_sg(albedo, normal, rough, axisOrig, lambOrig, weightOrig, need_e
                    cameraPos=(0, 0, 0), envWidth=16, envHeight=8):
     """Functional form of :meth:`renderingLayer.forwardSG` (env grid taken from the SG tensors)."""
     R, C = axisOrig.shape[3], axisOrig.shape[4]
-    layer = renderingLayer(imWidth=C, imHeight=R, fov=fov, F0=F0, cameraPos=list(cameraPos),
-                           envWidth=envWidth, envHeight=envHeight)
+    key = (C, R, float(fov), float(F0), tuple(float(c) for c in cameraPos), envWidth, envHeight)
+    layer = _LAYERS.get(key)
+    if layer is None:
+        if len(_LAYERS) >= 32:
+            _LAYERS.pop(next(iter(_LAYERS)))
+        layer = _LAYERS[key] = renderingLayer(imWidth=C, imHeight=R, fov=fov, F0=F0, cameraPos=list(cameraPos),
+                                              envWidth=envWidth, envHeight=envHeight)
     return layer.forwardSG(albedo, normal, rough, axisOrig, lambOrig, weightOrig, need_env=need_env)
+
+
+_LAYERS: Dict[Tuple, "renderingLayer"] = {}
 
 
 def predToShading(pred, envWidth=32, envHeight=16, SGNum=12):
