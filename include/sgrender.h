@@ -184,6 +184,36 @@ int sgr_recon_loss_bwd(const float* g_num, const float* env, const float* env_gt
                        const float* coef, float* g_env,
                        int bn, int R, int C, int eh, int ew, float offset, void* stream);
 
+/* ---- trainLight objective without the env image (fully fused) --------------
+ * wrapperBRDFLight.py:172-207 in two heavy passes; neither the predicted env image (:177) nor its
+ * cotangent is ever written.  Needs ew == 16 and K <= 12 (sgr_fused_recon_supported; SGR_ERR_UNSUPPORTED
+ * otherwise -- use sgr_fused_fwd + sgr_recon_loss_* there).  Workspace is shared by the two calls. */
+int sgr_fused_recon_supported(int K, int R, int C, int eh, int ew);
+int sgr_fused_recon_workspace_floats(int bn, int R, int C);
+
+/* Forward: sgr_fused_fwd without the env output, plus the statistics of sgr_recon_loss_fwd stage 0 taken on
+ * the fly against env_gt:  diffuse, spec [bn,3,R,C];  mask [bn,R*C];  coef [bn] (LSregress scale, models.py:7-21);
+ * parts = (0, sum mask) for this rank's shard. */
+int sgr_fused_fwd_recon(const float* albedo, const float* normal, const float* rough, const float* axis,
+                        const float* lamb, const float* weight, const float* dirs, const float* view,
+                        const float* env_gt, const float* seg_small, const float* env_ind,
+                        float* diffuse, float* spec, float* mask, float* coef, float* parts, float* workspace,
+                        int bn, int K, int R, int C, int eh, int ew, int imH, int imW, float F0, int premap,
+                        void* stream);
+
+/* Backward of  objective = (render terms, through g_diffuse / g_spec) + rec_weight * reconstErr,
+ *   reconstErr = num / max(den, 1e-5) / 3 / (eh*ew),  num = sum mask (log(coef env + offset) - log(env_gt + offset))^2,
+ * w.r.t. the SG parameters, with env recomputed in registers.  den = *den_global when given (the mask sum
+ * all-reduced over ranks) else this shard's own.  Also returns parts = (num, local sum mask): the loss value
+ * comes out of the same pass.  g_axis [bn,K,3,R,C]  g_lamb [bn,K,R,C]  g_weight [bn,3K,R,C]. */
+int sgr_fused_bwd_recon(const float* albedo, const float* normal, const float* rough, const float* axis,
+                        const float* lamb, const float* weight, const float* dirs, const float* view,
+                        const float* env_gt, const float* mask, const float* coef, const float* den_global,
+                        const float* g_diffuse, const float* g_spec,
+                        float* g_axis, float* g_lamb, float* g_weight, float* parts, float* workspace,
+                        int bn, int K, int R, int C, int eh, int ew, int imH, int imW, float F0, int premap,
+                        float offset, float rec_weight, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

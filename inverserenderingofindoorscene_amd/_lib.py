@@ -56,6 +56,10 @@ SIGNATURES = {
     "sgr_recon_workspace_floats": ([_I, _I, _I], c_int),
     "sgr_recon_loss_fwd": ([_P] * 8 + [_I] * 5 + [_F, _P], c_int),
     "sgr_recon_loss_bwd": ([_P] * 6 + [_I] * 5 + [_F, _P], c_int),
+    "sgr_fused_recon_supported": ([_I] * 5, c_int),
+    "sgr_fused_recon_workspace_floats": ([_I, _I, _I], c_int),
+    "sgr_fused_fwd_recon": ([_P] * 17 + [_I] * 8 + [_F, _I, _P], c_int),
+    "sgr_fused_bwd_recon": ([_P] * 19 + [_I] * 8 + [_F, _I, _F, _F, _P], c_int),
 }
 
 _lib = None

@@ -327,6 +327,16 @@ struct Args {
   const float* g_env;     // [bn,3,R,C,J]
   const float* g_diffuse; // [bn,3,R,C]
   const float* g_spec;    // [bn,3,R,C]
+  // env reconstruction (fused objective): ground-truth env, pooled env mask inputs, per-image scale
+  const float* env_gt;    // [bn,3,R,C,J]
+  const float* seg_small; // [bn,R,C]
+  const float* env_ind;   // [bn]
+  const float* coef;      // [bn]      LSregress scale (constant in backward)
+  const float* mask_in;   // [bn,R,C]  env mask from the forward pass
+  const float* rec_scale; // [1]       d objective / d num
+  float* mask;            // [bn,R,C]
+  float* ws;              // per-wave partial sums
+  float offset;
   // outputs
   float* env_out;         // [bn,3,R,C,J]
   float* lamb_tan;        // [bn,K,R,C]     nullable

@@ -13,6 +13,12 @@
 #include <type_traits>
 #include "sgr_launch.h"
 
+#ifndef SGR_F1_NOSTATS
+#define SGR_F1_NOSTATS 0
+#endif
+#ifndef SGR_F1_NODMA
+#define SGR_F1_NODMA 0
+#endif
 #ifndef SGR_FWD_DIRECT
 #define SGR_FWD_DIRECT 0
 #endif
@@ -109,13 +115,21 @@ __device__ __forceinline__ void shade_dir(const PixLocal& q, const RowCtx& rc, i
 }
 
 // ============================== forward ==========================================================
-template <int KP, int POOL, int EW, int TJ, bool WRITE_ENV, bool DO_RENDER>
+//
+// HAS_GT (fused objective, no env image): the ground-truth env rows stream in by double-buffered LDS-DMA
+// and every lane accumulates <pred, gt>, <pred, pred> and sum(gt) of its pixel on the fly -- the statistics
+// behind the env mask and the LSregress scale (wrapperBRDFLight.py:172-176, models.py:7-21) -- so the
+// predicted env never goes to memory.  Per-wave partials land in a.ws[(b*tiles + tile)*3 + {0,1,2}].
+template <int KP, int POOL, int EW, int TJ, bool WRITE_ENV, bool DO_RENDER, bool HAS_GT = false>
 __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
   static_assert(TJ % EW == 0, "a tile holds whole table rows");
+  static_assert(!HAS_GT || (TJ == EW && EW == 16 && !WRITE_ENV), "fused statistics: one 16-direction row per tile, no env output");
   constexpr int RPC = TJ / EW;      // table rows per tile (TJ=32: 2 for EW=16, 1 for EW=32)
   constexpr int HALF = EW / 2;
   constexpr int NQ = HALF / 4;      // azimuth quads per half row
   __shared__ __attribute__((aligned(16))) float tile[WRITE_ENV ? Tile<TJ>::kFloats : 4];
+  using GD = DmaTile<16>;
+  __shared__ __attribute__((aligned(16))) float gtile[HAS_GT ? 2 * GD::kFloats : 4];
 
   const Pix x = locate(a);
   const int lane = x.lane, b = x.b, p = x.p;
@@ -138,10 +152,22 @@ __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
   const XTable xt = (XTable)(a.cols + EW);                                     // extras, general path only
   const size_t img = (size_t)b * 3 * RC * a.J;
   const int ehp = RPC == 2 ? ((a.eh + 1) & ~1) : a.eh;
+  float s_pg = 0.f, s_pp = 0.f, s_g = 0.f;
+  __amdgpu_buffer_rsrc_t gimg = env_rsrc(HAS_GT ? a.env_gt + img : a.view, RC, a.J);
+  if (HAS_GT && !SGR_F1_NODMA) tile_dma_issue<16>(gtile, gimg, x.p0, RC, a.J, 0, lane);
 
   // the wave-uniform frame test is hoisted out of the direction loops: two copies of the row loop
   auto row_loop = [&](auto ortho_c) {
   for (int e0 = 0; e0 < ehp; e0 += RPC) {
+      const float* gcur = gtile + (e0 & 1) * GD::kFloats;
+      if (HAS_GT && !SGR_F1_NODMA) {
+        if (e0 + 1 < ehp) {
+          tile_dma_issue<16>(gtile + ((e0 + 1) & 1) * GD::kFloats, gimg, x.p0, RC, a.J, (e0 + 1) * EW, lane);
+          wait_vmcnt<GD::kInstr>();      // row e0 has landed; row e0+1 stays in flight
+        } else {
+          wait_vmcnt<0>();
+        }
+      }
       // U_ka = ax ca_a + ay sa_a does not depend on the row: keep LICM from hoisting all KP*EW/2 of them out
       // of the row loop (they would not fit in registers) by making the axes opaque once per row.
   #pragma unroll
@@ -209,6 +235,24 @@ __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
           __builtin_amdgcn_sched_barrier(0);
   #endif
         }
+        if (HAS_GT && !SGR_F1_NOSTATS) {
+  #pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            float g[2][3][2];
+            tile_dma_read_pairs<16>(gcur, lane, aq * 4 + 2 * h, HALF + aq * 4 + 2 * h, g);
+  #pragma unroll
+            for (int sg = 0; sg < 2; ++sg)
+  #pragma unroll
+              for (int c = 0; c < 3; ++c)
+  #pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                  const float pv = acc[0][sg][c][2 * h + i], gv = g[sg][c][i];
+                  s_pg = fmaf(pv, gv, s_pg);
+                  s_pp = fmaf(pv, pv, s_pp);
+                  s_g += gv;
+                }
+          }
+        }
         if (WRITE_ENV) {
   #if SGR_FWD_DIRECT
           // experiment: per-lane 16-byte stores straight from registers (no LDS transpose)
@@ -242,6 +286,21 @@ __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
   };
   if (ortho) row_loop(std::true_type{}); else row_loop(std::false_type{});
 
+  if (HAS_GT) {
+    // env mask of the pixel (wrapperBRDFLight.py:172-174) and the wave's share of the per-image sums
+    const float not_dark = (s_g / (3.0f * (float)a.J)) > 0.001f ? 1.0f : 0.0f;
+    const float m = x.active ? (a.seg_small + (size_t)b * RC)[(unsigned)p] * a.env_ind[b] * not_dark : 0.0f;
+    if (x.active) (a.mask + (size_t)b * RC)[(unsigned)p] = m;
+    float r0 = m * m * s_pg, r1 = m * m * s_pp, r2 = m;
+  #pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      r0 += __shfl_xor(r0, off, 64); r1 += __shfl_xor(r1, off, 64); r2 += __shfl_xor(r2, off, 64);
+    }
+    if (lane == 0) {
+      float* w = a.ws + (size_t)blockIdx.x * 3;
+      w[0] = r0; w[1] = r1; w[2] = r2;
+    }
+  }
   if (DO_RENDER && x.active) {
     const size_t o = (size_t)b * 3 * RC;
     const unsigned up = (unsigned)p;

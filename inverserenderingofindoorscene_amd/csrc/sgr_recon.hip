@@ -14,11 +14,10 @@
 //   stage 1: num = sum mask (log(coef pred + off) - log(gt + off))^2                   (:183-187)
 //   backward: dnum/dpred = 2 mask (log(coef pred + off) - log(gt + off)) coef / (coef pred + off)
 //            (coef is a constant: models.py:13 detaches it)
-#include "sgr_launch.h"
+#include "sgr_recon_fold.h"
 
 namespace sgr {
 
-constexpr int kRThreads = 256;
 constexpr int kRWaves = kRThreads / 64;
 constexpr int kPixPerBlock = 64;
 
@@ -93,41 +92,6 @@ __global__ __launch_bounds__(kRThreads) void recon_stage0(const float* __restric
   }
 }
 
-// deterministic block sum in double: thread t adds elements t, t+256, ...; fixed LDS tree afterwards
-template <int N>
-__device__ __forceinline__ void block_sum_double(double (&v)[N], double* lds /* [256*N] */) {
-#pragma unroll
-  for (int i = 0; i < N; ++i) lds[threadIdx.x * N + i] = v[i];
-  __syncthreads();
-  for (int s = kRThreads / 2; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) {
-#pragma unroll
-      for (int i = 0; i < N; ++i) lds[threadIdx.x * N + i] += lds[(threadIdx.x + s) * N + i];
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int i = 0; i < N; ++i) v[i] = lds[i];
-}
-
-// fold stage-0 partials: coef[b], den partial per image   (one block per image)
-__global__ __launch_bounds__(kRThreads) void recon_fold0(const float* __restrict__ ws, float* __restrict__ coef,
-                                                          float* __restrict__ den_img, int nblk) {
-  __shared__ double lds[kRThreads * 3];
-  const int b = blockIdx.x;
-  double v[3] = {0.0, 0.0, 0.0};
-  for (int i = threadIdx.x; i < nblk; i += kRThreads) {
-    v[0] += (double)ws[((size_t)b * nblk + i) * 3 + 0];
-    v[1] += (double)ws[((size_t)b * nblk + i) * 3 + 1];
-    v[2] += (double)ws[((size_t)b * nblk + i) * 3 + 2];
-  }
-  block_sum_double<3>(v, lds);
-  if (threadIdx.x == 0) {
-    coef[b] = fminf(fmaxf((float)v[0] / fmaxf((float)v[1], 1e-5f), 0.001f), 1000.0f);
-    den_img[b] = (float)v[2];
-  }
-}
-
 __global__ __launch_bounds__(kRThreads) void recon_stage1(const float* __restrict__ env, const float* __restrict__ gt,
                                                            const float* __restrict__ mask, const float* __restrict__ coef,
                                                            float* __restrict__ ws /* [bn,nblk] */, int RC, int J, int nblk, float offset) {
@@ -175,19 +139,6 @@ __global__ __launch_bounds__(kRThreads) void recon_stage1(const float* __restric
   if (lane == 0) red[wave] = acc;
   __syncthreads();
   if (threadIdx.x == 0) ws[(size_t)b * nblk + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-}
-
-__global__ __launch_bounds__(kRThreads) void recon_fold1(const float* __restrict__ ws, const float* __restrict__ den_img,
-                                                          float* __restrict__ parts, int bn, int nblk) {
-  __shared__ double lds[kRThreads * 2];
-  double v[2] = {0.0, 0.0};
-  for (int i = threadIdx.x; i < bn * nblk; i += kRThreads) v[0] += (double)ws[i];
-  for (int i = threadIdx.x; i < bn; i += kRThreads) v[1] += (double)den_img[i];
-  block_sum_double<2>(v, lds);
-  if (threadIdx.x == 0) {
-    parts[0] = (float)v[0];
-    parts[1] = (float)v[1];
-  }
 }
 
 __global__ __launch_bounds__(kRThreads) void recon_bwd(const float* __restrict__ g_num, const float* __restrict__ env,

@@ -1,0 +1,59 @@
+// Deterministic folds of the env-reconstruction partial sums (shared by sgr_recon.hip and the fused
+// objective, sgr_fused_recon.hip): double accumulation in a fixed order, no atomics, no host sync.
+#pragma once
+#include "sgr_launch.h"
+
+namespace sgr {
+
+constexpr int kRThreads = 256;
+
+// deterministic block sum in double: thread t adds elements t, t+256, ...; fixed LDS tree afterwards
+template <int N>
+__device__ __forceinline__ void block_sum_double(double (&v)[N], double* lds /* [256*N] */) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) lds[threadIdx.x * N + i] = v[i];
+  __syncthreads();
+  for (int s = kRThreads / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) lds[threadIdx.x * N + i] += lds[(threadIdx.x + s) * N + i];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = lds[i];
+}
+
+// fold stage-0 partials: coef[b], den partial per image   (one block per image)
+static __global__ __launch_bounds__(kRThreads) void recon_fold0(const float* __restrict__ ws, float* __restrict__ coef,
+                                                          float* __restrict__ den_img, int nblk) {
+  __shared__ double lds[kRThreads * 3];
+  const int b = blockIdx.x;
+  double v[3] = {0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < nblk; i += kRThreads) {
+    v[0] += (double)ws[((size_t)b * nblk + i) * 3 + 0];
+    v[1] += (double)ws[((size_t)b * nblk + i) * 3 + 1];
+    v[2] += (double)ws[((size_t)b * nblk + i) * 3 + 2];
+  }
+  block_sum_double<3>(v, lds);
+  if (threadIdx.x == 0) {
+    coef[b] = fminf(fmaxf((float)v[0] / fmaxf((float)v[1], 1e-5f), 0.001f), 1000.0f);
+    den_img[b] = (float)v[2];
+  }
+}
+
+static __global__ __launch_bounds__(kRThreads) void recon_fold1(const float* __restrict__ ws, const float* __restrict__ den_img,
+                                                          float* __restrict__ parts, int bn, int nblk) {
+  __shared__ double lds[kRThreads * 2];
+  double v[2] = {0.0, 0.0};
+  for (int i = threadIdx.x; i < bn * nblk; i += kRThreads) v[0] += (double)ws[i];
+  for (int i = threadIdx.x; i < bn; i += kRThreads) v[1] += (double)den_img[i];
+  block_sum_double<2>(v, lds);
+  if (threadIdx.x == 0) {
+    parts[0] = (float)v[0];
+    parts[1] = (float)v[1];
+  }
+}
+
+
+}  // namespace sgr

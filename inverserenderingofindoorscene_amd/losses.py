@@ -22,9 +22,10 @@ import torch.distributed as dist
 import torch.nn.functional as F
 
 from . import _lib
-from .layers import _ptr, _require_hip, _stream
+from .layers import _check_brdf, _check_sg, _dirs, _prepool, _ptr, _require_hip, _stream, _view
 
-__all__ = ["LSregress", "LSregressDiffSpec", "render_loss", "recon_loss", "combine_loss_parts"]
+__all__ = ["LSregress", "LSregressDiffSpec", "render_loss", "recon_loss", "combine_loss_parts", "light_objective",
+           "light_objective_supported"]
 
 
 def _workspace(bn: int, dev) -> torch.Tensor:
@@ -201,3 +202,128 @@ def recon_loss(envmapsPredImage, envmapsBatch, segBRDFBatch, envmapsIndBatch, en
     if return_scaled:
         return err, envmapsPredImage * coef.reshape(-1, 1, 1, 1, 1, 1)
     return err
+
+
+# --------------------------------------------------------------------------- #
+# the whole trainLight objective, env image never materialised                 #
+# --------------------------------------------------------------------------- #
+def light_objective_supported(SGNum: int, envRow: int, envCol: int, envHeight: int = 8, envWidth: int = 16) -> bool:
+    """Whether :func:`light_objective` has a fused kernel for this configuration (envWidth 16, SGNum <= 12)."""
+    return bool(_lib.load().sgr_fused_recon_supported(int(SGNum), int(envRow), int(envCol), int(envHeight), int(envWidth)))
+
+
+def _global_pair(a: torch.Tensor, b: torch.Tensor, group):
+    """Sum a pair of device scalars over the ranks of ``group`` (one all-reduce of two floats)."""
+    if group is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        pair = torch.stack([a, b])
+        dist.all_reduce(pair, op=dist.ReduceOp.SUM, group=group)
+        return pair[0], pair[1], True
+    return a, b, False
+
+
+class _LightObjective(torch.autograd.Function):
+    """sgr_fused_fwd_recon -> sgr_render_loss_fwd/bwd -> sgr_fused_bwd_recon.
+
+    The loss value of the reconstruction term comes out of the same pass as the SG gradients, so the
+    gradients are produced here and handed out (times the incoming cotangent) in ``backward``."""
+
+    @staticmethod
+    def forward(ctx, albedo, normal, rough, axis, lamb, weight, im, seg, env_gt, env_ind, layer_cfg, ren_w, rec_w, offset, group):
+        dev = _require_hip(albedo, normal, rough, axis, lamb, weight, im, seg, env_gt, env_ind)
+        eh, ew, fov, F0, cam = layer_cfg
+        albedo_c, normal_c, rough_c = albedo.contiguous(), normal.contiguous(), rough.contiguous()
+        axis_c, lamb_c, weight_c = axis.contiguous(), lamb.contiguous(), weight.contiguous()
+        bn, K, R, C = _check_sg(axis_c, lamb_c, weight_c, None)
+        bn2, h, w = _check_brdf(albedo_c, normal_c, rough_c)
+        gt = env_gt.contiguous()
+        if bn2 != bn or tuple(gt.shape) != (bn, 3, R, C, eh, ew):
+            raise RuntimeError(f"sgrender: envmapsBatch must be [bn,3,{R},{C},{eh},{ew}] and the batch sizes must agree")
+        im_c, seg_c = im.contiguous(), seg.contiguous()
+        imH, imW = im_c.shape[2], im_c.shape[3]
+        if tuple(seg_c.shape) != (bn, 1, imH, imW) or im_c.shape[1] != 3:
+            raise RuntimeError("sgrender: im must be [bn,3,h,w] and seg [bn,1,h,w]")
+        ind = env_ind.contiguous().reshape(bn)
+        lib = _lib.load()
+        f32 = dict(device=dev, dtype=torch.float32)
+        diffuse, spec = torch.empty((bn, 3, R, C), **f32), torch.empty((bn, 3, R, C), **f32)
+        im_s, seg_s = torch.empty((bn, 3, R, C), **f32), torch.empty((bn, 1, R, C), **f32)
+        rendered = torch.empty_like(im_s)
+        mask, coef = torch.empty((bn, R * C), **f32), torch.empty(bn, **f32)
+        coef_ds = torch.empty((bn, 2), **f32)
+        parts_f, parts_r, parts_b = torch.empty(2, **f32), torch.empty(2, **f32), torch.empty(2, **f32)
+        ws = torch.empty(lib.sgr_fused_recon_workspace_floats(bn, R, C), **f32)
+        ws_r = _workspace(bn, dev)
+        g_axis, g_lamb, g_weight = torch.empty_like(axis_c), torch.empty_like(lamb_c), torch.empty_like(weight_c)
+        d, v = _dirs(dev, eh, ew), _view(dev, R, C, fov, cam)
+        st = _stream(dev)
+        sg_args = (_ptr(albedo_c), _ptr(normal_c), _ptr(rough_c), _ptr(axis_c), _ptr(lamb_c), _ptr(weight_c), _ptr(d), _ptr(v))
+        with torch.cuda.device(dev):
+            # the pooled object mask is an output of the render-loss pass; the env mask needs it first
+            if (imH, imW) == (R, C):
+                seg_small = seg_c
+            else:
+                seg_small = F.avg_pool2d(seg_c, 2)
+            _lib.call("sgr_fused_fwd_recon", *sg_args, _ptr(gt), _ptr(seg_small), _ptr(ind), _ptr(diffuse), _ptr(spec),
+                      _ptr(mask), _ptr(coef), _ptr(parts_f), _ptr(ws), bn, K, R, C, eh, ew, h, w, float(F0), 1, st)
+            _lib.call("sgr_render_loss_fwd", _ptr(diffuse), _ptr(spec), _ptr(im_c), _ptr(seg_c), _ptr(im_s), _ptr(seg_s),
+                      _ptr(rendered), _ptr(coef_ds), _ptr(parts_r), _ptr(ws_r), bn, R, C, imH, imW, st)
+            den_r, den_e, sharded = _global_pair(parts_r[1], parts_f[1], group)
+            g_num_r = (float(ren_w) / 3.0 / torch.clamp(den_r, min=1e-5)).reshape(1)
+            g_d, g_s = torch.empty_like(diffuse), torch.empty_like(spec)
+            _lib.call("sgr_render_loss_bwd", _ptr(g_num_r), _ptr(diffuse), _ptr(spec), _ptr(im_s), _ptr(seg_s), _ptr(coef_ds),
+                      _ptr(g_d), _ptr(g_s), bn, R, C, st)
+            den_e_c = den_e.reshape(1).contiguous() if sharded else None
+            _lib.call("sgr_fused_bwd_recon", *sg_args, _ptr(gt), _ptr(mask), _ptr(coef), _ptr(den_e_c), _ptr(g_d), _ptr(g_s),
+                      _ptr(g_axis), _ptr(g_lamb), _ptr(g_weight), _ptr(parts_b), _ptr(ws),
+                      bn, K, R, C, eh, ew, h, w, float(F0), 1, float(offset), float(rec_w), st)
+            num_r, num_e, _ = _global_pair(parts_r[0], parts_b[0], group)
+        render_err = num_r / torch.clamp(den_r, min=1e-5) / 3.0
+        recon_err = num_e / torch.clamp(den_e, min=1e-5) / (3.0 * eh * ew)
+        objective = float(ren_w) * render_err + float(rec_w) * recon_err
+        ctx.save_for_backward(g_axis, g_lamb, g_weight)
+        ctx.mark_non_differentiable(render_err, recon_err, rendered, coef)
+        return objective, render_err, recon_err, rendered, coef
+
+    @staticmethod
+    def backward(ctx, g_obj, *_unused):
+        g_axis, g_lamb, g_weight = ctx.saved_tensors
+        if any(ctx.needs_input_grad[:3]) or any(ctx.needs_input_grad[6:10]):
+            raise NotImplementedError("sgrender: light_objective differentiates w.r.t. the SG parameters only "
+                                      "(trainLight mode, wrapperBRDFLight.py:194 detaches the BRDF maps)")
+        outs = [None] * 15
+        for i, g in ((3, g_axis), (4, g_lamb), (5, g_weight)):
+            if ctx.needs_input_grad[i]:
+                outs[i] = g * g_obj
+        return tuple(outs)
+
+
+def light_objective(renderLayer, albedoPred, normalPred, roughPred, axisPred, lambPred, weightPred, imBatch, segBRDFBatch,
+                    envmapsBatch, envmapsIndBatch, renderWeight: float = 1.0, reconWeight: float = 10.0, offset: float = 1.0,
+                    group=None):
+    """The cascade-0 light objective ``renderWeight * renderErr + reconWeight * reconstErr`` of
+    wrapperBRDFLight.py:167-207 / trainLight.py:237 in two heavy kernel passes, without ever writing the
+    predicted env image or its gradient.
+
+    ``renderLayer`` is a :class:`renderingLayer` (its fov / F0 / camera / direction grid are used);
+    ``axisPred, lambPred, weightPred`` are the raw decoder outputs (pre-tan), exactly what
+    ``output2env.output2env`` takes.  Differentiable w.r.t. those three only.
+
+    Returns ``(objective, renderErr, reconstErr, renderedImPred, envScale)``; the two error terms are reported
+    values (no gradient), ``envScale [bn]`` is the LSregress coefficient (``envmapsPredScaledImage =
+    envScale * envmapsPredImage`` if the caller materialises the env for logging).  Under batch sharding the
+    mask sums are all-reduced before the backward pass and the numerators after it (two collectives of two
+    floats each)."""
+    impl = getattr(renderLayer, "impl", renderLayer)
+    bn, K, R, C = _check_sg(axisPred, lambPred, weightPred, None)
+    impl._check_grid(R, C)
+    if not light_objective_supported(K, R, C, impl.envHeight, impl.envWidth):
+        raise NotImplementedError("sgrender: light_objective needs envWidth 16 and SGNum <= 12; use forwardSG + render_loss + recon_loss")
+    a, n, r = _prepool(albedoPred, normalPred, roughPred, R, C)
+    im, seg = imBatch, segBRDFBatch
+    h, w = im.shape[2], im.shape[3]
+    if (h, w) != (R, C) and (h, w) != (2 * R, 2 * C):
+        im = F.adaptive_avg_pool2d(im, (R, C))
+        seg = F.adaptive_avg_pool2d(seg, (R, C))
+    cfg = (impl.envHeight, impl.envWidth, impl.fov_deg, impl.F0, impl._cam)
+    return _LightObjective.apply(a, n, r, axisPred, lambPred, weightPred, im, seg, envmapsBatch, envmapsIndBatch, cfg,
+                                 float(renderWeight), float(reconWeight), float(offset), group)

@@ -1,0 +1,150 @@
+"""GPU: the fused trainLight objective (sgr_fused_fwd_recon / sgr_fused_bwd_recon, env image never written)
+against the golden fixtures (reference values and gradients), the fp64 oracle and the unfused HIP path."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ("albedo", "normal", "rough", "axis", "lamb", "weight")
+
+
+@pytest.fixture(scope="module")
+def sgr():
+    import inverserenderingofindoorscene_amd as pkg
+    from inverserenderingofindoorscene_amd import _lib
+    _lib.load()
+    return pkg
+
+
+def _t(z, k):
+    return torch.from_numpy(np.ascontiguousarray(z[k])).cuda()
+
+
+def _oracle_objective(inp, ind, R, C, eh, ew, fov, F0, ren_w, rec_w, offset=1.0):
+    """fp64 restatement of wrapperBRDFLight.py:167-207 from the oracle's pieces; returns values and SG gradients."""
+    from oracle import sg_oracle as O
+    x = {k: v.double() for k, v in inp.items()}
+    for k in ("axis", "lamb", "weight"):
+        x[k] = x[k].clone().requires_grad_(True)
+    env, d, s = O.render_from_sg(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], eh, ew, fov, F0)
+    rerr, _, _, _ = O.render_loss(d, s, x["im"], x["seg"], R, C)
+    cerr, _, _, _ = O.recon_loss(env, x["env_gt"], x["seg"], ind.double(), R, C, offset)
+    tot = ren_w * rerr + rec_w * cerr
+    grads = torch.autograd.grad(tot, [x["axis"], x["lamb"], x["weight"]])
+    return tot.item(), rerr.item(), cerr.item(), grads
+
+
+def test_light_objective_vs_golden(sgr, golden):
+    """renderErr + 10 reconstErr (trainLight.py:47-48,237) and its SG gradients against the reference's."""
+    name, z, cfg = golden
+    R, C = cfg["R"], cfg["C"]
+    x = {k: _t(z, "in_" + k) for k in NAMES}
+    for k in ("axis", "lamb", "weight"):
+        x[k].requires_grad_(True)
+    layer = sgr.renderingLayer(imWidth=C, imHeight=R, fov=cfg["fov"], F0=cfg["F0"], envWidth=cfg["ew"], envHeight=cfg["eh"])
+    ind = torch.ones(cfg["bn"], 1, 1, 1, device="cuda")
+    args = (layer, x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], _t(z, "in_im"), _t(z, "in_seg"),
+            _t(z, "in_env_gt"), ind)
+    if not sgr.light_objective_supported(cfg["K"], R, C, cfg["eh"], cfg["ew"]):
+        with pytest.raises(NotImplementedError):
+            sgr.light_objective(*args, 1.0, 10.0)
+        return
+    obj, rerr, cerr, ren, coef = sgr.light_objective(*args, 1.0, 10.0)
+    r_ref, c_ref = float(z["ref32_render_err"][0]), float(z["ref32_recon_err"][0])
+    assert abs(rerr.item() - r_ref) < 1e-4 * max(1.0, r_ref), (name, rerr.item(), r_ref)
+    assert abs(cerr.item() - c_ref) < 1e-4 * max(1.0, c_ref), (name, cerr.item(), c_ref)
+    assert abs(obj.item() - (r_ref + 10.0 * c_ref)) < 1e-4 * max(1.0, r_ref + 10.0 * c_ref)
+    assert rel_l2(ren.cpu(), z["ref32_rendered"]) < 1e-4, name
+    grads = torch.autograd.grad(obj, [x["axis"], x["lamb"], x["weight"]])
+    for k, g in zip(("axis", "lamb", "weight"), grads):
+        ref32, ref64 = z["ref32_gtot_" + k], z["ref64_gtot_" + k]
+        e_ref = rel_l2(ref32, ref64)
+        assert rel_l2(g.cpu(), ref64) < max(3 * e_ref, 1e-4), (name, k, rel_l2(g.cpu(), ref64), e_ref)
+
+
+@pytest.mark.parametrize("bn,imH,imW,R,C,K,benign", [
+    (2, 12, 20, 12, 20, 12, True),      # q = 1, one partial 64-pixel tile per image
+    (3, 18, 26, 9, 13, 12, False),      # q = 4, odd grid, decoder-range (stress) lobes
+    (2, 10, 14, 10, 14, 5, True),       # SGNum <= 6: the second wave of a workgroup owns no lobes
+    (1, 16, 40, 8, 20, 9, True),        # SGNum between 6 and 12
+])
+def test_light_objective_vs_oracle(sgr, bn, imH, imW, R, C, K, benign):
+    """Values and gradients against the fp64 oracle, with env_ind == 0 images, dark ground-truth cells and
+    unequal loss weights; the unfused HIP path (forwardSG + render_loss + recon_loss) must agree too."""
+    from oracle import sg_oracle as O
+    eh, ew, fov, F0 = 8, 16, 57.0, 0.05
+    inp = O.synthetic_inputs(bn, imH, imW, R, C, K, eh, ew, seed=77 + K, benign=benign)
+    inp["env_gt"][0, :, 1:3, 2:6] = 0.0                      # dark cells drop out of the env mask
+    ind = torch.ones(bn, 1, 1, 1)
+    if bn > 1:
+        ind[1] = 0.0
+    ren_w, rec_w, offset = 0.7, 3.0, 1.0
+    tot_o, rerr_o, cerr_o, g_o = _oracle_objective(inp, ind, R, C, eh, ew, fov, F0, ren_w, rec_w, offset)
+
+    dev = {k: v.cuda() for k, v in inp.items()}
+    for k in ("axis", "lamb", "weight"):
+        dev[k].requires_grad_(True)
+    layer = sgr.renderingLayer(imWidth=C, imHeight=R, fov=fov, F0=F0, envWidth=ew, envHeight=eh)
+    obj, rerr, cerr, ren, coef = sgr.light_objective(layer, dev["albedo"], dev["normal"], dev["rough"], dev["axis"], dev["lamb"],
+                                                      dev["weight"], dev["im"], dev["seg"], dev["env_gt"], ind.cuda(), ren_w, rec_w,
+                                                      offset)
+    assert abs(rerr.item() - rerr_o) < 1e-4 * max(1.0, rerr_o), (rerr.item(), rerr_o)
+    assert abs(cerr.item() - cerr_o) < 1e-4 * max(1.0, cerr_o), (cerr.item(), cerr_o)
+    assert abs(obj.item() - tot_o) < 1e-4 * max(1.0, tot_o)
+    grads = torch.autograd.grad(2.0 * obj, [dev["axis"], dev["lamb"], dev["weight"]])     # cotangent != 1
+    for k, g, go in zip(("axis", "lamb", "weight"), grads, g_o):
+        assert rel_l2(g.cpu(), 2.0 * go) < 2e-4, (k, rel_l2(g.cpu(), 2.0 * go))
+
+    # unfused HIP path on the same inputs
+    env, d, s = layer.forwardSG(dev["albedo"], dev["normal"], dev["rough"], dev["axis"], dev["lamb"], dev["weight"], need_env=True)
+    r2, _ = sgr.render_loss(d, s, dev["im"], dev["seg"], R, C)
+    c2 = sgr.recon_loss(env, dev["env_gt"], dev["seg"], ind.cuda(), R, C, offset)
+    g2 = torch.autograd.grad(2.0 * (ren_w * r2 + rec_w * c2), [dev["axis"], dev["lamb"], dev["weight"]])
+    assert abs(r2.item() - rerr.item()) < 2e-5 * max(1.0, rerr_o) and abs(c2.item() - cerr.item()) < 2e-5 * max(1.0, cerr_o)
+    for k, ga, gb in zip(("axis", "lamb", "weight"), grads, g2):
+        assert rel_l2(ga, gb) < 1e-4, (k, rel_l2(ga, gb))
+
+
+def test_light_objective_full_size_matches_unfused(sgr):
+    """BASELINE config 2 shapes: the fused objective equals the unfused HIP pipeline (value and gradients) and is
+    bit-reproducible (no atomics)."""
+    from oracle import sg_oracle as O
+    bn, imH, imW, R, C, K, eh, ew = 16, 240, 320, 120, 160, 12, 8, 16
+    inp = O.synthetic_inputs(bn, imH, imW, R, C, K, eh, ew, seed=20202)
+    dev = {k: v.cuda() for k, v in inp.items()}
+    for k in ("axis", "lamb", "weight"):
+        dev[k].requires_grad_(True)
+    ind = torch.ones(bn, 1, 1, 1, device="cuda")
+    layer = sgr.renderingLayer(imWidth=C, imHeight=R, fov=57, F0=0.05, envWidth=ew, envHeight=eh)
+
+    def fused():
+        out = sgr.light_objective(layer, dev["albedo"], dev["normal"], dev["rough"], dev["axis"], dev["lamb"], dev["weight"],
+                                  dev["im"], dev["seg"], dev["env_gt"], ind, 1.0, 10.0)
+        return out, torch.autograd.grad(out[0], [dev["axis"], dev["lamb"], dev["weight"]])
+    (o1, g1), (o2, g2) = fused(), fused()
+    assert torch.equal(o1[0], o2[0]) and all(torch.equal(a, b) for a, b in zip(g1, g2))
+    env, d, s = layer.forwardSG(dev["albedo"], dev["normal"], dev["rough"], dev["axis"], dev["lamb"], dev["weight"], need_env=True)
+    r2, _ = sgr.render_loss(d, s, dev["im"], dev["seg"], R, C)
+    c2 = sgr.recon_loss(env, dev["env_gt"], dev["seg"], ind, R, C)
+    g3 = torch.autograd.grad(r2 + 10.0 * c2, [dev["axis"], dev["lamb"], dev["weight"]])
+    assert abs(o1[1].item() - r2.item()) < 2e-5 * max(1.0, r2.item())
+    assert abs(o1[2].item() - c2.item()) < 2e-5 * max(1.0, c2.item())
+    for k, ga, gb in zip(("axis", "lamb", "weight"), g1, g3):
+        assert rel_l2(ga, gb) < 1e-4, (k, rel_l2(ga, gb))
+    for g in g1:
+        assert torch.isfinite(g).all()
+
+
+def test_light_objective_rejects_brdf_gradients(sgr):
+    from oracle import sg_oracle as O
+    inp = {k: v.cuda() for k, v in O.synthetic_inputs(1, 8, 16, 8, 16, 12, 8, 16, seed=3, benign=True).items()}
+    inp["rough"].requires_grad_(True)
+    inp["axis"].requires_grad_(True)
+    layer = sgr.renderingLayer(imWidth=16, imHeight=8, envWidth=16, envHeight=8)
+    obj = sgr.light_objective(layer, inp["albedo"], inp["normal"], inp["rough"], inp["axis"], inp["lamb"], inp["weight"],
+                              inp["im"], inp["seg"], inp["env_gt"], torch.ones(1, 1, 1, 1, device="cuda"))[0]
+    with pytest.raises(NotImplementedError):
+        obj.backward()

@@ -45,6 +45,7 @@ int main(int argc, char** argv) {
   SYM(sgr_fill_direction_table) SYM(sgr_fill_view_vectors) SYM(sgr_dirs_floats)
   SYM(sgr_sg_to_env_fwd) SYM(sgr_render_env_fwd) SYM(sgr_fused_fwd) SYM(sgr_sg_to_env_bwd) SYM(sgr_fused_bwd_sg)
   SYM(sgr_render_env_bwd_env) SYM(sgr_render_bwd_brdf) SYM(sgr_render_loss_fwd) SYM(sgr_render_loss_bwd) SYM(sgr_loss_workspace_floats)
+  SYM(sgr_fused_fwd_recon) SYM(sgr_fused_bwd_recon) SYM(sgr_fused_recon_workspace_floats) SYM(sgr_recon_loss_fwd) SYM(sgr_recon_loss_bwd) SYM(sgr_recon_workspace_floats)
   const int K = argc > 4 ? atoi(argv[4]) : 12;
   const int imH = 240, imW = 320, R = 120, C = 160, eh = 8, ew = 16, J = eh * ew, q = 4;
   const size_t RC = (size_t)R * C, P = (size_t)bn * RC;
@@ -102,5 +103,13 @@ int main(int argc, char** argv) {
   bench("sgr_render_bwd_brdf (from SG)", 2 * Bbrdf + Bout + Bsg, [&] { return sgr_render_bwd_brdf_p(g_d, g_s, albedo, normal, rough, (float*)nullptr, axis, lamb, weight, dirs, view, g_alb, g_nrm, g_rgh, bn, K, R, C, eh, ew, imH, imW, F0d, 1, st); });
   bench("sgr_render_loss_fwd (4 kernels)", 3 * 4 * q + 4 * q + 24 + 12 + 4 + 12 + 36, [&] { return sgr_render_loss_fwd_p(diffuse, spec, im, seg, im_s, seg_s, rendered, coef, parts, ws, bn, R, C, imH, imW, st); });
   bench("sgr_render_loss_bwd", 24 + 12 + 4 + 24, [&] { return sgr_render_loss_bwd_p(g_num, diffuse, spec, im_s, seg_s, coef, g_d, g_s, bn, R, C, st); });
+  // env reconstruction: unfused passes over the materialised env image vs the fused objective
+  float* env_gt = dev_rand(P * 3 * J, 0, 2, 13); float* ind = dev_rand(bn, 1, 1, 14);
+  float* mask = dev_empty(P); float* rcoef = dev_empty(bn); float* rparts = dev_empty(2);
+  float* rws = dev_empty(sgr_recon_workspace_floats_p(bn, R, C)); float* fws = dev_empty(sgr_fused_recon_workspace_floats_p(bn, R, C));
+  bench("sgr_recon_loss_fwd (2 passes)", 4 * Benv, [&] { return sgr_recon_loss_fwd_p(env, env_gt, seg_s, ind, mask, rcoef, rparts, rws, bn, R, C, eh, ew, 1.0f, st); });
+  bench("sgr_recon_loss_bwd", 3 * Benv, [&] { return sgr_recon_loss_bwd_p(g_num, env, env_gt, mask, rcoef, g_env, bn, R, C, eh, ew, 1.0f, st); });
+  bench("sgr_fused_fwd_recon", Bbrdf + Bsg + Benv + Bout, [&] { return sgr_fused_fwd_recon_p(albedo, normal, rough, axis, lamb, weight, dirs, view, env_gt, seg_s, ind, diffuse, spec, mask, rcoef, rparts, fws, bn, K, R, C, eh, ew, imH, imW, F0d, 1, st); });
+  bench("sgr_fused_bwd_recon", Bbrdf + Bsg + Bout + Benv + Bsg, [&] { return sgr_fused_bwd_recon_p(albedo, normal, rough, axis, lamb, weight, dirs, view, env_gt, mask, rcoef, (float*)nullptr, g_d, g_s, g_axis, g_lamb, g_weight, rparts, fws, bn, K, R, C, eh, ew, imH, imW, F0d, 1, 1.0f, 10.0f, st); });
   return 0;
 }
