@@ -149,6 +149,40 @@ def main() -> None:
     barrier()
     loss_step_ms = (time.perf_counter() - t1) / args.steps * 1e3
 
+    # informational: the whole cascade-0 light objective (render loss + 10 x env reconstruction loss,
+    # wrapperBRDFLight.py:167-207) -- fused (env image never written, sgr.light_objective) and unfused
+    obj_ms = obj_unfused_ms = None
+    if args.config == 2 and need_env and pkg.light_objective_supported(K, R, C, eh, ew):
+        ind = torch.ones(bn, 1, 1, 1, device=dev)
+
+        def clear():
+            for k in ("axis", "lamb", "weight"):
+                x[k].grad = None
+
+        def step_obj_fused():
+            obj = pkg.light_objective(layer, x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"],
+                                      x["im"], x["seg"], x["env_gt"], ind, 1.0, 10.0)[0]
+            obj.backward()
+            clear()
+
+        def step_obj_unfused():
+            env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=True)
+            err, _ = pkg.render_loss(d, s, x["im"], x["seg"], R, C)
+            rec = pkg.recon_loss(env, x["env_gt"], x["seg"], ind, R, C)
+            (err + 10.0 * rec).backward()
+            clear()
+
+        res = []
+        for fn in (step_obj_fused, step_obj_unfused):
+            fn()
+            barrier()
+            t2 = time.perf_counter()
+            for _ in range(args.steps):
+                fn()
+            barrier()
+            res.append((time.perf_counter() - t2) / args.steps * 1e3)
+        obj_ms, obj_unfused_ms = res
+
     if rank == 0:
         P = bn * R * C                      # shaded (env-grid) pixels per GPU per step
         img_px = bn * imH * imW
@@ -161,7 +195,7 @@ def main() -> None:
         bwd_gbps = bwd_bytes / (bwd_ms * 1e-3) / 1e9
         dom = ("sg_bwd", bwd_ms, bwd_bytes, bwd_gbps) if bwd_ms >= fwd_ms else ("fwd_fast", fwd_ms, fwd_bytes, fwd_gbps)
         # HBM bytes per launch from the PMC passes (tools/pmc_traffic.sh -> profiles/traffic.json), if recorded;
-        # the entry is matched by kernel family (the backward is sg_bwd_split_kernel / sg_bwd_fast_kernel)
+        # the entry is matched by kernel family (the backward is sg_bwd_half_kernel / sg_bwd_split_kernel / sg_bwd_fast_kernel)
         traffic, dom_name = None, dom[0] + "_kernel"
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.isfile(tpath):
@@ -190,13 +224,15 @@ def main() -> None:
                        "shaded_px_per_step_per_gpu": P, "image_px_per_step_per_gpu": img_px, "q": q,
                        "Mshade_per_s": round(world * P / (dt / args.steps) / 1e6, 1),
                        "ms_per_step_with_render_loss": round(loss_step_ms, 4),
+                       "ms_per_step_light_objective_fused": None if obj_ms is None else round(obj_ms, 4),
+                       "ms_per_step_light_objective_unfused": None if obj_unfused_ms is None else round(obj_unfused_ms, 4),
                        "parallelism": f"batch-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(dom[3], 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(dom[3] / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": dom[2], "avg_launch_ms": round(dom[1], 4)},
             "kernels": {"forward (fwd_fast_kernel)": {"ms": round(fwd_ms, 4), "GBps": round(fwd_gbps, 1), "frac": round(fwd_gbps / HBM_PEAK_GBPS, 4),
                                        "bytes": fwd_bytes},
-                        "backward (sg_bwd_split_kernel)": {"ms": round(bwd_ms, 4), "GBps": round(bwd_gbps, 1), "frac": round(bwd_gbps / HBM_PEAK_GBPS, 4),
+                        "backward (sg_bwd_half_kernel)": {"ms": round(bwd_ms, 4), "GBps": round(bwd_gbps, 1), "frac": round(bwd_gbps / HBM_PEAK_GBPS, 4),
                                           "bytes": bwd_bytes}},
         }
         if world == 1 and not args.no_cpu_baseline and args.config == 2:

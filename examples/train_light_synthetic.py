@@ -7,10 +7,12 @@ its step (trainLight.py:203-244 -> wrapperBRDFLight.py:158-207) around synthetic
   * "frozen BRDF net outputs": albedo / normal / rough maps (no grad, like trainLight.py:121-144);
   * the light network is replaced by three learnable tensors pushed through decoderLight's output
     activations (models.py:336-346): 1.01*tanh -> unit axes, 0.5*(x+1) clamped to [0,1] for lamb/weight;
-  * step = zero_grad -> fused render layer (env image + diffuse + specular) -> render loss (HIP) +
-    log-L2 reconstruction loss (HIP streaming kernels) -> backward -> Adam.
+  * step = zero_grad -> objective -> backward -> Adam, the objective being either
+      fused (default): sgr.light_objective -- render loss + 10 x log-L2 env reconstruction loss in two heavy
+                       kernel passes, the predicted env image never written, or
+      --unfused:       forwardSG (env image + diffuse + specular) -> sgr.render_loss + sgr.recon_loss.
 
-    python examples/train_light_synthetic.py --batch 16 --steps 20
+    python examples/train_light_synthetic.py --batch 16 --steps 20 [--unfused]
 """
 import argparse
 import os
@@ -59,7 +61,7 @@ def make_batch(bn, imH, imW, R, C, eh, ew, dev, seed=0):
 
 
 def train(bn=16, steps=10, imH=240, imW=320, R=120, C=160, K=12, eh=8, ew=16, renW=1.0, recW=10.0, lr=1e-2,
-          seed=0, verbose=True):
+          seed=0, verbose=True, fused=True):
     dev = torch.device("cuda")
     batch = make_batch(bn, imH, imW, R, C, eh, ew, dev, seed)
     g = torch.Generator().manual_seed(seed + 1)
@@ -76,10 +78,15 @@ def train(bn=16, steps=10, imH=240, imW=320, R=120, C=160, K=12, eh=8, ew=16, re
             t0 = time.perf_counter()
         opt.zero_grad()
         axis, lam, w = decoder_heads(*params)
-        env, diffuse, spec = layer.forwardSG(batch["albedo"], batch["normal"], batch["rough"], axis, lam, w, need_env=True)
-        render_err, _ = sgr.render_loss(diffuse, spec, batch["im"], batch["seg"], R, C)
-        recon_err = sgr.recon_loss(env, batch["env_gt"], batch["seg"], batch["env_ind"], R, C)
-        total = renW * render_err + recW * recon_err                   # trainLight.py:237
+        if fused and sgr.light_objective_supported(K, R, C, eh, ew):
+            total, render_err, recon_err, _, _ = sgr.light_objective(layer, batch["albedo"], batch["normal"], batch["rough"], axis, lam, w,
+                                                                     batch["im"], batch["seg"], batch["env_gt"], batch["env_ind"],
+                                                                     renW, recW)
+        else:
+            env, diffuse, spec = layer.forwardSG(batch["albedo"], batch["normal"], batch["rough"], axis, lam, w, need_env=True)
+            render_err, _ = sgr.render_loss(diffuse, spec, batch["im"], batch["seg"], R, C)
+            recon_err = sgr.recon_loss(env, batch["env_gt"], batch["seg"], batch["env_ind"], R, C)
+            total = renW * render_err + recW * recon_err               # trainLight.py:237
         total.backward()
         opt.step()
         hist.append((total.detach(), render_err.detach(), recon_err.detach()))
@@ -97,5 +104,6 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--unfused", action="store_true", help="materialise the env image and use the separate loss kernels")
     args = ap.parse_args()
-    train(bn=args.batch, steps=args.steps)
+    train(bn=args.batch, steps=args.steps, fused=not args.unfused)

@@ -13,12 +13,6 @@
 #include <type_traits>
 #include "sgr_launch.h"
 
-#ifndef SGR_F1_NOSTATS
-#define SGR_F1_NOSTATS 0
-#endif
-#ifndef SGR_F1_NODMA
-#define SGR_F1_NODMA 0
-#endif
 #ifndef SGR_FWD_DIRECT
 #define SGR_FWD_DIRECT 0
 #endif
@@ -128,8 +122,8 @@ __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
   constexpr int HALF = EW / 2;
   constexpr int NQ = HALF / 4;      // azimuth quads per half row
   __shared__ __attribute__((aligned(16))) float tile[WRITE_ENV ? Tile<TJ>::kFloats : 4];
-  using GD = DmaTile<16>;
-  __shared__ __attribute__((aligned(16))) float gtile[HAS_GT ? 2 * GD::kFloats : 4];
+  using GD = DmaTile<8>;           // ground-truth env, one azimuth quad of both half rows at a time
+  __shared__ __attribute__((aligned(16))) float gtile[HAS_GT ? 3 * GD::kFloats : 4];
 
   const Pix x = locate(a);
   const int lane = x.lane, b = x.b, p = x.p;
@@ -154,22 +148,15 @@ __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
   const int ehp = RPC == 2 ? ((a.eh + 1) & ~1) : a.eh;
   float s_pg = 0.f, s_pp = 0.f, s_g = 0.f;
   __amdgpu_buffer_rsrc_t gimg = env_rsrc(HAS_GT ? a.env_gt + img : a.view, RC, a.J);
-  if (HAS_GT && !SGR_F1_NODMA) tile_dma_issue<16>(gtile, gimg, x.p0, RC, a.J, 0, lane);
+  if (HAS_GT) {      // two quads ahead (three buffers)
+    tile_dma_issue_quad(gtile, gimg, x.p0, RC, a.J, 0, lane);
+    tile_dma_issue_quad(gtile + GD::kFloats, gimg, x.p0, RC, a.J, 4, lane);
+  }
+  unsigned gpar = 0;
 
   // the wave-uniform frame test is hoisted out of the direction loops: two copies of the row loop
   auto row_loop = [&](auto ortho_c) {
   for (int e0 = 0; e0 < ehp; e0 += RPC) {
-      const float* gcur = gtile + (e0 & 1) * GD::kFloats;
-      if (HAS_GT && !SGR_F1_NODMA) {
-        if (e0 + 1 < ehp) {
-          tile_dma_issue<16>(gtile + ((e0 + 1) & 1) * GD::kFloats, gimg, x.p0, RC, a.J, (e0 + 1) * EW, lane);
-          wait_vmcnt<GD::kInstr>();      // row e0 has landed; row e0+1 stays in flight
-        } else {
-          wait_vmcnt<0>();
-        }
-      }
-      // U_ka = ax ca_a + ay sa_a does not depend on the row: keep LICM from hoisting all KP*EW/2 of them out
-      // of the row loop (they would not fit in registers) by making the axes opaque once per row.
   #pragma unroll
       for (int k = 0; k < KP; ++k) { asm volatile("" : "+v"(L.ax[k])); asm volatile("" : "+v"(L.ay[k])); }
       if (DO_RENDER) fence_row_invariants(q);
@@ -235,23 +222,33 @@ __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
           __builtin_amdgcn_sched_barrier(0);
   #endif
         }
-        if (HAS_GT && !SGR_F1_NOSTATS) {
-  #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            float g[2][3][2];
-            tile_dma_read_pairs<16>(gcur, lane, aq * 4 + 2 * h, HALF + aq * 4 + 2 * h, g);
-  #pragma unroll
-            for (int sg = 0; sg < 2; ++sg)
-  #pragma unroll
-              for (int c = 0; c < 3; ++c)
-  #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                  const float pv = acc[0][sg][c][2 * h + i], gv = g[sg][c][i];
-                  s_pg = fmaf(pv, gv, s_pg);
-                  s_pp = fmaf(pv, pv, s_pp);
-                  s_g += gv;
-                }
+        if (HAS_GT) {
+          // the ground truth of the quad after next goes in flight (third buffer) while this one is consumed
+          const float* gcur = gtile + gpar * GD::kFloats;
+          const int lin = (e0 * NQ + aq) + 2, ne = lin / NQ, nq = lin - ne * NQ;
+          const unsigned nbuf = gpar >= 1u ? gpar - 1u : 2u;       // (gpar + 2) % 3
+          if (ne < ehp) {
+            tile_dma_issue_quad(gtile + nbuf * GD::kFloats, gimg, x.p0, RC, a.J, ne * EW + nq * 4, lane);
+            wait_vmcnt<2 * GD::kInstr>();
+          } else if (lin - 1 < ehp * NQ) {
+            wait_vmcnt<GD::kInstr>();
+          } else {
+            wait_vmcnt<0>();
           }
+          gpar = gpar == 2u ? 0u : gpar + 1u;
+          float g[2][3][4];
+          tile_quad_read(gcur, lane, g);
+  #pragma unroll
+          for (int sg = 0; sg < 2; ++sg)
+  #pragma unroll
+            for (int c = 0; c < 3; ++c)
+  #pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const float pv = acc[0][sg][c][i], gv = g[sg][c][i];
+                s_pg = fmaf(pv, gv, s_pg);
+                s_pp = fmaf(pv, pv, s_pp);
+                s_g += gv;
+              }
         }
         if (WRITE_ENV) {
   #if SGR_FWD_DIRECT
@@ -639,6 +636,196 @@ __global__ __launch_bounds__(2 * kWave, 3) void sg_bwd_split_kernel(const Args a
           (a.g_weight + ab + RC)[up] = q1;
           (a.g_weight + ab + 2 * (size_t)RC)[up] = q2;
         }
+      }
+    }
+  }
+}
+
+// ============================== backward, half-wave lobe split ====================================
+// One wave = 32 pixels x 2 lobe groups: lanes l and l+32 own the same pixel, lanes 0..31 hold lobes 0..5 and
+// lanes 32..63 lobes 6..11 (12 lobes + 12 gradient sets per lane do not fit the register file).  What the two
+// halves have to share -- the render term of the cotangent, of which each half evaluates the BRDF for one
+// half row -- is traded with v_permlane32_swap_b32 (gfx950: upper 32 lanes of one VGPR <-> lower 32 of
+// another): swap(D = r, S = r) leaves lanes 0..31's value in D and lanes 32..63's in S, in all lanes.
+// No LDS exchange, no barrier; the env cotangent rows arrive by LDS-DMA, 32 pixels x 16 directions at a time.
+template <int POOL, bool HAS_GENV, bool HAS_RENDER, int OCC>
+__global__ __launch_bounds__(kWave, OCC) void sg_bwd_half_kernel(const Args a) {
+  constexpr int EW = 16, HALF = 8, NP = 4, KPW = 6;
+  __shared__ __attribute__((aligned(16))) float tile[HAS_GENV ? 2 * kT32Floats : 4];
+
+  const int lane = threadIdx.x, half = lane >> 5, pl = lane & 31;
+  const int own = 1 - half;                         // the half row (sign) whose BRDF terms this half-wave evaluates
+  const int RC = a.R * a.C, K = a.K;
+  Pix x;
+  x.lane = lane;
+  {
+    const int tiles = (RC + kPx - 1) / kPx;
+    x.b = blockIdx.x / tiles;
+    x.p0 = (blockIdx.x - x.b * tiles) * kPx;
+    x.active = (x.p0 + pl) < RC;
+    x.p = x.active ? (x.p0 + pl) : (RC - 1);
+  }
+  const int b = x.b, p = x.p;
+
+  __amdgpu_buffer_rsrc_t gimg = env_rsrc(HAS_GENV ? a.g_env + (size_t)b * 3 * RC * a.J : a.view, RC, a.J);
+  if (HAS_GENV) tile32_dma_issue(tile, gimg, x.p0, RC, a.J, 0, lane);
+
+  PixLocal q;
+  bool ortho = true;
+  float gd0 = 0.f, gd1 = 0.f, gd2 = 0.f, gs0 = 0.f, gs1 = 0.f, gs2 = 0.f;
+  if (HAS_RENDER) {
+    float alb[3];
+    const Frame f = load_frame<POOL>(a, x, alb);
+    q = make_local(f, a.F0);
+    ortho = __all(frame_is_orthonormal(q));
+    const size_t o = (size_t)b * 3 * RC;
+    const unsigned up = (unsigned)p;
+    gd0 = (a.g_diffuse + o)[up] * (alb[0] * kInvPi);
+    gd1 = (a.g_diffuse + o + RC)[up] * (alb[1] * kInvPi);
+    gd2 = (a.g_diffuse + o + 2 * (size_t)RC)[up] * (alb[2] * kInvPi);
+    gs0 = (a.g_spec + o)[up];
+    gs1 = (a.g_spec + o + RC)[up];
+    gs2 = (a.g_spec + o + 2 * (size_t)RC)[up];
+  }
+
+  // this half's lobes: per-lane offsets into the image's SG block (the lobe index differs between the halves)
+  Lobes<KPW> L;
+  {
+    const float* axis_b = a.axis + (size_t)b * K * 3 * RC;
+    const float* lamb_b = a.lamb + (size_t)b * K * RC;
+    const float* weight_b = a.weight + (size_t)b * K * 3 * RC;
+#pragma unroll
+    for (int k = 0; k < KPW; ++k) {
+      const int kc = min(half * KPW + k, K - 1);
+      const unsigned o3 = (unsigned)(kc * 3 * RC + p), o1 = (unsigned)(kc * RC + p);
+      L.ax[k] = axis_b[o3]; L.ay[k] = axis_b[o3 + RC]; L.az[k] = axis_b[o3 + 2 * RC];
+      L.lp[k] = lamb_b[o1];
+      L.w0[k] = weight_b[o3]; L.w1[k] = weight_b[o3 + RC]; L.w2[k] = weight_b[o3 + 2 * RC];
+    }
+#pragma unroll
+    for (int k = 0; k < KPW; ++k) {
+      const bool live = half * KPW + k < K;
+      float l = L.lp[k], t0 = L.w0[k], t1 = L.w1[k], t2 = L.w2[k];
+      if (a.premap) { l = premap(l); t0 = premap(t0); t1 = premap(t1); t2 = premap(t2); }
+      L.lp[k] = l * kLog2e;
+      L.w0[k] = live ? t0 : 0.0f; L.w1[k] = live ? t1 : 0.0f; L.w2[k] = live ? t2 : 0.0f;
+    }
+  }
+  float gax[KPW], gay[KPW], gaz[KPW], glam[KPW], gw0[KPW], gw1[KPW], gw2[KPW];
+#pragma unroll
+  for (int k = 0; k < KPW; ++k) gax[k] = gay[k] = gaz[k] = glam[k] = gw0[k] = gw1[k] = gw2[k] = 0.0f;
+
+  const SepTable rows = as_sep_table(a.rows);
+  const XTable cst = (XTable)(a.cols);
+  const XTable xt = (XTable)(a.cols + EW);
+  const int eh = a.eh;
+
+  auto row_loop = [&](auto ortho_c) {
+    for (int e = 0; e < eh; ++e) {
+      const float* cur = tile + (HAS_GENV ? (e & 1) * kT32Floats : 0);
+      if (HAS_GENV) {
+        if (e + 1 < eh) {
+          tile32_dma_issue(tile + ((e + 1) & 1) * kT32Floats, gimg, x.p0, RC, a.J, (e + 1) * EW, lane);
+          wait_vmcnt<6>();        // row e has landed; row e+1 stays in flight
+        } else {
+          wait_vmcnt<0>();
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < KPW; ++k) { asm volatile("" : "+v"(L.ax[k])); asm volatile("" : "+v"(L.ay[k])); }   // no LICM of u_ka
+      if (HAS_RENDER) fence_row_invariants(q);
+      const f32x8 row = rows[e];
+      const float sr = row[0], cr = row[1];
+      const RowCtx rc = make_row_ctx(q, row, HAS_RENDER);
+
+#pragma unroll 1
+      for (int ap = 0; ap < NP; ++ap) {
+        const f32x4 cs = cst[ap];
+        const float ca[2] = {cs[0], cs[2]}, sa[2] = {cs[1], cs[3]};
+        float g[2][3][2];
+        if (HAS_GENV) {
+          float t0[3][2], t1[3][2];
+          tile32_read_pair(cur, pl, ap * 2, t0);
+          tile32_read_pair(cur, pl, HALF + ap * 2, t1);
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { g[0][c][i] = t0[c][i]; g[1][c][i] = t1[c][i]; }
+        } else {
+#pragma unroll
+          for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g[sg][c][0] = g[sg][c][1] = 0.0f;
+        }
+        if (HAS_RENDER) {
+          // the render term of the half row this half-wave owns, then both halves' terms to all lanes
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            float wt, sp;
+            shade_dir<decltype(ortho_c)::value>(q, rc, own, ca[i], sa[i], xt, ap * 2 + i, wt, sp);
+            float r_[3] = {wt * fmaf(gs0, sp, gd0), wt * fmaf(gs1, sp, gd1), wt * fmaf(gs2, sp, gd2)};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              float d_ = r_[c], s_ = r_[c];
+              swap32(d_, s_);
+              g[1][c][i] += d_;     // evaluated by lanes 0..31
+              g[0][c][i] += s_;     // evaluated by lanes 32..63
+            }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < KPW; ++k) {
+          const float czr = fmaf(L.az[k], cr, -1.0f);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const float u = fmaf(L.ay[k], sa[i], L.ax[k] * ca[i]);
+            float A = 0.0f;
+#pragma unroll
+            for (int sg = 0; sg < 2; ++sg) {
+              const float ss = sg ? -sr : sr;
+              const float t = fmaf(ss, u, czr);
+              const float ex = fexp2(L.lp[k] * t);
+              const float c0 = g[sg][0][i], c1 = g[sg][1][i], c2 = g[sg][2][i];
+              gw0[k] = fmaf(c0, ex, gw0[k]);
+              gw1[k] = fmaf(c1, ex, gw1[k]);
+              gw2[k] = fmaf(c2, ex, gw2[k]);
+              const float T = fmaf(c2, L.w2[k], fmaf(c1, L.w1[k], c0 * L.w0[k])) * ex;
+              glam[k] = fmaf(T, t, glam[k]);
+              A = fmaf(ss, T, A);
+              gaz[k] = fmaf(cr, T, gaz[k]);
+            }
+            gax[k] = fmaf(ca[i], A, gax[k]);
+            gay[k] = fmaf(sa[i], A, gay[k]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  if (ortho) row_loop(std::true_type{}); else row_loop(std::false_type{});
+
+  if (x.active) {
+    float* g_axis_b = a.g_axis + (size_t)b * K * 3 * RC;
+    float* g_lamb_b = a.g_lamb + (size_t)b * K * RC;
+    float* g_weight_b = a.g_weight + (size_t)b * K * 3 * RC;
+#pragma unroll
+    for (int k = 0; k < KPW; ++k) {
+      const int kk = half * KPW + k;
+      if (kk < K) {
+        const unsigned o3 = (unsigned)(kk * 3 * RC + p), o1 = (unsigned)(kk * RC + p);
+        const float lam = L.lp[k] * kLn2;
+        g_axis_b[o3] = lam * gax[k];
+        g_axis_b[o3 + RC] = lam * gay[k];
+        g_axis_b[o3 + 2 * RC] = lam * gaz[k];
+        float gl = glam[k], q0 = gw0[k], q1 = gw1[k], q2 = gw2[k];
+        if (a.premap) {
+          gl *= premap_grad(lam);
+          q0 *= premap_grad(L.w0[k]); q1 *= premap_grad(L.w1[k]); q2 *= premap_grad(L.w2[k]);
+        }
+        g_lamb_b[o1] = gl;
+        g_weight_b[o3] = q0;
+        g_weight_b[o3 + RC] = q1;
+        g_weight_b[o3 + 2 * RC] = q2;
       }
     }
   }

@@ -12,48 +12,43 @@
 //                         four directions at a time, evaluates the reconstruction loss AND its cotangent
 //                         there and then, adds the render cotangent, and accumulates the SG gradients.
 //
-// Backward work decomposition (same as sg_bwd_split_kernel): a 128-thread workgroup = two waves over the
-// same 64 pixels, wave w owning lobes [6w, 6w+6).  The radiance of a direction needs all 12 lobes, so per
-// chunk of 4 directions (two azimuths x both half-rows) each wave publishes its 6-lobe partial radiance (12
-// floats) and the BRDF terms of the two directions it shaded (4 floats) in LDS; one barrier per chunk
-// (exchange buffers alternate), after which both waves hold the full radiance and cotangent.
+// Backward work decomposition: one wave = 32 pixels x 2 lobe groups.  Lanes l and l+32 own the same pixel;
+// lanes 0..31 hold lobes 0..5, lanes 32..63 lobes 6..11 (the register budget of 12 lobes + 12 gradient sets
+// per lane would not fit).  The radiance of a direction needs all 12 lobes and its cotangent is needed by
+// both halves, so per chunk of 4 directions (two azimuths x both half rows) the halves trade values with
+// v_permlane32_swap_b32 -- gfx950's swap of the upper 32 lanes of one VGPR with the lower 32 of another --
+// arranged so that no select is needed:
+//   swap(D = partial of half row 1, S = partial of half row 0); D + S = total of half row 1 in lanes 0..31,
+//                                                                       total of half row 0 in lanes 32..63
+//   each half evaluates loss, reconstruction and render cotangent for the half row it now holds (6 values)
+//   swap(D = g, S = g):  D = cotangent of half row 1 in all lanes, S = cotangent of half row 0 in all lanes
+// 12 VALU swaps + 6 adds per chunk; no LDS traffic, no barrier, no duplicated transcendental.
 #include "sgr_forward.inl"
 #include "sgr_recon_fold.h"
 
 namespace sgr {
 
-// exchange area: [buf][wave][16 values][64 lanes]; inline-asm LDS ops for the same reason as
-// tile_dma_read_pairs (a ds_read the compiler can see drains all outstanding LDS-DMA first)
-__device__ __forceinline__ void xch_write(unsigned addr, const float (&v)[16]) {
-#pragma unroll
-  for (int i = 0; i < 16; ++i) asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(addr), "v"(v[i]), "n"(i * 256) : "memory");
-}
-__device__ __forceinline__ void xch_read(unsigned addr, float (&v)[16]) {
-#pragma unroll
-  for (int i = 0; i < 16; ++i) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[i]) : "v"(addr), "n"(i * 256) : "memory");
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-}
-
 template <int POOL>
-__global__ __launch_bounds__(2 * kWave, 2) void sg_bwd_recon_kernel(const Args a) {
-  constexpr int EW = 16, TJ = 16, HALF = 8, NP = 4, KPW = 6;
-  using D = DmaTile<TJ>;
-  __shared__ __attribute__((aligned(16))) float tile[2 * D::kFloats];          // ground-truth rows, double-buffered
-  __shared__ __attribute__((aligned(16))) float xch[2 * 2 * 16 * kWave];       // partial radiance + BRDF terms
+__global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_kernel(const Args a) {
+  constexpr int EW = 16, HALF = 8, NP = 4, KPW = 6;
+  __shared__ __attribute__((aligned(16))) float tile[2 * kT32Floats];          // ground-truth rows, double-buffered
 
-  const int wave = threadIdx.x >> 6;
-  Pix x;
-  x.lane = threadIdx.x & 63;
+  const int lane = threadIdx.x, half = lane >> 5, pl = lane & 31;
+  const int own = 1 - half;                         // the half row (sign) this half-wave evaluates the cotangent of
   const int RC = a.R * a.C, K = a.K;
+  Pix x;
+  x.lane = lane;
   {
-    const int tiles = (RC + kWave - 1) / kWave;
+    const int tiles = (RC + kPx - 1) / kPx;
     x.b = blockIdx.x / tiles;
-    x.p0 = (blockIdx.x - x.b * tiles) * kWave;
-    x.active = (x.p0 + x.lane) < RC;
-    x.p = x.active ? (x.p0 + x.lane) : (RC - 1);
+    x.p0 = (blockIdx.x - x.b * tiles) * kPx;
+    x.active = (x.p0 + pl) < RC;
+    x.p = x.active ? (x.p0 + pl) : (RC - 1);
   }
-  const int lane = x.lane, b = x.b, p = x.p;
+  const int b = x.b, p = x.p;
+
+  __amdgpu_buffer_rsrc_t gimg = env_rsrc(a.env_gt + (size_t)b * 3 * RC * a.J, RC, a.J);
+  tile32_dma_issue(tile, gimg, x.p0, RC, a.J, 0, lane);
 
   float alb[3];
   const Frame f = load_frame<POOL>(a, x, alb);
@@ -76,34 +71,45 @@ __global__ __launch_bounds__(2 * kWave, 2) void sg_bwd_recon_kernel(const Args a
   const float grec = 2.0f * m * a.rec_scale[0] * cf * kLn2;     // times dl (in log2 units) / x
   float loss = 0.0f;
 
-  const SepTable rows = as_sep_table(a.rows);
-  const XTable cst = (XTable)(a.cols);
-  const XTable xt = (XTable)(a.cols + EW);
-  __amdgpu_buffer_rsrc_t gimg = env_rsrc(a.env_gt + (size_t)b * 3 * RC * a.J, RC, a.J);
-  const int eh = a.eh;
-  const unsigned xmine = lds_addr(xch) + (unsigned)((wave * 16 * kWave + lane) * 4);
-  const unsigned xother = lds_addr(xch) + (unsigned)(((wave ^ 1) * 16 * kWave + lane) * 4);
-  constexpr unsigned kBufBytes = 2 * 16 * kWave * 4;
-
+  // this half's lobes: per-lane offsets into the image's SG block (lobe index differs between the halves)
   Lobes<KPW> L;
-  load_lobes<KPW, false>(a, x, wave * KPW, L, false);
+  const float* axis_b = a.axis + (size_t)b * K * 3 * RC;
+  const float* lamb_b = a.lamb + (size_t)b * K * RC;
+  const float* weight_b = a.weight + (size_t)b * K * 3 * RC;
+#pragma unroll
+  for (int k = 0; k < KPW; ++k) {
+    const int kk = half * KPW + k, kc = min(kk, K - 1);
+    const unsigned o3 = (unsigned)(kc * 3 * RC + p), o1 = (unsigned)(kc * RC + p);
+    L.ax[k] = axis_b[o3]; L.ay[k] = axis_b[o3 + RC]; L.az[k] = axis_b[o3 + 2 * RC];
+    L.lp[k] = lamb_b[o1];
+    L.w0[k] = weight_b[o3]; L.w1[k] = weight_b[o3 + RC]; L.w2[k] = weight_b[o3 + 2 * RC];
+  }
+#pragma unroll
+  for (int k = 0; k < KPW; ++k) {
+    const bool live = half * KPW + k < K;
+    float l = L.lp[k], t0 = L.w0[k], t1 = L.w1[k], t2 = L.w2[k];
+    if (a.premap) { l = premap(l); t0 = premap(t0); t1 = premap(t1); t2 = premap(t2); }
+    L.lp[k] = l * kLog2e;
+    L.w0[k] = live ? t0 : 0.0f; L.w1[k] = live ? t1 : 0.0f; L.w2[k] = live ? t2 : 0.0f;
+  }
   float gax[KPW], gay[KPW], gaz[KPW], glam[KPW], gw0[KPW], gw1[KPW], gw2[KPW];
 #pragma unroll
   for (int k = 0; k < KPW; ++k) gax[k] = gay[k] = gaz[k] = glam[k] = gw0[k] = gw1[k] = gw2[k] = 0.0f;
 
-  tile_dma_issue_part<TJ>(tile, gimg, x.p0, RC, a.J, 0, lane, wave, 2);
+  const SepTable rows = as_sep_table(a.rows);
+  const XTable cst = (XTable)(a.cols);
+  const XTable xt = (XTable)(a.cols + EW);
+  const int eh = a.eh;
 
   auto row_loop = [&](auto ortho_c) {
-    unsigned par = 0;
     for (int e = 0; e < eh; ++e) {
-      const float* cur = tile + (e & 1) * D::kFloats;
+      const float* cur = tile + (e & 1) * kT32Floats;
       if (e + 1 < eh) {
-        tile_dma_issue_part<TJ>(tile + ((e + 1) & 1) * D::kFloats, gimg, x.p0, RC, a.J, (e + 1) * EW, lane, wave, 2);
-        wait_vmcnt<6>();        // this wave's half of row e has landed; its half of row e+1 stays in flight
+        tile32_dma_issue(tile + ((e + 1) & 1) * kT32Floats, gimg, x.p0, RC, a.J, (e + 1) * EW, lane);
+        wait_vmcnt<6>();        // row e has landed; row e+1 stays in flight
       } else {
         wait_vmcnt<0>();
       }
-      barrier_lds_only();       // ... and so has the other wave's half
 #pragma unroll
       for (int k = 0; k < KPW; ++k) { asm volatile("" : "+v"(L.ax[k])); asm volatile("" : "+v"(L.ay[k])); }   // no LICM of u_ka
       fence_row_invariants(q);
@@ -115,11 +121,13 @@ __global__ __launch_bounds__(2 * kWave, 2) void sg_bwd_recon_kernel(const Args a
       for (int ap = 0; ap < NP; ++ap) {
         const f32x4 cs = cst[ap];
         const float ca[2] = {cs[0], cs[2]}, sa[2] = {cs[1], cs[3]};
-        // ---- 1. this wave's lobes: exponentials and partial radiance of the 4 directions ---------------
+        // ---- 1. this half's lobes: exponentials and partial radiance of the 4 directions -----------------
         float ex[KPW][2][2], u[KPW][2];
-        float v[16];
+        float v[2][3][2];        // [half row][colour][azimuth]
 #pragma unroll
-        for (int i = 0; i < 12; ++i) v[i] = 0.0f;
+        for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) v[sg][c][0] = v[sg][c][1] = 0.0f;
 #pragma unroll
         for (int k = 0; k < KPW; ++k) {
           const float czr = fmaf(L.az[k], cr, -1.0f);
@@ -131,54 +139,52 @@ __global__ __launch_bounds__(2 * kWave, 2) void sg_bwd_recon_kernel(const Args a
               const float t = fmaf(sg ? -sr : sr, u[k][i], czr);
               const float e_ = fexp2(L.lp[k] * t);
               ex[k][i][sg] = e_;
-              v[(sg * 3 + 0) * 2 + i] = fmaf(L.w0[k], e_, v[(sg * 3 + 0) * 2 + i]);
-              v[(sg * 3 + 1) * 2 + i] = fmaf(L.w1[k], e_, v[(sg * 3 + 1) * 2 + i]);
-              v[(sg * 3 + 2) * 2 + i] = fmaf(L.w2[k], e_, v[(sg * 3 + 2) * 2 + i]);
+              v[sg][0][i] = fmaf(L.w0[k], e_, v[sg][0][i]);
+              v[sg][1][i] = fmaf(L.w1[k], e_, v[sg][1][i]);
+              v[sg][2][i] = fmaf(L.w2[k], e_, v[sg][2][i]);
             }
           }
         }
-        // ---- 2. BRDF terms of the two directions of half-row `wave`; publish; fetch the other wave's -----
+        // ---- 2. full radiance of the half row this half-wave owns (lanes 0..31: half row 1, 32..63: half row 0)
+        float tot[3][2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            float d_ = v[1][c][i], s_ = v[0][c][i];
+            swap32(d_, s_);
+            tot[c][i] = d_ + s_;
+          }
+        // ---- 3. its cotangent: reconstruction term (and loss) + render term --------------------------------
+        float gt[3][2];
+        tile32_read_pair(cur, pl, own * HALF + ap * 2, gt);
+        float go[3][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           float wt, sp;
-          shade_dir<decltype(ortho_c)::value>(q, rc, wave, ca[i], sa[i], xt, ap * 2 + i, wt, sp);
-          v[12 + 2 * i] = wt;
-          v[13 + 2 * i] = sp;
-        }
-        xch_write(xmine + par * kBufBytes, v);
-        barrier_lds_only();
-        float o[16];
-        xch_read(xother + par * kBufBytes, o);
-        par ^= 1u;
-        float wts[2][2], sps[2][2];      // [sg][i]
+          shade_dir<decltype(ortho_c)::value>(q, rc, own, ca[i], sa[i], xt, ap * 2 + i, wt, sp);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          wts[0][i] = wave ? o[12 + 2 * i] : v[12 + 2 * i];
-          sps[0][i] = wave ? o[13 + 2 * i] : v[13 + 2 * i];
-          wts[1][i] = wave ? v[12 + 2 * i] : o[12 + 2 * i];
-          sps[1][i] = wave ? v[13 + 2 * i] : o[13 + 2 * i];
+          for (int c = 0; c < 3; ++c) {
+            const float xx = fmaf(cf, tot[c][i], off);
+            const float r = __builtin_amdgcn_rcpf(xx);
+            const float dl = -__builtin_amdgcn_logf((gt[c][i] + off) * r);   // log2(x / (gt + off))
+            loss = fmaf(dl, dl, loss);
+            const float gr = c == 0 ? fmaf(gs0, sp, gd0) : (c == 1 ? fmaf(gs1, sp, gd1) : fmaf(gs2, sp, gd2));
+            go[c][i] = fmaf(grec * dl, r, wt * gr);
+          }
         }
-        // ---- 3. cotangent of the radiance: reconstruction term (and loss) + render term -----------------
-        float gt[2][3][2];
-        tile_dma_read_pairs<TJ>(cur, lane, ap * 2, HALF + ap * 2, gt);
+        // ---- 4. both half rows' cotangents to all lanes --------------------------------------------------------
         float g[2][3][2];
 #pragma unroll
-        for (int sg = 0; sg < 2; ++sg)
+        for (int c = 0; c < 3; ++c)
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
-            const float wt = wts[sg][i], sp = sps[sg][i];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              const float pf = v[(sg * 3 + c) * 2 + i] + o[(sg * 3 + c) * 2 + i];
-              const float xx = fmaf(cf, pf, off);
-              const float r = __builtin_amdgcn_rcpf(xx);
-              const float dl = -__builtin_amdgcn_logf((gt[sg][c][i] + off) * r);   // log2(x / (gt + off))
-              loss = fmaf(dl, dl, loss);
-              const float gr = c == 0 ? fmaf(gs0, sp, gd0) : (c == 1 ? fmaf(gs1, sp, gd1) : fmaf(gs2, sp, gd2));
-              g[sg][c][i] = fmaf(grec * dl, r, wt * gr);
-            }
+            float d_ = go[c][i], s_ = go[c][i];
+            swap32(d_, s_);
+            g[1][c][i] = d_;     // from lanes 0..31
+            g[0][c][i] = s_;     // from lanes 32..63
           }
-        // ---- 4. this wave's lobes: gradient accumulation ------------------------------------------------
+        // ---- 5. this half's lobes: gradient accumulation -------------------------------------------------------
 #pragma unroll
         for (int k = 0; k < KPW; ++k) {
           const float czr = fmaf(L.az[k], cr, -1.0f);
@@ -205,40 +211,40 @@ __global__ __launch_bounds__(2 * kWave, 2) void sg_bwd_recon_kernel(const Args a
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      barrier_lds_only();   // both waves are done with `cur` before it is refilled
     }
   };
   if (ortho) row_loop(std::true_type{}); else row_loop(std::false_type{});
 
-  // loss partial of the tile: sum_p m_p sum_{c,j} (ln x - ln(gt+off))^2   (both waves hold it; wave 0 writes)
+  // loss partial of the tile: sum_p m_p sum_{c,j} (ln x - ln(gt+off))^2   (each half holds its half rows' share)
   {
     float r0 = m * loss * (kLn2 * kLn2);
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) r0 += __shfl_xor(r0, s, 64);
-    if (wave == 0 && lane == 0) a.ws[blockIdx.x] = r0;
+    if (lane == 0) a.ws[blockIdx.x] = r0;
   }
 
   if (x.active) {
+    float* g_axis_b = a.g_axis + (size_t)b * K * 3 * RC;
+    float* g_lamb_b = a.g_lamb + (size_t)b * K * RC;
+    float* g_weight_b = a.g_weight + (size_t)b * K * 3 * RC;
 #pragma unroll
     for (int k = 0; k < KPW; ++k) {
-      const int kk = wave * KPW + k;
+      const int kk = half * KPW + k;
       if (kk < K) {
-        const size_t ab = ((size_t)(b * K + kk) * 3) * RC;
-        const size_t lb = (size_t)(b * K + kk) * RC;
-        const unsigned up = (unsigned)p;
+        const unsigned o3 = (unsigned)(kk * 3 * RC + p), o1 = (unsigned)(kk * RC + p);
         const float lam = L.lp[k] * kLn2;
-        (a.g_axis + ab)[up] = lam * gax[k];
-        (a.g_axis + ab + RC)[up] = lam * gay[k];
-        (a.g_axis + ab + 2 * (size_t)RC)[up] = lam * gaz[k];
+        g_axis_b[o3] = lam * gax[k];
+        g_axis_b[o3 + RC] = lam * gay[k];
+        g_axis_b[o3 + 2 * RC] = lam * gaz[k];
         float gl = glam[k], q0 = gw0[k], q1 = gw1[k], q2 = gw2[k];
         if (a.premap) {
           gl *= premap_grad(lam);
           q0 *= premap_grad(L.w0[k]); q1 *= premap_grad(L.w1[k]); q2 *= premap_grad(L.w2[k]);
         }
-        (a.g_lamb + lb)[up] = gl;
-        (a.g_weight + ab)[up] = q0;
-        (a.g_weight + ab + RC)[up] = q1;
-        (a.g_weight + ab + 2 * (size_t)RC)[up] = q2;
+        g_lamb_b[o1] = gl;
+        g_weight_b[o3] = q0;
+        g_weight_b[o3 + RC] = q1;
+        g_weight_b[o3 + 2 * RC] = q2;
       }
     }
   }
@@ -272,8 +278,11 @@ static bool fused_recon_ok(int K, int R, int C, int eh, int ew) {
 
 extern "C" int sgr_fused_recon_supported(int K, int R, int C, int eh, int ew) { return fused_recon_ok(K, R, C, eh, ew) ? 1 : 0; }
 
-// workspace: [bn,tiles,3] forward partials | [bn,tiles] loss partials | [bn] per-image mask sums | [1] scale
-extern "C" int sgr_fused_recon_workspace_floats(int bn, int R, int C) { return bn * recon_tiles(R * C) * 4 + bn + 4; }
+static int recon_tiles32(int RC) { return (RC + kPx - 1) / kPx; }
+// workspace: [bn] per-image mask sums | [4] scale | [bn,tiles64,3] forward partials | [bn,tiles32] loss partials
+extern "C" int sgr_fused_recon_workspace_floats(int bn, int R, int C) {
+  return bn + 4 + bn * recon_tiles(R * C) * 3 + bn * recon_tiles32(R * C);
+}
 
 extern "C" int sgr_fused_fwd_recon(const float* albedo, const float* normal, const float* rough, const float* axis, const float* lamb,
                                    const float* weight, const float* dirs, const float* view, const float* env_gt,
@@ -293,8 +302,8 @@ extern "C" int sgr_fused_fwd_recon(const float* albedo, const float* normal, con
   set_dims(a, bn, K, R, C, eh, ew, imH, imW);
   a.F0 = F0; a.premap = premap;
   const int tiles = recon_tiles(R * C);
-  float* ws0 = workspace;
-  float* den_img = workspace + (size_t)bn * tiles * 4;
+  float* den_img = workspace;
+  float* ws0 = workspace + bn + 4;
   a.ws = ws0;
   const hipStream_t st = (hipStream_t)stream;
   const dim3 grid = wave_grid(bn, R, C), block(kWave);
@@ -330,16 +339,16 @@ extern "C" int sgr_fused_bwd_recon(const float* albedo, const float* normal, con
   a.env_gt = env_gt; a.mask_in = mask; a.coef = coef; a.offset = offset;
   set_dims(a, bn, K, R, C, eh, ew, imH, imW);
   a.F0 = F0; a.premap = premap;
-  const int tiles = recon_tiles(R * C);
-  float* ws1 = workspace + (size_t)bn * tiles * 3;
-  float* den_img = workspace + (size_t)bn * tiles * 4;
-  float* scale = den_img + bn;
+  const int tiles = recon_tiles(R * C), tiles32 = recon_tiles32(R * C);
+  float* den_img = workspace;
+  float* scale = workspace + bn;
+  float* ws1 = workspace + bn + 4 + (size_t)bn * tiles * 3;
   a.ws = ws1; a.rec_scale = scale;
   const hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(recon_scale_kernel, dim3(1), dim3(64), 0, st, den_img, den_global, scale, bn, rec_weight / (3.0f * (float)(eh * ew)));
-  const dim3 grid = wave_grid(bn, R, C), block(2 * kWave);
+  const dim3 grid((unsigned)(bn * tiles32)), block(kWave);
   if (imH == R && imW == C) hipLaunchKernelGGL((sg_bwd_recon_kernel<1>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((sg_bwd_recon_kernel<2>), grid, block, 0, st, a);
-  hipLaunchKernelGGL(recon_fold1, dim3(1), dim3(kRThreads), 0, st, ws1, den_img, parts, bn, tiles);     // parts = (loss numerator, local sum of the env mask)
+  hipLaunchKernelGGL(recon_fold1, dim3(1), dim3(kRThreads), 0, st, ws1, den_img, parts, bn, tiles32);     // parts = (loss numerator, local sum of the env mask)
   return sgr_check((int)hipGetLastError(), "sgr_fused_bwd_recon");
 }
