@@ -6,7 +6,8 @@ its step (trainLight.py:203-244 -> wrapperBRDFLight.py:158-207) around synthetic
 
   * "frozen BRDF net outputs": albedo / normal / rough maps (no grad, like trainLight.py:121-144);
   * the light network is replaced by three learnable tensors pushed through decoderLight's output
-    activations (models.py:336-346): 1.01*tanh -> unit axes, 0.5*(x+1) clamped to [0,1] for lamb/weight;
+    activations (models.py:336-346): 1.01*tanh -> unit axes, 0.5*(x+1) clamped to [0,1] for lamb/weight
+    (sgr.light_heads, one HIP pass each way; --torch-heads for the op-by-op torch version);
   * step = zero_grad -> objective -> backward -> Adam, the objective being either
       fused (default): sgr.light_objective -- render loss + 10 x log-L2 env reconstruction loss in two heavy
                        kernel passes, the predicted env image never written, or
@@ -27,7 +28,8 @@ import inverserenderingofindoorscene_amd as sgr  # noqa: E402
 
 
 def decoder_heads(t_axis, t_lamb, t_weight):
-    """Output activations of decoderLight (models.py:336-346)."""
+    """Output activations of decoderLight (models.py:336-346) in torch ops (--torch-heads; the default path is the
+    fused sgr.light_heads kernel pair)."""
     a = 1.01 * torch.tanh(t_axis)
     a = a / torch.clamp(torch.sqrt((a * a).sum(2, keepdim=True)), min=1e-6)
     lam = torch.clamp(0.5 * (1.01 * torch.tanh(t_lamb) + 1), 0, 1)
@@ -61,7 +63,7 @@ def make_batch(bn, imH, imW, R, C, eh, ew, dev, seed=0):
 
 
 def train(bn=16, steps=10, imH=240, imW=320, R=120, C=160, K=12, eh=8, ew=16, renW=1.0, recW=10.0, lr=1e-2,
-          seed=0, verbose=True, fused=True):
+          seed=0, verbose=True, fused=True, hip_heads=True):
     dev = torch.device("cuda")
     batch = make_batch(bn, imH, imW, R, C, eh, ew, dev, seed)
     g = torch.Generator().manual_seed(seed + 1)
@@ -77,7 +79,10 @@ def train(bn=16, steps=10, imH=240, imW=320, R=120, C=160, K=12, eh=8, ew=16, re
             torch.cuda.synchronize()
             t0 = time.perf_counter()
         opt.zero_grad()
-        axis, lam, w = decoder_heads(*params)
+        if hip_heads:
+            axis, lam, w, _ = sgr.light_heads(params[0].view(bn, 3 * K, R, C), params[1], params[2])
+        else:
+            axis, lam, w = decoder_heads(*params)
         if fused and sgr.light_objective_supported(K, R, C, eh, ew):
             total, render_err, recon_err, _, _ = sgr.light_objective(layer, batch["albedo"], batch["normal"], batch["rough"], axis, lam, w,
                                                                      batch["im"], batch["seg"], batch["env_gt"], batch["env_ind"],
@@ -105,5 +110,6 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--unfused", action="store_true", help="materialise the env image and use the separate loss kernels")
+    ap.add_argument("--torch-heads", action="store_true", help="decoder output activations as torch ops instead of sgr.light_heads")
     args = ap.parse_args()
-    train(bn=args.batch, steps=args.steps, fused=not args.unfused)
+    train(bn=args.batch, steps=args.steps, fused=not args.unfused, hip_heads=not args.torch_heads)

@@ -214,6 +214,30 @@ int sgr_fused_bwd_recon(const float* albedo, const float* normal, const float* r
                         int bn, int K, int R, int C, int eh, int ew, int imH, int imW, float F0, int premap,
                         float offset, float rec_weight, void* stream);
 
+/* Cotangent scaling for gradients produced ahead of the backward call: x[i][0..n[i]) *= *scale / *applied in
+ * place (i < count; x, n are HOST arrays of device pointers / lengths), then *applied = *scale.  Skipped on the
+ * device when the two are equal (the cotangent of a scalar objective is normally 1).  No host sync. */
+int sgr_rescale_inplace(float* const* x, const long long* n, int count, const float* scale, float* applied, void* stream);
+
+/* ---- light-decoder output heads --------------------------------------------
+ * The activations at the end of models.decoderLight.forward (models.py:336-346) for the three decoders
+ * and, if `packed` is given, the cascade hand-off tensor envmapsPred of wrapperBRDFLight.py:167-168:
+ *   axis   [bn,K,3,R,C] = a / max(|a|, 1e-6),  a = 1.01 tanh(x_axis)        (mode 0)
+ *   lamb   [bn,K,R,C]   = clamp(0.5 (1.01 tanh(x_lamb) + 1), 0, 1)          (mode 1)
+ *   weight [bn,3K,R,C]  = clamp(0.5 (1.01 tanh(x_weight) + 1), 0, 1)        (mode 2)
+ *   packed [bn,7K,R,C]  = axis (3K channels) | lamb (K) | weight (3K)        (nullable)
+ * x_* are the dconvFinal outputs ([bn,3K,R,C], [bn,K,R,C], [bn,3K,R,C]). */
+int sgr_light_heads_fwd(const float* x_axis, const float* x_lamb, const float* x_weight,
+                        float* axis, float* lamb, float* weight, float* packed,
+                        int bn, int K, int R, int C, void* stream);
+
+/* Cotangents may come through the separate outputs, the packed tensor, or both (each nullable; they add).
+ * Clamp passes the cotangent on the closed interval, like torch; the norm clamp blocks it below 1e-6. */
+int sgr_light_heads_bwd(const float* x_axis, const float* x_lamb, const float* x_weight,
+                        const float* g_axis, const float* g_lamb, const float* g_weight, const float* g_packed,
+                        float* gx_axis, float* gx_lamb, float* gx_weight,
+                        int bn, int K, int R, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

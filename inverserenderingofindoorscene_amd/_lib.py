@@ -59,6 +59,9 @@ SIGNATURES = {
     "sgr_fused_recon_supported": ([_I] * 5, c_int),
     "sgr_fused_recon_workspace_floats": ([_I, _I, _I], c_int),
     "sgr_fused_fwd_recon": ([_P] * 17 + [_I] * 8 + [_F, _I, _P], c_int),
+    "sgr_light_heads_fwd": ([_P] * 7 + [_I] * 4 + [_P], c_int),
+    "sgr_light_heads_bwd": ([_P] * 10 + [_I] * 4 + [_P], c_int),
+    "sgr_rescale_inplace": ([_P, _P, _I, _P, _P, _P], c_int),
     "sgr_fused_bwd_recon": ([_P] * 19 + [_I] * 8 + [_F, _I, _F, _F, _P], c_int),
 }
 

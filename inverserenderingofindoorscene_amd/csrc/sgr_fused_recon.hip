@@ -266,6 +266,22 @@ __global__ void recon_scale_kernel(const float* __restrict__ den_img, const floa
   }
 }
 
+// x *= s / applied, skipped entirely when the two are equal (the usual cotangent of a scalar objective is 1)
+__global__ __launch_bounds__(256) void rescale_kernel(float* __restrict__ x, long long n, const float* __restrict__ s,
+                                                      const float* __restrict__ applied) {
+  const float f = s[0] / applied[0];
+  if (f == 1.0f) return;
+  const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i0 + 3 < n) {
+    f32x4 v = *reinterpret_cast<f32x4*>(x + i0);
+    v *= f;
+    *reinterpret_cast<f32x4*>(x + i0) = v;
+  } else {
+    for (long long i = i0; i < n; ++i) x[i] *= f;
+  }
+}
+__global__ void set_scalar_kernel(float* dst, const float* src) { dst[0] = src[0]; }
+
 }  // namespace sgr
 
 using namespace sgr;
@@ -351,4 +367,19 @@ extern "C" int sgr_fused_bwd_recon(const float* albedo, const float* normal, con
   else hipLaunchKernelGGL((sg_bwd_recon_kernel<2>), grid, block, 0, st, a);
   hipLaunchKernelGGL(recon_fold1, dim3(1), dim3(kRThreads), 0, st, ws1, den_img, parts, bn, tiles32);     // parts = (loss numerator, local sum of the env mask)
   return sgr_check((int)hipGetLastError(), "sgr_fused_bwd_recon");
+}
+
+// Cotangent scaling for gradients that were produced ahead of the backward call (sgr.light_objective):
+// every x[i] (i = 0..count-1, n[i] floats, 16-byte aligned) is multiplied in place by scale / *applied, then
+// *applied = scale; nothing is touched when the two are equal.  All on the stream, no host sync.
+extern "C" int sgr_rescale_inplace(float* const* x, const long long* n, int count, const float* scale, float* applied, void* stream) {
+  SGR_REQUIRE(x && n && scale && applied && count >= 0, "sgr_rescale_inplace: NULL argument");
+  const hipStream_t st = (hipStream_t)stream;
+  for (int i = 0; i < count; ++i) {
+    SGR_REQUIRE(x[i] && n[i] > 0, "sgr_rescale_inplace: empty tensor");
+    const long long blocks = (n[i] + 1023) / 1024;
+    hipLaunchKernelGGL(rescale_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x[i], n[i], scale, applied);
+  }
+  hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, st, applied, scale);
+  return sgr_check((int)hipGetLastError(), "sgr_rescale_inplace");
 }

@@ -27,7 +27,7 @@ import torch.nn.functional as F
 
 from . import _lib, tables
 
-__all__ = ["output2env", "renderingLayer", "render_from_sg", "renderLayer", "output_radiance", "predToShading"]
+__all__ = ["light_heads", "output2env", "renderingLayer", "render_from_sg", "renderLayer", "output_radiance", "predToShading"]
 
 
 # --------------------------------------------------------------------------- #
@@ -394,6 +394,60 @@ def render_from_sg(albedo, normal, rough, axisOrig, lambOrig, weightOrig, need_e
 
 
 _LAYERS: Dict[Tuple, "renderingLayer"] = {}
+
+
+class _LightHeads(torch.autograd.Function):
+    """sgr_light_heads_fwd / sgr_light_heads_bwd."""
+
+    @staticmethod
+    def forward(ctx, xa, xl, xw, need_packed):
+        dev = _require_hip(xa, xl, xw)
+        xa_c, xl_c, xw_c = xa.contiguous(), xl.contiguous(), xw.contiguous()
+        if xa_c.dim() != 4 or xl_c.dim() != 4 or xw_c.dim() != 4 or xa_c.shape[1] % 3 != 0:
+            raise RuntimeError("sgrender: light_heads takes the three decoders' [bn,3K,R,C], [bn,K,R,C], [bn,3K,R,C] outputs")
+        bn, K3, R, C = xa_c.shape
+        K = K3 // 3
+        if tuple(xl_c.shape) != (bn, K, R, C) or tuple(xw_c.shape) != (bn, 3 * K, R, C):
+            raise RuntimeError(f"sgrender: light_heads shapes disagree: {tuple(xa_c.shape)}, {tuple(xl_c.shape)}, {tuple(xw_c.shape)}")
+        axis = torch.empty((bn, K, 3, R, C), device=dev, dtype=torch.float32)
+        lamb = torch.empty((bn, K, R, C), device=dev, dtype=torch.float32)
+        weight = torch.empty((bn, 3 * K, R, C), device=dev, dtype=torch.float32)
+        packed = torch.empty((bn, 7 * K, R, C), device=dev, dtype=torch.float32) if need_packed else None
+        with torch.cuda.device(dev):
+            _lib.call("sgr_light_heads_fwd", _ptr(xa_c), _ptr(xl_c), _ptr(xw_c), _ptr(axis), _ptr(lamb), _ptr(weight), _ptr(packed),
+                      bn, K, R, C, _stream(dev))
+        ctx.save_for_backward(xa_c, xl_c, xw_c)
+        ctx.set_materialize_grads(False)
+        if need_packed:
+            return axis, lamb, weight, packed
+        return axis, lamb, weight
+
+    @staticmethod
+    def backward(ctx, *grads):
+        xa, xl, xw = ctx.saved_tensors
+        dev = xa.device
+        bn, K3, R, C = xa.shape
+        g = [None if t is None else t.contiguous() for t in grads] + [None] * (4 - len(grads))
+        if all(t is None for t in g):
+            return None, None, None, None
+        gxa, gxl, gxw = torch.empty_like(xa), torch.empty_like(xl), torch.empty_like(xw)
+        with torch.cuda.device(dev):
+            _lib.call("sgr_light_heads_bwd", _ptr(xa), _ptr(xl), _ptr(xw), _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]),
+                      _ptr(gxa), _ptr(gxl), _ptr(gxw), bn, K3 // 3, R, C, _stream(dev))
+        return gxa, gxl, gxw, None
+
+
+def light_heads(xAxis, xLamb, xWeight, need_packed=False):
+    """Output activations of the reference's three light decoders (``models.decoderLight`` modes 0 / 1 / 2,
+    models.py:336-346) applied to their last convolution's outputs, in one HIP pass each way:
+    ``(axisPred [bn,K,3,R,C], lambPred [bn,K,R,C], weightPred [bn,3K,R,C], envmapsPred or None)``.
+
+    ``envmapsPred [bn,7K,R,C]`` (``need_packed=True``) is the packed cascade hand-off tensor of
+    wrapperBRDFLight.py:167-168 (what ``outputBRDFLight.py`` stores as ``imenv_*.h5`` and cascade 1 reads)."""
+    out = _LightHeads.apply(xAxis, xLamb, xWeight, bool(need_packed))
+    if need_packed:
+        return out
+    return tuple(out) + (None,)
 
 
 def predToShading(pred, envWidth=32, envHeight=16, SGNum=12):

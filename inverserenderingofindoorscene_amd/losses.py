@@ -15,6 +15,7 @@ loss is the reference's batch-global ratio.
 """
 from __future__ import annotations
 
+import ctypes
 from typing import Optional, Tuple
 
 import torch
@@ -280,20 +281,34 @@ class _LightObjective(torch.autograd.Function):
         render_err = num_r / torch.clamp(den_r, min=1e-5) / 3.0
         recon_err = num_e / torch.clamp(den_e, min=1e-5) / (3.0 * eh * ew)
         objective = float(ren_w) * render_err + float(rec_w) * recon_err
-        ctx.save_for_backward(g_axis, g_lamb, g_weight)
+        applied = torch.ones(1, **f32)            # the cotangent the stored gradients are currently scaled by
+        ctx.save_for_backward(g_axis, g_lamb, g_weight, applied)
         ctx.mark_non_differentiable(render_err, recon_err, rendered, coef)
         return objective, render_err, recon_err, rendered, coef
 
     @staticmethod
     def backward(ctx, g_obj, *_unused):
-        g_axis, g_lamb, g_weight = ctx.saved_tensors
+        g_axis, g_lamb, g_weight, applied = ctx.saved_tensors
         if any(ctx.needs_input_grad[:3]) or any(ctx.needs_input_grad[6:10]):
             raise NotImplementedError("sgrender: light_objective differentiates w.r.t. the SG parameters only "
                                       "(trainLight mode, wrapperBRDFLight.py:194 detaches the BRDF maps)")
+        # the gradients exist already; scale them by the incoming cotangent on the device (a no-op kernel when it
+        # equals what they are scaled by already -- 1 for a plain objective.backward())
+        dev = g_axis.device
+        gs = (g_axis, g_lamb, g_weight)
+        if getattr(ctx, "handed_out", False):      # a second backward through this node (retain_graph): the buffers
+            f = g_obj.detach() / applied[0]        # may be somebody's .grad by now -- leave them alone
+            return tuple([None] * 3 + [g * f if ctx.needs_input_grad[3 + i] else None for i, g in enumerate(gs)] + [None] * 9)
+        ctx.handed_out = True
+        ptrs = (ctypes.c_void_p * 3)(*[g.data_ptr() for g in gs])
+        lens = (ctypes.c_longlong * 3)(*[g.numel() for g in gs])
+        scale = g_obj.detach().to(torch.float32).reshape(1).contiguous()
+        with torch.cuda.device(dev):
+            _lib.call("sgr_rescale_inplace", ctypes.addressof(ptrs), ctypes.addressof(lens), 3, _ptr(scale), _ptr(applied), _stream(dev))
         outs = [None] * 15
         for i, g in ((3, g_axis), (4, g_lamb), (5, g_weight)):
             if ctx.needs_input_grad[i]:
-                outs[i] = g * g_obj
+                outs[i] = g
         return tuple(outs)
 
 

@@ -316,6 +316,25 @@ def recon_loss(env_pred, env_gt, seg, env_ind, R: int, C: int, offset: float = 1
 
 
 # --------------------------------------------------------------------------- #
+# light-decoder output heads                      #
+# --------------------------------------------------------------------------- #
+def light_heads(x_axis, x_lamb, x_weight):
+    """Output activations of the three light decoders and the packed cascade hand-off tensor
+    (models.py:336-346 per decoder, mode 0 / 1 / 2; wrapperBRDFLight.py:163-168 for the packing).
+
+    ``x_axis [bn,3K,R,C]``, ``x_lamb [bn,K,R,C]``, ``x_weight [bn,3K,R,C]`` are the outputs of ``dconvFinal``.
+    Returns ``(axisPred [bn,K,3,R,C], lambPred [bn,K,R,C], weightPred [bn,3K,R,C], envmapsPred [bn,7K,R,C])``."""
+    bn, K3, R, C = x_axis.shape
+    K = K3 // 3
+    a = (1.01 * torch.tanh(x_axis)).view(bn, K, 3, R, C)                              # models.py:336,343
+    a = a / torch.clamp(torch.sqrt(torch.sum(a * a, dim=2).unsqueeze(2)), min=1e-6)     # :344-345
+    lam = torch.clamp(0.5 * (1.01 * torch.tanh(x_lamb) + 1), 0, 1)                     # :336,339-340
+    w = torch.clamp(0.5 * (1.01 * torch.tanh(x_weight) + 1), 0, 1)
+    packed = torch.cat([a.view(bn, K * 3, R, C), lam, w], dim=1)                        # wrapperBRDFLight.py:167-168
+    return a, lam, w, packed
+
+
+# --------------------------------------------------------------------------- #
 # seeded synthetic inputs (SURVEY.md section 8d) -- shared by tests and bench   #
 # --------------------------------------------------------------------------- #
 def synthetic_inputs(bn: int, imH: int, imW: int, R: int, C: int, K: int = 12,

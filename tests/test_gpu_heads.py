@@ -1,0 +1,76 @@
+"""GPU: light-decoder output heads (sgr_light_heads_fwd / _bwd) against the reference decoders' own outputs and
+gradients (tests/golden/g4_heads.npz) and the fp64 oracle at the training size."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sgr():
+    import inverserenderingofindoorscene_amd as pkg
+    from inverserenderingofindoorscene_amd import _lib
+    _lib.load()
+    return pkg
+
+
+def test_light_heads_vs_reference_decoders(sgr):
+    z = np.load(os.path.join(GOLDEN_DIR, "g4_heads.npz"))
+    x = {k: torch.from_numpy(z["x_" + k]).cuda().requires_grad_(True) for k in ("axis", "lamb", "weight")}
+    a, l, w, packed = sgr.light_heads(x["axis"], x["lamb"], x["weight"], need_packed=True)
+    outs = dict(axis=a, lamb=l, weight=w)
+    for k, y in outs.items():
+        ref = torch.from_numpy(z["y_" + k])
+        assert (y.detach().cpu() - ref).abs().max().item() < 1e-6, k
+        # the clamp decisions are the reference's bit for bit (same op-by-op rounding before the clamp)
+        if k != "axis":
+            assert torch.equal((y.detach().cpu() == 0) | (y.detach().cpu() == 1), (ref == 0) | (ref == 1)), k
+    K = a.shape[1]
+    assert torch.equal(packed[:, :3 * K], a.reshape(a.shape[0], 3 * K, *a.shape[3:]))
+    assert torch.equal(packed[:, 3 * K:4 * K], l) and torch.equal(packed[:, 4 * K:], w)
+    tot = sum((y * torch.from_numpy(z["ct_" + k]).cuda()).sum() for k, y in outs.items())
+    g = torch.autograd.grad(tot, [x["axis"], x["lamb"], x["weight"]])
+    for k, gi in zip(("axis", "lamb", "weight"), g):
+        assert rel_l2(gi.cpu(), z["gx_" + k]) < 1e-5, (k, rel_l2(gi.cpu(), z["gx_" + k]))
+
+
+def test_light_heads_packed_cotangent_and_full_size(sgr):
+    """Cotangents arriving through the packed tensor and through the separate outputs add up; config-2 size against
+    the fp64 oracle."""
+    from oracle import sg_oracle as O
+    bn, K, R, C = 16, 12, 120, 160
+    g = torch.Generator().manual_seed(5)
+    xs = [(torch.randn(s, generator=g) * 1.5) for s in ((bn, 3 * K, R, C), (bn, K, R, C), (bn, 3 * K, R, C))]
+    xs[0][0, :3, 0, 0] = 0.0                                   # a zero axis: the norm clamp is live
+    dev = [t.cuda().requires_grad_(True) for t in xs]
+    a, l, w, packed = sgr.light_heads(*dev, need_packed=True)
+    ct = [torch.randn(t.shape, generator=g) for t in (a, l, w, packed)]
+    tot = sum((y * c.cuda()).sum() for y, c in zip((a, l, w, packed), ct))
+    grads = torch.autograd.grad(tot, dev)
+    sub = slice(0, 2)                                          # oracle on two images; fp32 like the reference, so that
+    xo = [t[sub].clone().requires_grad_(True) for t in xs]     # the clamp decisions are taken on the same roundings
+    ao, lo, wo, po = O.light_heads(*xo)
+    for y, yo in zip((a, l, w, packed), (ao, lo, wo, po)):
+        assert (y[sub].detach().cpu() - yo.detach()).abs().max().item() < 1e-6
+    xo[0].data[0, :3, 0, 0] = 1e-30                            # the reference's gradient is NaN at an exactly-zero axis
+    ao, lo, wo, po = O.light_heads(*xo)
+    tot_o = sum((y * c[sub]).sum() for y, c in zip((ao, lo, wo, po), ct))
+    go = torch.autograd.grad(tot_o, xo)
+    for gi, gr in zip(grads, go):
+        gi, gr = gi[sub].cpu().clone(), gr.clone()
+        gi[0, :3, 0, 0] = 0.0
+        gr[0, :3, 0, 0] = 0.0
+        assert rel_l2(gi, gr) < 1e-5, rel_l2(gi, gr)
+    assert all(torch.isfinite(t).all() for t in grads)
+
+
+def test_light_heads_rejects_bad_shapes(sgr):
+    with pytest.raises(RuntimeError):
+        sgr.light_heads(torch.zeros(1, 35, 4, 4, device="cuda"), torch.zeros(1, 12, 4, 4, device="cuda"), torch.zeros(1, 36, 4, 4, device="cuda"))
+    with pytest.raises(RuntimeError):
+        sgr.light_heads(torch.zeros(1, 36, 4, 4), torch.zeros(1, 12, 4, 4), torch.zeros(1, 36, 4, 4))

@@ -138,6 +138,29 @@ def test_light_objective_full_size_matches_unfused(sgr):
         assert torch.isfinite(g).all()
 
 
+def test_light_objective_cotangent_scaling_and_second_backward(sgr):
+    """The gradients exist before backward is called: a cotangent != 1 rescales them on the device, and a second
+    backward through the same node (retain_graph) returns fresh tensors."""
+    from oracle import sg_oracle as O
+    inp = {k: v.cuda() for k, v in O.synthetic_inputs(2, 16, 32, 8, 16, 12, 8, 16, seed=11, benign=True).items()}
+    for k in ("axis", "lamb", "weight"):
+        inp[k].requires_grad_(True)
+    layer = sgr.renderingLayer(imWidth=16, imHeight=8, envWidth=16, envHeight=8)
+    ind = torch.ones(2, 1, 1, 1, device="cuda")
+
+    def objective():
+        return sgr.light_objective(layer, inp["albedo"], inp["normal"], inp["rough"], inp["axis"], inp["lamb"], inp["weight"],
+                                   inp["im"], inp["seg"], inp["env_gt"], ind)[0]
+    leaves = [inp["axis"], inp["lamb"], inp["weight"]]
+    g1 = torch.autograd.grad(objective(), leaves)
+    obj = objective()
+    g3 = torch.autograd.grad(3.0 * obj, leaves, retain_graph=True)
+    g3 = [g.clone() for g in g3]
+    g5 = torch.autograd.grad(5.0 * obj, leaves)
+    for a, b, c in zip(g1, g3, g5):
+        assert torch.allclose(3.0 * a, b, rtol=1e-6, atol=0) and torch.allclose(5.0 * a, c, rtol=1e-6, atol=0)
+
+
 def test_light_objective_rejects_brdf_gradients(sgr):
     from oracle import sg_oracle as O
     inp = {k: v.cuda() for k, v in O.synthetic_inputs(1, 8, 16, 8, 16, 12, 8, 16, seed=3, benign=True).items()}

@@ -9,15 +9,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("fused", [True, False])
-def test_synthetic_trainlight_loop_descends_and_matches_oracle(fused):
+@pytest.mark.parametrize("fused,hip_heads", [(True, True), (False, False), (True, False)])
+def test_synthetic_trainlight_loop_descends_and_matches_oracle(fused, hip_heads):
     from conftest import ROOT
     sys.path.insert(0, os.path.join(ROOT, "examples"))
     import train_light_synthetic as T
     from oracle import sg_oracle as O
 
     bn, imH, imW, R, C, K = 2, 48, 64, 24, 32, 12
-    hist, _ = T.train(bn=bn, steps=6, imH=imH, imW=imW, R=R, C=C, K=K, verbose=False, fused=fused)
+    hist, _ = T.train(bn=bn, steps=6, imH=imH, imW=imW, R=R, C=C, K=K, verbose=False, fused=fused, hip_heads=hip_heads)
     assert all(torch.isfinite(torch.tensor(h)).all() for h in hist)
     assert hist[-1][0] < hist[0][0], hist                       # Adam makes progress on the objective
 

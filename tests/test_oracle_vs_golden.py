@@ -61,3 +61,26 @@ def test_tables_match_reference_bits(golden):
     w = O.premap(torch.from_numpy(z["in_weight"]))
     assert np.array_equal(lam.numpy(), z["ref32_lamb_tan"])
     assert np.array_equal(w.numpy(), z["ref32_weight_tan"])
+
+
+def test_oracle_light_heads_vs_reference_decoders():
+    """oracle.light_heads against the outputs and autograd gradients of the reference's decoderLight modules
+    (tests/golden/g4_heads.npz, made by oracle/make_golden_heads.py with a hook on dconvFinal)."""
+    import os
+    import numpy as np
+    import torch
+    from conftest import GOLDEN_DIR, rel_l2
+    from oracle import sg_oracle as O
+    z = np.load(os.path.join(GOLDEN_DIR, "g4_heads.npz"))
+    x = {k: torch.from_numpy(z["x_" + k]).double().requires_grad_(True) for k in ("axis", "lamb", "weight")}
+    a, l, w, packed = O.light_heads(x["axis"], x["lamb"], x["weight"])
+    outs = dict(axis=a, lamb=l, weight=w)
+    for k, y in outs.items():
+        assert (y.detach() - torch.from_numpy(z["y_" + k]).double()).abs().max().item() < 5e-7, k
+    K = a.shape[1]
+    assert torch.equal(packed[:, :3 * K], a.reshape(a.shape[0], 3 * K, *a.shape[3:])) and torch.equal(packed[:, 3 * K:4 * K], l)
+    assert torch.equal(packed[:, 4 * K:], w)
+    tot = sum((y * torch.from_numpy(z["ct_" + k]).double()).sum() for k, y in outs.items())
+    g = torch.autograd.grad(tot, [x["axis"], x["lamb"], x["weight"]])
+    for k, gi in zip(("axis", "lamb", "weight"), g):
+        assert rel_l2(gi, z["gx_" + k]) < 1e-6, (k, rel_l2(gi, z["gx_" + k]))
