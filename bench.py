@@ -198,11 +198,19 @@ def main() -> None:
         # the entry is matched by kernel family (the backward is sg_bwd_half_kernel / sg_bwd_split_kernel / sg_bwd_fast_kernel)
         traffic, dom_name = None, dom[0] + "_kernel"
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        # the headline kernels by template instance: backward with env cotangent + render cotangents
+        # (<.., true, true[, occ]>), forward with env output + render and no ground-truth statistics (<.., true, true, false>)
+        import re
+        want = ([r"sg_bwd_half_kernel<\d+, true, true, \d+>", r"sg_bwd_split_kernel<\d+, \d+, true, true>", r"sg_bwd_fast_kernel<.*true, true>"]
+                if dom[0] == "sg_bwd" else [r"fwd_fast_kernel<[\d, ]+true, true, false>", r"fwd_fast_kernel<[\d, ]+true, true>"])
         if os.path.isfile(tpath):
             try:
-                for name, rec in json.load(open(tpath)).items():
-                    if ("::" + dom[0]) in name:
-                        traffic, dom_name = rec["hbm_bytes"], name.split("::")[-1].split("<")[0]
+                recs = json.load(open(tpath))
+                for pat in want:
+                    hits = [n for n in recs if re.search("::" + pat + "$", n)]
+                    if hits:
+                        traffic, dom_name = recs[hits[0]]["hbm_bytes"], hits[0].split("::")[-1].split("<")[0]
+                        break
             except Exception:
                 traffic = None
         out = {

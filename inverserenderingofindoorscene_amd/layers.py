@@ -27,7 +27,7 @@ import torch.nn.functional as F
 
 from . import _lib, tables
 
-__all__ = ["light_heads", "output2env", "renderingLayer", "render_from_sg", "renderLayer", "output_radiance", "predToShading"]
+__all__ = ["light_heads", "unpack_envmaps", "output2env", "renderingLayer", "render_from_sg", "renderLayer", "output_radiance", "predToShading"]
 
 
 # --------------------------------------------------------------------------- #
@@ -448,6 +448,17 @@ def light_heads(xAxis, xLamb, xWeight, need_packed=False):
     if need_packed:
         return out
     return tuple(out) + (None,)
+
+
+def unpack_envmaps(envmapsPred, SGNum=12):
+    """Views ``(axis [bn,K,3,R,C], lamb [bn,K,R,C], weight [bn,3K,R,C])`` of the packed ``[bn,7K,R,C]`` light
+    prediction -- the cascade hand-off layout written by wrapperBRDFLight.py:167-168 / ``light_heads(need_packed=True)``
+    and read back as ``envmapsPreBatch`` by cascade 1 (models.py:229, dataLoader.py:277-283)."""
+    if envmapsPred.dim() != 4 or envmapsPred.shape[1] != 7 * SGNum:
+        raise RuntimeError(f"sgrender: envmapsPred must be [bn,{7 * SGNum},envRow,envCol], got {tuple(envmapsPred.shape)}")
+    bn, _, R, C = envmapsPred.shape
+    K = SGNum
+    return (envmapsPred[:, :3 * K].reshape(bn, K, 3, R, C), envmapsPred[:, 3 * K:4 * K], envmapsPred[:, 4 * K:])
 
 
 def predToShading(pred, envWidth=32, envHeight=16, SGNum=12):

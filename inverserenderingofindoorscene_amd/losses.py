@@ -323,6 +323,9 @@ def light_objective(renderLayer, albedoPred, normalPred, roughPred, axisPred, la
     ``axisPred, lambPred, weightPred`` are the raw decoder outputs (pre-tan), exactly what
     ``output2env.output2env`` takes.  Differentiable w.r.t. those three only.
 
+    Configurations without a fused kernel (envWidth != 16 or SGNum > 12, see :func:`light_objective_supported`)
+    are evaluated by the unfused HIP kernels (forwardSG + render_loss + recon_loss) with the same return values.
+
     Returns ``(objective, renderErr, reconstErr, renderedImPred, envScale)``; the two error terms are reported
     values (no gradient), ``envScale [bn]`` is the LSregress coefficient (``envmapsPredScaledImage =
     envScale * envmapsPredImage`` if the caller materialises the env for logging).  Under batch sharding the
@@ -332,7 +335,14 @@ def light_objective(renderLayer, albedoPred, normalPred, roughPred, axisPred, la
     bn, K, R, C = _check_sg(axisPred, lambPred, weightPred, None)
     impl._check_grid(R, C)
     if not light_objective_supported(K, R, C, impl.envHeight, impl.envWidth):
-        raise NotImplementedError("sgrender: light_objective needs envWidth 16 and SGNum <= 12; use forwardSG + render_loss + recon_loss")
+        # other direction grids / more than 12 lobes: same objective from the unfused HIP kernels (env image materialised)
+        env, diffuse, spec = impl.forwardSG(albedoPred, normalPred, roughPred, axisPred, lambPred, weightPred, need_env=True)
+        render_err, rendered = render_loss(diffuse, spec, imBatch, segBRDFBatch, R, C, group)
+        seg_s = segBRDFBatch if tuple(segBRDFBatch.shape[2:]) == (R, C) else F.adaptive_avg_pool2d(segBRDFBatch, (R, C))
+        num, den, coef = _ReconLossParts.apply(env, envmapsBatch, seg_s, envmapsIndBatch, offset)
+        recon_err = combine_loss_parts(num, den, group, divisor=3.0 * impl.envHeight * impl.envWidth)
+        objective = float(renderWeight) * render_err + float(reconWeight) * recon_err
+        return objective, render_err.detach(), recon_err.detach(), rendered, coef
     a, n, r = _prepool(albedoPred, normalPred, roughPred, R, C)
     im, seg = imBatch, segBRDFBatch
     h, w = im.shape[2], im.shape[3]

@@ -33,6 +33,8 @@ def test_light_heads_vs_reference_decoders(sgr):
     K = a.shape[1]
     assert torch.equal(packed[:, :3 * K], a.reshape(a.shape[0], 3 * K, *a.shape[3:]))
     assert torch.equal(packed[:, 3 * K:4 * K], l) and torch.equal(packed[:, 4 * K:], w)
+    a2, l2, w2 = sgr.unpack_envmaps(packed.detach(), K)        # cascade hand-off layout, wrapperBRDFLight.py:167-168
+    assert torch.equal(a2, a) and torch.equal(l2, l) and torch.equal(w2, w)
     tot = sum((y * torch.from_numpy(z["ct_" + k]).cuda()).sum() for k, y in outs.items())
     g = torch.autograd.grad(tot, [x["axis"], x["lamb"], x["weight"]])
     for k, gi in zip(("axis", "lamb", "weight"), g):

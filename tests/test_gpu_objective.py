@@ -48,10 +48,8 @@ def test_light_objective_vs_golden(sgr, golden):
     ind = torch.ones(cfg["bn"], 1, 1, 1, device="cuda")
     args = (layer, x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], _t(z, "in_im"), _t(z, "in_seg"),
             _t(z, "in_env_gt"), ind)
-    if not sgr.light_objective_supported(cfg["K"], R, C, cfg["eh"], cfg["ew"]):
-        with pytest.raises(NotImplementedError):
-            sgr.light_objective(*args, 1.0, 10.0)
-        return
+    # g2 (4x8 directions) has no fused kernel: light_objective evaluates it with the unfused HIP kernels
+    assert sgr.light_objective_supported(cfg["K"], R, C, cfg["eh"], cfg["ew"]) == (cfg["ew"] == 16 and cfg["K"] <= 12)
     obj, rerr, cerr, ren, coef = sgr.light_objective(*args, 1.0, 10.0)
     r_ref, c_ref = float(z["ref32_render_err"][0]), float(z["ref32_recon_err"][0])
     assert abs(rerr.item() - r_ref) < 1e-4 * max(1.0, r_ref), (name, rerr.item(), r_ref)

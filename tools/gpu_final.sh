@@ -12,4 +12,8 @@ echo "== bench torchrun world=1 (RCCL init / barrier / all-reduce path)"; timeou
 echo "== rocprof"; cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/rocprof.txt 2>&1; cd $GRAFT_REPO_ROOT
 for f in $(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); do cp $f gpurun_out/kernel_stats.csv; head -14 $f; done
 echo "== pmc traffic"; bash tools/pmc_traffic.sh
-echo "== trainlight example"; timeout 300 python examples/train_light_synthetic.py --batch 16 --steps 23 2>&1 | tail -2
+echo "== trainlight example (fused objective + HIP heads | unfused + torch heads)"
+timeout 300 python examples/train_light_synthetic.py --batch 16 --steps 23 2>&1 | tail -1 | tee gpurun_out/trainlight_fused.txt
+timeout 300 python examples/train_light_synthetic.py --batch 16 --steps 23 --unfused --torch-heads 2>&1 | tail -1 | tee gpurun_out/trainlight_unfused.txt
+echo "== config 5"; timeout 600 python bench.py --config 5 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/bench_config5.txt 2>&1; tail -1 gpurun_out/bench_config5.txt | cut -c1-200
+echo "== issue-cost microbenchmarks"; timeout 120 ./tools/ubench3 > gpurun_out/ubench3.txt 2>&1; timeout 120 ./tools/ubench4 > gpurun_out/ubench4.txt 2>&1; tail -3 gpurun_out/ubench4.txt
