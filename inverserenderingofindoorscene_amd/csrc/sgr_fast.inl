@@ -310,6 +310,178 @@ __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
   }
 }
 
+// ============================== forward, half-wave lobe split =====================================
+// One wave = 32 pixels x 2 lobe groups (lanes l and l+32 own the same pixel; lobes 0..5 / 6..11), like the
+// half-wave backward.  Each half accumulates its six lobes' share of all 8 directions of an azimuth quad;
+// swap(D = share of half row 1, S = share of half row 0); D + S gives lanes 0..31 the radiance of half row 1 and
+// lanes 32..63 that of half row 0, so each half then shades / stores / takes statistics for 4 of the 8 directions.
+// Same arithmetic per pixel as fwd_fast_kernel plus 12 swaps + 12 adds per quad, but the work unit is half as long
+// (9600 instead of 4800 waves at config 2: half the ramp/tail) and the register footprint allows 3 waves per SIMD.
+template <int POOL, bool WRITE_ENV, bool DO_RENDER, int OCC>
+__global__ __launch_bounds__(kWave, OCC) void fwd_half_kernel(const Args a) {
+  constexpr int EW = 16, HALF = 8, NQ = 2, KPW = 6;
+  __shared__ __attribute__((aligned(16))) float tile[WRITE_ENV ? kT32OutFloats : 4];
+
+  const int lane = threadIdx.x, half = lane >> 5, pl = lane & 31;
+  const int own = 1 - half;                         // the half row (sign) whose totals this half-wave ends up holding
+  const int RC = a.R * a.C, K = a.K;
+  Pix x;
+  x.lane = lane;
+  {
+    const int tiles = (RC + kPx - 1) / kPx;
+    x.b = blockIdx.x / tiles;
+    x.p0 = (blockIdx.x - x.b * tiles) * kPx;
+    x.active = (x.p0 + pl) < RC;
+    x.p = x.active ? (x.p0 + pl) : (RC - 1);
+  }
+  const int b = x.b, p = x.p;
+
+  // this half's lobes, folded (axis pre-multiplied by lam * log2e)
+  Lobes<KPW> L;
+  {
+    const float* axis_b = a.axis + (size_t)b * K * 3 * RC;
+    const float* lamb_b = a.lamb + (size_t)b * K * RC;
+    const float* weight_b = a.weight + (size_t)b * K * 3 * RC;
+#pragma unroll
+    for (int k = 0; k < KPW; ++k) {
+      const int kc = min(half * KPW + k, K - 1);
+      const unsigned o3 = (unsigned)(kc * 3 * RC + p), o1 = (unsigned)(kc * RC + p);
+      L.ax[k] = axis_b[o3]; L.ay[k] = axis_b[o3 + RC]; L.az[k] = axis_b[o3 + 2 * RC];
+      L.lp[k] = lamb_b[o1];
+      L.w0[k] = weight_b[o3]; L.w1[k] = weight_b[o3 + RC]; L.w2[k] = weight_b[o3 + 2 * RC];
+    }
+#pragma unroll
+    for (int k = 0; k < KPW; ++k) {
+      const int kk = half * KPW + k;
+      const bool live = kk < K;
+      float l = L.lp[k], t0 = L.w0[k], t1 = L.w1[k], t2 = L.w2[k];
+      if (a.premap) {
+        l = premap(l); t0 = premap(t0); t1 = premap(t1); t2 = premap(t2);
+        if (live && x.active) {
+          const unsigned o3 = (unsigned)(kk * 3 * RC + p), o1 = (unsigned)(kk * RC + p);
+          if (a.lamb_tan) (a.lamb_tan + (size_t)b * K * RC)[o1] = l;
+          if (a.weight_tan) {
+            float* wt_b = a.weight_tan + (size_t)b * K * 3 * RC;
+            wt_b[o3] = t0; wt_b[o3 + RC] = t1; wt_b[o3 + 2 * RC] = t2;
+          }
+        }
+      }
+      const float lp = l * kLog2e;
+      L.lp[k] = lp;
+      L.ax[k] *= lp; L.ay[k] *= lp; L.az[k] *= lp;
+      L.w0[k] = live ? t0 : 0.0f; L.w1[k] = live ? t1 : 0.0f; L.w2[k] = live ? t2 : 0.0f;
+    }
+  }
+
+  PixLocal q;
+  float alb[3] = {0.f, 0.f, 0.f};
+  bool ortho = true;
+  if (DO_RENDER) {
+    const Frame f = load_frame<POOL>(a, x, alb);
+    q = make_local(f, a.F0);
+    ortho = __all(frame_is_orthonormal(q));
+  }
+  float d0 = 0.f, d1 = 0.f, d2 = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  const SepTable rows = as_sep_table(a.rows);
+  const SepTable cst = as_sep_table(a.cols);                                   // [(EW/2)/4] x 4 x (ca, sa)
+  const XTable xt = (XTable)(a.cols + EW);
+  const size_t img = (size_t)b * 3 * RC * a.J;
+  const int eh = a.eh;
+
+  auto row_loop = [&](auto ortho_c) {
+    for (int e = 0; e < eh; ++e) {
+#pragma unroll
+      for (int k = 0; k < KPW; ++k) { asm volatile("" : "+v"(L.ax[k])); asm volatile("" : "+v"(L.ay[k])); }   // no LICM of U_ka
+      if (DO_RENDER) fence_row_invariants(q);
+      const f32x8 row = rows[e];
+      const float sr = row[0];
+      float Ck[KPW];
+#pragma unroll
+      for (int k = 0; k < KPW; ++k) Ck[k] = fmaf(L.az[k], row[1], -L.lp[k]);
+      const RowCtx rc = make_row_ctx(q, row, DO_RENDER);
+#pragma unroll 1
+      for (int aq = 0; aq < NQ; ++aq) {
+        const f32x8 cs = cst[aq];
+        float acc[2][3][4];
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[sg][c][i] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float ca = cs[2 * i], sa = cs[2 * i + 1];
+#pragma unroll
+          for (int k = 0; k < KPW; ++k) {
+            const float U = fmaf(L.ay[k], sa, L.ax[k] * ca);
+            const float ep = fexp2(fmaf(sr, U, Ck[k]));
+            const float em = fexp2(fmaf(-sr, U, Ck[k]));
+            acc[0][0][i] = fmaf(L.w0[k], ep, acc[0][0][i]);
+            acc[0][1][i] = fmaf(L.w1[k], ep, acc[0][1][i]);
+            acc[0][2][i] = fmaf(L.w2[k], ep, acc[0][2][i]);
+            acc[1][0][i] = fmaf(L.w0[k], em, acc[1][0][i]);
+            acc[1][1][i] = fmaf(L.w1[k], em, acc[1][1][i]);
+            acc[1][2][i] = fmaf(L.w2[k], em, acc[1][2][i]);
+          }
+        }
+        // radiance of the half row this half-wave owns
+        float tot[3][4];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float d_ = acc[1][c][i], s_ = acc[0][c][i];
+            swap32(d_, s_);
+            tot[c][i] = d_ + s_;
+          }
+        if (DO_RENDER) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float wt, sp;
+            shade_dir<decltype(ortho_c)::value>(q, rc, own, cs[2 * i], cs[2 * i + 1], xt, aq * 4 + i, wt, sp);
+            const float sw = sp * wt;
+            d0 = fmaf(wt, tot[0][i], d0);
+            d1 = fmaf(wt, tot[1][i], d1);
+            d2 = fmaf(wt, tot[2][i], d2);
+            s0 = fmaf(sw, tot[0][i], s0);
+            s1 = fmaf(sw, tot[1][i], s1);
+            s2 = fmaf(sw, tot[2][i], s2);
+          }
+        }
+        if (WRITE_ENV) tile32_write4(tile, pl, own * HALF + aq * 4, tot[0], tot[1], tot[2]);
+      }
+      if (WRITE_ENV) {
+        __syncthreads();
+        tile32_store_global(tile, a.env_out + img, x.p0, RC, a.J, e * EW, lane);
+        __syncthreads();
+      }
+    }
+  };
+  if (ortho) row_loop(std::true_type{}); else row_loop(std::false_type{});
+
+  if (DO_RENDER) {
+    // each half integrated one half row: add the two
+    float v[6] = {d0, d1, d2, s0, s1, s2};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      float d_ = v[i], s_ = v[i];
+      swap32(d_, s_);
+      v[i] = d_ + s_;
+    }
+    if (x.active && half == 0) {
+      const size_t o = (size_t)b * 3 * RC;
+      const unsigned up = (unsigned)p;
+      (a.diffuse + o)[up] = (alb[0] * kInvPi) * v[0];
+      (a.diffuse + o + RC)[up] = (alb[1] * kInvPi) * v[1];
+      (a.diffuse + o + 2 * (size_t)RC)[up] = (alb[2] * kInvPi) * v[2];
+      (a.spec + o)[up] = v[3];
+      (a.spec + o + RC)[up] = v[4];
+      (a.spec + o + 2 * (size_t)RC)[up] = v[5];
+    }
+  }
+}
+
 // ============================== backward w.r.t. the SG parameters ================================
 // g[c,j] = gEnv[c,j] (+) omega_j ndl_j (gD_c A_c/pi + gS_c spec_j);  per lobe, with T = (g . w) E:
 //   dL/dw_c = sum g_c E,   dL/dlam = sum T t,   dL/da = lam (ca A, sa A, sum T c_e),  A_a = sum_e (+-s_e) T

@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include "sgr_common.h"
 #include "sgr_launch.h"
+#include <string.h>
 #include "sgr_fast.inl"
 
 #ifndef SGR_TJ
@@ -163,8 +164,34 @@ static inline int fwd_tile_width() {
   static const int tj = [] { const char* e = getenv("SGR_FWD_TJ"); return (e && atoi(e) == 32) ? 32 : 16; }();   // 16 measured faster
   return tj;
 }
+// lobes split over the two halves of a wave (envWidth 16, 6 < SGNum <= 12); SGR_FWD_MODE = full | half2 | half3
+template <bool WRITE_ENV, bool DO_RENDER, int OCC>
+static int fwd_half_launch(const Args& a, hipStream_t st) {
+  const dim3 grid((unsigned)(a.bn * ((a.R * a.C + kPx - 1) / kPx))), block(kWave);
+  if (!DO_RENDER || (a.imH == a.R && a.imW == a.C))
+    hipLaunchKernelGGL((fwd_half_kernel<1, WRITE_ENV, DO_RENDER, OCC>), grid, block, 0, st, a);
+  else
+    hipLaunchKernelGGL((fwd_half_kernel<2, WRITE_ENV, DO_RENDER, OCC>), grid, block, 0, st, a);
+  return (int)hipGetLastError();
+}
+static inline int fwd_mode() {     // 0 one pixel per lane, 2 / 3 half-wave kernel built for that many waves per SIMD, -1 default
+  static const int mode = [] {
+    const char* e = getenv("SGR_FWD_MODE");
+    if (e && !strcmp(e, "full")) return 0;
+    if (e && !strcmp(e, "half2")) return 2;
+    if (e && !strcmp(e, "half3")) return 3;
+    return -1;
+  }();
+  return mode;
+}
 template <bool WRITE_ENV, bool DO_RENDER>
 static int fwd_fast_launch(const Args& a, hipStream_t st) {
+  // measured at config 2 (full / half2 us, two sessions): env only 178 / 149 (both); env + render 223 / 209 and 214 / 219
+  // (a wash: both halves of a wave pay for the pixel's frame and row context); render only 165 / 175
+  // -> half-wave by default only for the SG -> env image call (output2env.output2env)
+  const int mode = fwd_mode() >= 0 ? fwd_mode() : ((WRITE_ENV && !DO_RENDER) ? 2 : 0);
+  if (a.ew == 16 && a.K > 6 && a.K <= 12 && mode != 0)
+    return mode == 3 ? fwd_half_launch<WRITE_ENV, DO_RENDER, 3>(a, st) : fwd_half_launch<WRITE_ENV, DO_RENDER, 2>(a, st);
   if (a.ew == 16) {
     if (WRITE_ENV && fwd_tile_width() == 16) {
       if (a.K <= 6) return fwd_fast_launch_pool<6, 16, 16, WRITE_ENV, DO_RENDER>(a, st);

@@ -1,0 +1,35 @@
+"""GPU: the kernels that are NOT the default dispatch for the fixtures' shapes, selected through the library's tuning
+knobs (read once per process, hence the subprocesses), must pass the same golden-fixture parity tests:
+
+  SGR_BWD_MODE=split              two-wave lobe-split backward (sg_bwd_split_kernel)
+  SGR_FWD_MODE/SGR_BWD_MODE=half2 half-wave forward for every forward variant, half-wave backward built for 2 waves/SIMD
+  SGR_FWD_MODE=full               one-pixel-per-lane forward also for the SG -> env call
+  SGR_GENERIC=1                   generic kernels (table-driven, any direction grid) on the reference's grid
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SUBSET = "golden or trainlight or full_size_backward"
+
+
+@pytest.mark.parametrize("env", [
+    {"SGR_BWD_MODE": "split"},
+    {"SGR_FWD_MODE": "half2", "SGR_BWD_MODE": "half2"},
+    {"SGR_FWD_MODE": "full"},
+    {"SGR_GENERIC": "1"},
+], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
+@pytest.mark.timeout(600)
+def test_alternative_kernels_pass_golden_parity(env):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-m", "gpu", "-x",
+                        "-k", SUBSET, "-p", "no:cacheprovider"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=580)
+    tail = (r.stdout or "")[-1500:] + (r.stderr or "")[-500:]
+    assert r.returncode == 0, tail
+    assert " passed" in r.stdout and "failed" not in r.stdout, tail
