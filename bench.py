@@ -245,10 +245,47 @@ def main() -> None:
         }
         if world == 1 and not args.no_cpu_baseline and args.config == 2:
             out["cpu_baseline"] = cpu_baseline(O, 240, 320, 120, 160, 12, 8, 16) if args.config == 2 else None
+            try:
+                out["eager_gpu_baseline"] = eager_gpu_baseline(O, dev, 240, 320, 120, 160, 12, 8, 16)
+            except Exception as exc:       # informational leg: never fail the bench over it
+                out["eager_gpu_baseline"] = {"error": str(exc)[:200]}
         print(json.dumps(out), flush=True)
 
     if world > 1:
         dist.destroy_process_group()
+
+
+def eager_gpu_baseline(O, dev, imH, imW, R, C, K, eh, ew) -> dict:
+    """The torch port of the reference algorithm in the reference's own tensor formulation (whole-batch broadcast
+    temporaries, oracle.render_from_sg_broadcast) run eagerly ON THE GPU through PyTorch-ROCm's aten kernels: the
+    GPU-vs-GPU baseline BASELINE.md asks for (the reference itself cannot travel to the GPU box).  Bounded sample:
+    four images, forward + backward (SG grads), best of 3."""
+    n = 4
+    inp = O.synthetic_inputs(n, imH, imW, R, C, K, eh, ew, seed=20202)
+    names = ("albedo", "normal", "rough", "axis", "lamb", "weight")
+    x = {k: inp[k].to(dev) for k in names}
+    for k in ("axis", "lamb", "weight"):
+        x[k].requires_grad_(True)
+    g = torch.Generator().manual_seed(99)
+    cts = [(torch.randn((n, 3, R, C, eh, ew), generator=g) * 1e-3).to(dev), torch.randn((n, 3, R, C), generator=g).to(dev),
+           torch.randn((n, 3, R, C), generator=g).to(dev)]
+
+    def one():
+        env, d, s = O.render_from_sg_broadcast(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], eh, ew)
+        torch.autograd.grad([env, d, s], [x["axis"], x["lamb"], x["weight"]], grad_outputs=cts)
+        torch.cuda.synchronize()
+
+    one()
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        one()
+        times.append(time.perf_counter() - t0)
+    best = min(times)
+    return {"value": round(n * imH * imW / best / 1e6, 2), "unit": "Mpix/s", "kind": "port",
+            "sample": f"{n} images of the same workload, fwd+bwd (SG grads), eager PyTorch-ROCm on this GPU running the torch port "
+                      f"of the reference algorithm in its broadcast formulation (oracle.render_from_sg_broadcast), best of 3; "
+                      f"{best / n * 1e3:.2f} ms per image"}
 
 
 def cpu_baseline(O, imH, imW, R, C, K, eh, ew) -> dict:

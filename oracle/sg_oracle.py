@@ -51,6 +51,7 @@ __all__ = [
     "render_from_sg",
     "lsregress",
     "lsregress_diffspec",
+    "render_from_sg_broadcast",
     "render_loss",
     "recon_loss",
 ]
@@ -118,7 +119,7 @@ def sg_to_env(axis: torch.Tensor, lamb: torch.Tensor, weight: torch.Tensor,
     """
     bn, K, _, R, C = axis.shape
     ls_np, _ = direction_table(env_height, env_width)
-    ls = torch.from_numpy(ls_np).to(axis.dtype)            # [J,3]
+    ls = torch.from_numpy(ls_np).to(device=axis.device, dtype=axis.dtype)   # [J,3]
     J = ls.shape[0]
     w = weight.reshape(bn, K, 3, R * C)
     lam = lamb.reshape(bn, K, R * C)
@@ -181,13 +182,14 @@ def render_env(albedo, normal, rough, env, fov_deg: float = 57.0, F0: float = 0.
     bn, _, R, C, eh, ew = env.shape
     dt = env.dtype
     ls_np, om_np = direction_table(eh, ew)
-    ls = torch.from_numpy(ls_np).to(dt)                      # [J,3]
-    om = torch.from_numpy(om_np).to(dt)                      # [J]
-    v = torch.from_numpy(view_vectors(C, R, fov_deg, camera_pos)).to(dt)[None]   # [1,3,R,C]
+    dev = env.device
+    ls = torch.from_numpy(ls_np).to(device=dev, dtype=dt)   # [J,3]
+    om = torch.from_numpy(om_np).to(device=dev, dtype=dt)   # [J]
+    v = torch.from_numpy(view_vectors(C, R, fov_deg, camera_pos)).to(device=dev, dtype=dt)[None]   # [1,3,R,C]
     J = eh * ew
 
     A, N, rho = pool_brdf(albedo, normal, rough, R, C)
-    up = torch.zeros(1, 3, 1, 1, dtype=dt)
+    up = torch.zeros(1, 3, 1, 1, dtype=dt, device=dev)
     up[0, 1] = 1.0
     camy = _unit(up - (up * N).sum(1, keepdim=True) * N)
     camx = -_unit(torch.cross(camy, N, dim=1))
@@ -199,8 +201,8 @@ def render_env(albedo, normal, rough, env, fov_deg: float = 57.0, F0: float = 0.
     ndv = torch.clamp((N * v).sum(1, keepdim=True), 0.0, 1.0)
 
     envf = env.reshape(bn, 3, R, C, J)
-    diff = torch.zeros(bn, 3, R, C, dtype=dt)
-    spec = torch.zeros(bn, 3, R, C, dtype=dt)
+    diff = torch.zeros(bn, 3, R, C, dtype=dt, device=dev)
+    spec = torch.zeros(bn, 3, R, C, dtype=dt, device=dev)
     for j in range(J):
         l = ls[j, 0] * camx + ls[j, 1] * camy + ls[j, 2] * N             # [bn,3,R,C]
         h = (v + l) / 2.0
@@ -227,6 +229,55 @@ def render_from_sg(albedo, normal, rough, axis_orig, lamb_orig, weight_orig,
     env, _, _, _ = output2env(axis_orig, lamb_orig, weight_orig, env_height, env_width)
     d, s = render_env(albedo, normal, rough, env, fov_deg, F0, camera_pos)
     return env, d, s
+
+
+def render_from_sg_broadcast(albedo, normal, rough, axis_orig, lamb_orig, weight_orig,
+                             env_height: int = 8, env_width: int = 16, fov_deg: float = 57.0, F0: float = 0.05,
+                             camera_pos: Sequence[float] = (0.0, 0.0, 0.0)):
+    """Same result as :func:`render_from_sg`, evaluated the way the reference evaluates it: whole-batch
+    broadcast temporaries of shape ``[bn,K,3,R,C,eh,ew]`` (models.py:371-389) and ``[bn,J,{1,3},R,C]``
+    (models.py:461-522) instead of loops over lobes / directions.  Memory-hungry (354 MB per image per
+    temporary at the reference sizes); exists so that the eager-GPU baseline of ``bench.py`` has the
+    reference's kernel-count and traffic profile.  Checked against the looped oracle in the CPU tests."""
+    bn, K, _, R, C = axis_orig.shape
+    eh, ew, J = env_height, env_width, env_height * env_width
+    dt, dev = axis_orig.dtype, axis_orig.device
+    ls_np, om_np = direction_table(eh, ew)
+    ls = torch.from_numpy(ls_np).to(device=dev, dtype=dt)                      # [J,3]
+    om = torch.from_numpy(om_np).to(device=dev, dtype=dt)                      # [J]
+    lam = premap(lamb_orig)
+    wgt = premap(weight_orig).view(bn, K, 3, R, C)
+    lsg = ls.t().reshape(1, 1, 3, 1, 1, eh, ew)
+    dot = (axis_orig[..., None, None] * lsg).sum(dim=2)                        # [bn,K,R,C,eh,ew]
+    mi = torch.exp(lam[..., None, None] * (dot - 1.0))                         # [bn,K,R,C,eh,ew]
+    env = (wgt[..., None, None] * mi[:, :, None]).sum(dim=1)                   # [bn,3,R,C,eh,ew]
+
+    v = torch.from_numpy(view_vectors(C, R, fov_deg, camera_pos)).to(device=dev, dtype=dt)[None, None]   # [1,1,3,R,C]
+    A, N, rho = pool_brdf(albedo, normal, rough, R, C)
+    up = torch.zeros(1, 3, 1, 1, dtype=dt, device=dev)
+    up[0, 1] = 1.0
+    camy = _unit(up - (up * N).sum(1, keepdim=True) * N)
+    camx = -_unit(torch.cross(camy, N, dim=1))
+    lj = ls.view(1, J, 3, 1, 1)
+    l = lj[:, :, 0:1] * camx[:, None] + lj[:, :, 1:2] * camy[:, None] + lj[:, :, 2:3] * N[:, None]      # [bn,J,3,R,C]
+    h = (v + l) / 2.0
+    h = h / torch.sqrt(torch.clamp((h * h).sum(2, keepdim=True), min=1e-6))
+    vdh = (v * h).sum(2, keepdim=True)                                                                  # [bn,J,1,R,C]
+    fres = F0 + (1.0 - F0) * torch.pow(torch.full_like(vdh, 2.0), (-5.55472 * vdh - 6.98316) * vdh)
+    r = (rho + 1.0) / 2.0
+    kk = ((r + 1.0) * (r + 1.0) / 8.0)[:, None]
+    alpha2 = ((r * r) * (r * r))[:, None]
+    ndv = torch.clamp((N[:, None] * v).sum(2, keepdim=True), 0.0, 1.0)
+    ndh = torch.clamp((N[:, None] * h).sum(2, keepdim=True), 0.0, 1.0)
+    ndl = torch.clamp((N[:, None] * l).sum(2, keepdim=True), 0.0, 1.0)
+    nom0 = ndh * ndh * (alpha2 - 1.0) + 1.0
+    nom = torch.clamp(4.0 * math.pi * nom0 * nom0 * (ndv * (1.0 - kk) + kk) * (ndl * (1.0 - kk) + kk), 1e-6, 4.0 * math.pi)
+    sp = alpha2 * fres / nom                                                                              # [bn,J,1,R,C]
+    envp = env.reshape(bn, 3, R, C, J).permute(0, 4, 1, 2, 3)                                            # [bn,J,3,R,C]
+    w = om.view(1, J, 1, 1, 1)
+    diff = ((A / math.pi)[:, None] * ndl * envp * w).sum(1)
+    spec = (sp * ndl * envp * w).sum(1)
+    return env, diff, spec
 
 
 # --------------------------------------------------------------------------- #

@@ -84,3 +84,22 @@ def test_oracle_light_heads_vs_reference_decoders():
     g = torch.autograd.grad(tot, [x["axis"], x["lamb"], x["weight"]])
     for k, gi in zip(("axis", "lamb", "weight"), g):
         assert rel_l2(gi, z["gx_" + k]) < 1e-6, (k, rel_l2(gi, z["gx_" + k]))
+
+
+def test_broadcast_restatement_matches_looped_oracle():
+    """render_from_sg_broadcast (the reference's tensor formulation, used by bench.py's eager-GPU baseline)
+    against the looped oracle, values and SG gradients, fp64."""
+    import torch
+    from conftest import rel_l2
+    from oracle import sg_oracle as O
+    inp = O.synthetic_inputs(2, 12, 16, 6, 8, 5, 4, 8, seed=9, dtype=torch.float64)
+    outs = []
+    for fn in (O.render_from_sg, O.render_from_sg_broadcast):
+        x = {k: inp[k].clone() for k in ("albedo", "normal", "rough", "axis", "lamb", "weight")}
+        for k in ("axis", "lamb", "weight"):
+            x[k].requires_grad_(True)
+        env, d, s = fn(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], 4, 8)
+        g = torch.autograd.grad((env * 0.01).sum() + (d * d).sum() + (s * 3).sum(), [x["axis"], x["lamb"], x["weight"]])
+        outs.append((env, d, s) + tuple(g))
+    for a, b in zip(*outs):
+        assert rel_l2(a.detach(), b.detach()) < 1e-12
