@@ -275,48 +275,6 @@ __device__ __forceinline__ void tile_dma_issue_part(float* tile, __amdgpu_buffer
     }
   }
 }
-// "Quad" tile for EW = 16: the 4 + 4 directions (j0..j0+3 and j0+8..j0+11: one azimuth quad of both half
-// rows) of 64 pixels x 3 colours -- 6 KB, 6 DMA instructions -- for consumers that walk a table row one
-// azimuth quad at a time; double-buffered it costs 12 KB of LDS instead of the 24 KB of whole rows.
-// Layout DmaTile<8> (two 16-byte slots per pixel row, slot s <-> half row s, XOR-swizzled).
-__device__ __forceinline__ void tile_dma_issue_quad(float* tile, __amdgpu_buffer_rsrc_t rsrc, int p0, int RC, int J, int j0, int lane) {
-  using D = DmaTile<8>;
-  const int lrow = lane / D::kSlots, slot = lane % D::kSlots;
-#pragma unroll
-  for (int it = 0; it < D::kInstrPerColour; ++it) {
-    const int row = it * D::kRowsPerInstr + lrow;
-    const int half = slot ^ D::swz(row);
-    const int voff = (row * J + half * 8) * 4;                           // the lane's byte offset (32-bit)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const int soff = (int)((((size_t)c * RC + p0) * J + j0) * 4);      // wave-uniform byte offset
-      float* dst = tile + (c * kWave + it * D::kRowsPerInstr) * 8;       // wave-uniform, + lane*16 B implicitly
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)dst, 16, voff, soff, 0, 0);
-    }
-  }
-}
-// the lane's own pixel: g[half row][colour][azimuth in quad]   (inline asm for the reason given above)
-__device__ __forceinline__ void tile_quad_read(const float* tile, int lane, float (&g)[2][3][4]) {
-  using D = DmaTile<8>;
-  const unsigned rowb = lds_addr(tile) + (unsigned)(lane * 8 * 4);
-  const unsigned a0 = rowb + (unsigned)((0 ^ D::swz(lane)) * 16);
-  const unsigned a1 = rowb + (unsigned)((1 ^ D::swz(lane)) * 16);
-  f32x4 r[2][3];
-  asm volatile("ds_read_b128 %0, %1" : "=v"(r[0][0]) : "v"(a0) : "memory");
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r[0][1]) : "v"(a0), "n"(1 * kWave * 8 * 4) : "memory");
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r[0][2]) : "v"(a0), "n"(2 * kWave * 8 * 4) : "memory");
-  asm volatile("ds_read_b128 %0, %1" : "=v"(r[1][0]) : "v"(a1) : "memory");
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r[1][1]) : "v"(a1), "n"(1 * kWave * 8 * 4) : "memory");
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r[1][2]) : "v"(a1), "n"(2 * kWave * 8 * 4) : "memory");
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int sg = 0; sg < 2; ++sg)
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) g[sg][c][i] = r[sg][c][i];
-}
 // workgroup barrier that does NOT drain outstanding LDS-DMA (unlike __syncthreads): LDS ops only
 __device__ __forceinline__ void barrier_lds_only() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -110,7 +110,9 @@ __device__ __forceinline__ void shade_dir(const PixLocal& q, const RowCtx& rc, i
 
 // ============================== forward ==========================================================
 //
-// HAS_GT (fused objective, no env image): the ground-truth env rows stream in by double-buffered LDS-DMA
+// HAS_GT (fused objective, no env image): the ground-truth env rows stream in by LDS-DMA (one 12 KB tile; row
+// e+1 is requested the moment row e's last quad is in registers and has a quad's worth of arithmetic to land --
+// whole 64-byte segments, where 16-byte quad tiles made L2 fetch every segment twice: 219 -> 201 us)
 // and every lane accumulates <pred, gt>, <pred, pred> and sum(gt) of its pixel on the fly -- the statistics
 // behind the env mask and the LSregress scale (wrapperBRDFLight.py:172-176, models.py:7-21) -- so the
 // predicted env never goes to memory.  Per-wave partials land in a.ws[(b*tiles + tile)*3 + {0,1,2}].
@@ -122,8 +124,8 @@ __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
   constexpr int HALF = EW / 2;
   constexpr int NQ = HALF / 4;      // azimuth quads per half row
   __shared__ __attribute__((aligned(16))) float tile[WRITE_ENV ? Tile<TJ>::kFloats : 4];
-  using GD = DmaTile<8>;           // ground-truth env, one azimuth quad of both half rows at a time
-  __shared__ __attribute__((aligned(16))) float gtile[HAS_GT ? 3 * GD::kFloats : 4];
+  using GD = DmaTile<16>;          // ground-truth env, one whole table row (64-byte segments), single buffer
+  __shared__ __attribute__((aligned(16))) float gtile[HAS_GT ? GD::kFloats : 4];
 
   const Pix x = locate(a);
   const int lane = x.lane, b = x.b, p = x.p;
@@ -148,11 +150,7 @@ __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
   const int ehp = RPC == 2 ? ((a.eh + 1) & ~1) : a.eh;
   float s_pg = 0.f, s_pp = 0.f, s_g = 0.f;
   __amdgpu_buffer_rsrc_t gimg = env_rsrc(HAS_GT ? a.env_gt + img : a.view, RC, a.J);
-  if (HAS_GT) {      // two quads ahead (three buffers)
-    tile_dma_issue_quad(gtile, gimg, x.p0, RC, a.J, 0, lane);
-    tile_dma_issue_quad(gtile + GD::kFloats, gimg, x.p0, RC, a.J, 4, lane);
-  }
-  unsigned gpar = 0;
+  if (HAS_GT) tile_dma_issue<16>(gtile, gimg, x.p0, RC, a.J, 0, lane);
 
   // the wave-uniform frame test is hoisted out of the direction loops: two copies of the row loop
   auto row_loop = [&](auto ortho_c) {
@@ -223,32 +221,26 @@ __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
   #endif
         }
         if (HAS_GT) {
-          // the ground truth of the quad after next goes in flight (third buffer) while this one is consumed
-          const float* gcur = gtile + gpar * GD::kFloats;
-          const int lin = (e0 * NQ + aq) + 2, ne = lin / NQ, nq = lin - ne * NQ;
-          const unsigned nbuf = gpar >= 1u ? gpar - 1u : 2u;       // (gpar + 2) % 3
-          if (ne < ehp) {
-            tile_dma_issue_quad(gtile + nbuf * GD::kFloats, gimg, x.p0, RC, a.J, ne * EW + nq * 4, lane);
-            wait_vmcnt<2 * GD::kInstr>();
-          } else if (lin - 1 < ehp * NQ) {
-            wait_vmcnt<GD::kInstr>();
-          } else {
-            wait_vmcnt<0>();
+          // whole rows in a single 12 KB tile: the row was requested when the previous row's last quad had been read
+          // (a quad's worth of arithmetic ago); the next row is requested as soon as this row's last quad is in registers
+          if (aq == 0) wait_vmcnt<0>();
+  #pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            float g[2][3][2];
+            tile_dma_read_pairs<16>(gtile, lane, aq * 4 + 2 * h, HALF + aq * 4 + 2 * h, g);
+            if (h == 1 && aq == NQ - 1 && e0 + 1 < ehp) tile_dma_issue<16>(gtile, gimg, x.p0, RC, a.J, (e0 + 1) * EW, lane);
+  #pragma unroll
+            for (int sg = 0; sg < 2; ++sg)
+  #pragma unroll
+              for (int c = 0; c < 3; ++c)
+  #pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                  const float pv = acc[0][sg][c][2 * h + i], gv = g[sg][c][i];
+                  s_pg = fmaf(pv, gv, s_pg);
+                  s_pp = fmaf(pv, pv, s_pp);
+                  s_g += gv;
+                }
           }
-          gpar = gpar == 2u ? 0u : gpar + 1u;
-          float g[2][3][4];
-          tile_quad_read(gcur, lane, g);
-  #pragma unroll
-          for (int sg = 0; sg < 2; ++sg)
-  #pragma unroll
-            for (int c = 0; c < 3; ++c)
-  #pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                const float pv = acc[0][sg][c][i], gv = g[sg][c][i];
-                s_pg = fmaf(pv, gv, s_pg);
-                s_pp = fmaf(pv, pv, s_pp);
-                s_g += gv;
-              }
         }
         if (WRITE_ENV) {
   #if SGR_FWD_DIRECT
