@@ -15,7 +15,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SUBSET = "golden or trainlight or full_size_backward"
+SUBSET = "golden or trainlight"
 
 
 @pytest.mark.parametrize("env", [
