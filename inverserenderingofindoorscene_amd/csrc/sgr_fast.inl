@@ -13,6 +13,9 @@
 #include <type_traits>
 #include "sgr_launch.h"
 
+#ifndef SGR_TABLE_PREFETCH
+#define SGR_TABLE_PREFETCH 1   // half-wave backward: scalar table entries requested one iteration ahead (324 -> 312 us; no gain in the forward)
+#endif
 #ifndef SGR_FWD_DIRECT
 #define SGR_FWD_DIRECT 0
 #endif
@@ -884,6 +887,9 @@ __global__ __launch_bounds__(kWave, OCC) void sg_bwd_half_kernel(const Args a) {
   const XTable xt = (XTable)(a.cols + EW);
   const int eh = a.eh;
 
+#if SGR_TABLE_PREFETCH
+  f32x8 row_next = rows[0];
+#endif
   auto row_loop = [&](auto ortho_c) {
     for (int e = 0; e < eh; ++e) {
       const float* cur = tile + (HAS_GENV ? (e & 1) * kT32Floats : 0);
@@ -898,13 +904,28 @@ __global__ __launch_bounds__(kWave, OCC) void sg_bwd_half_kernel(const Args a) {
 #pragma unroll
       for (int k = 0; k < KPW; ++k) { asm volatile("" : "+v"(L.ax[k])); asm volatile("" : "+v"(L.ay[k])); }   // no LICM of u_ka
       if (HAS_RENDER) fence_row_invariants(q);
+#if SGR_TABLE_PREFETCH
+      const f32x8 row = row_next;
+      {
+        int ne = e + 1 < eh ? e + 1 : e;
+        asm volatile("" : "+s"(ne) : "s"(row));
+        row_next = rows[ne];
+      }
+      f32x4 cs_next = cst[0];      // the next azimuth pair's scalar table entry is requested one iteration ahead
+      __builtin_amdgcn_sched_barrier(0);
+#else
       const f32x8 row = rows[e];
+#endif
       const float sr = row[0], cr = row[1];
       const RowCtx rc = make_row_ctx(q, row, HAS_RENDER);
 
 #pragma unroll 1
       for (int ap = 0; ap < NP; ++ap) {
+#if SGR_TABLE_PREFETCH
+        const f32x4 cs = cs_next;
+#else
         const f32x4 cs = cst[ap];
+#endif
         const float ca[2] = {cs[0], cs[2]}, sa[2] = {cs[1], cs[3]};
         float g[2][3][2];
         if (HAS_GENV) {
@@ -921,6 +942,14 @@ __global__ __launch_bounds__(kWave, OCC) void sg_bwd_half_kernel(const Args a) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) g[sg][c][0] = g[sg][c][1] = 0.0f;
         }
+#if SGR_TABLE_PREFETCH
+        {   // requested after the LDS reads (scalar loads and LDS share a counter), consumed an iteration later
+          int nxt = (ap + 1) & (NP - 1);
+          asm volatile("" : "+s"(nxt) : "s"(cs));  // `cs` is waited for here, not (together with the new request) at its first use
+          cs_next = cst[nxt];
+          __builtin_amdgcn_sched_barrier(0);      // ... and not sunk towards its use by the scheduler
+        }
+#endif
         if (HAS_RENDER) {
           // the render term of the half row this half-wave owns, then both halves' terms to all lanes
 #pragma unroll

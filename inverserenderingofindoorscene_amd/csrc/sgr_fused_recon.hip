@@ -101,6 +101,7 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_kernel(const Args a) {
   const XTable xt = (XTable)(a.cols + EW);
   const int eh = a.eh;
 
+  f32x8 row_next = rows[0];
   auto row_loop = [&](auto ortho_c) {
     for (int e = 0; e < eh; ++e) {
       const float* cur = tile + (e & 1) * kT32Floats;
@@ -113,13 +114,28 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_kernel(const Args a) {
 #pragma unroll
       for (int k = 0; k < KPW; ++k) { asm volatile("" : "+v"(L.ax[k])); asm volatile("" : "+v"(L.ay[k])); }   // no LICM of u_ka
       fence_row_invariants(q);
-      const f32x8 row = rows[e];
+      // scalar table entries are requested one iteration ahead (and after the wait for the current one, since
+      // scalar loads can only be waited for all together)
+      const f32x8 row = row_next;
+      {
+        int ne = e + 1 < eh ? e + 1 : e;
+        asm volatile("" : "+s"(ne) : "s"(row));
+        row_next = rows[ne];
+      }
+      f32x4 cs_next = cst[0];
+      __builtin_amdgcn_sched_barrier(0);
       const float sr = row[0], cr = row[1];
       const RowCtx rc = make_row_ctx(q, row, true);
 
 #pragma unroll 1
       for (int ap = 0; ap < NP; ++ap) {
-        const f32x4 cs = cst[ap];
+        const f32x4 cs = cs_next;
+        {
+          int nxt = (ap + 1) & (NP - 1);
+          asm volatile("" : "+s"(nxt) : "s"(cs));
+          cs_next = cst[nxt];
+          __builtin_amdgcn_sched_barrier(0);
+        }
         const float ca[2] = {cs[0], cs[2]}, sa[2] = {cs[1], cs[3]};
         // ---- 1. this half's lobes: exponentials and partial radiance of the 4 directions -----------------
         float ex[KPW][2][2], u[KPW][2];
