@@ -318,6 +318,23 @@ __device__ __forceinline__ void tile32_read_pair(const float* tile, int pl, int 
 #pragma unroll
   for (int c = 0; c < 3; ++c) { g[c][0] = r[c].x; g[c][1] = r[c].y; }
 }
+// both half rows' pairs with a single wait (six reads in flight)
+__device__ __forceinline__ void tile32_read_two_pairs(const float* tile, int pl, int jjA, int jjB, float (&gA)[3][2], float (&gB)[3][2]) {
+  const unsigned base = lds_addr(tile) + (unsigned)(pl * 64);
+  const unsigned aA = base + (unsigned)((((jjA >> 2) ^ ((pl >> 2) & 3)) * 4 + (jjA & 3)) * 4);
+  const unsigned aB = base + (unsigned)((((jjB >> 2) ^ ((pl >> 2) & 3)) * 4 + (jjB & 3)) * 4);
+  f32x2 r[2][3];
+  asm volatile("ds_read_b64 %0, %1" : "=v"(r[0][0]) : "v"(aA) : "memory");
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r[0][1]) : "v"(aA), "n"(1 * kPx * 64) : "memory");
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r[0][2]) : "v"(aA), "n"(2 * kPx * 64) : "memory");
+  asm volatile("ds_read_b64 %0, %1" : "=v"(r[1][0]) : "v"(aB) : "memory");
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r[1][1]) : "v"(aB), "n"(1 * kPx * 64) : "memory");
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r[1][2]) : "v"(aB), "n"(2 * kPx * 64) : "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { gA[c][0] = r[0][c].x; gA[c][1] = r[0][c].y; gB[c][0] = r[1][c].x; gB[c][1] = r[1][c].y; }
+}
 // D's lanes 32..63 <-> S's lanes 0..31.  Costs as much issue time as a transcendental (8.3-9.3 cycles, tools/ubench4).
 __device__ __forceinline__ void swap32(float& d, float& s) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(d), __float_as_uint(s), false, false);

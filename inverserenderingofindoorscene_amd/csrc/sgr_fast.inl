@@ -930,8 +930,7 @@ __global__ __launch_bounds__(kWave, OCC) void sg_bwd_half_kernel(const Args a) {
         float g[2][3][2];
         if (HAS_GENV) {
           float t0[3][2], t1[3][2];
-          tile32_read_pair(cur, pl, ap * 2, t0);
-          tile32_read_pair(cur, pl, HALF + ap * 2, t1);
+          tile32_read_two_pairs(cur, pl, ap * 2, HALF + ap * 2, t0, t1);
 #pragma unroll
           for (int c = 0; c < 3; ++c)
 #pragma unroll
