@@ -1,6 +1,7 @@
 // d/d{albedo, normal, rough} of renderingLayer.forwardEnv (autograd of models.py:461-522) on
 // gfx950: the env image is either read (un-fused API) or re-evaluated from the SG lobes
 // (fused API).  The per-direction / per-frame adjoints are in sgr_math.h.
+#include <stdlib.h>
 #include "sgr_common.h"
 #include "sgr_launch.h"
 
@@ -109,6 +110,78 @@ __global__ __launch_bounds__(kWave, 1) void brdf_bwd_kernel(const Args a) {
   }
 }
 
+// env given, envWidth 16: the env rows arrive by double-buffered LDS-DMA (as in render_fast_kernel) instead of being
+// staged through registers behind two workgroup barriers per tile; the arithmetic is the generic kernel's.
+template <int POOL>
+__global__ __launch_bounds__(kWave, 2) void brdf_bwd_dma_kernel(const Args a) {
+  constexpr int EW = 16, HALF = 8;
+  using D = DmaTile<EW>;
+  __shared__ __attribute__((aligned(16))) float tile[2 * D::kFloats];
+
+  const Pix x = locate(a);
+  const int lane = x.lane, b = x.b, p = x.p;
+  const int RC = a.R * a.C;
+  float pooled[7];
+  const Frame f = load_frame_pooled<POOL>(a, x, pooled);
+  const size_t o = (size_t)b * 3 * RC + p;
+  const float gD0 = a.g_diffuse[o], gD1 = a.g_diffuse[o + RC], gD2 = a.g_diffuse[o + 2 * (size_t)RC];
+  const float gs0 = a.g_spec[o], gs1 = a.g_spec[o + RC], gs2 = a.g_spec[o + 2 * (size_t)RC];
+  const float gd0 = gD0 * (pooled[0] * kInvPi), gd1 = gD1 * (pooled[1] * kInvPi), gd2 = gD2 * (pooled[2] * kInvPi);
+
+  FrameGrad g;
+  frame_grad_zero(g);
+  float ds0 = 0.f, ds1 = 0.f, ds2 = 0.f;
+  const DirTable dirs = as_dir_table(a.dirs);
+  __amdgpu_buffer_rsrc_t eimg = env_rsrc(a.env_in + (size_t)b * 3 * RC * a.J, RC, a.J);
+  const int eh = a.J / EW;
+
+  tile_dma_issue<EW>(tile, eimg, x.p0, RC, a.J, 0, lane);
+  for (int e = 0; e < eh; ++e) {
+    const float* cur = tile + (e & 1) * D::kFloats;
+    if (e + 1 < eh) {
+      tile_dma_issue<EW>(tile + ((e + 1) & 1) * D::kFloats, eimg, x.p0, RC, a.J, (e + 1) * EW, lane);
+      wait_vmcnt<D::kInstr>();
+    } else {
+      wait_vmcnt<0>();
+    }
+#pragma unroll 1
+    for (int ap = 0; ap < HALF / 2; ++ap) {
+      float ev[2][3][2];
+      tile_dma_read_pairs<EW>(cur, lane, ap * 2, HALF + ap * 2, ev);
+#pragma unroll
+      for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const f32x4 dir = dirs[e * EW + sg * HALF + ap * 2 + i];
+          const float e0 = ev[sg][0][i], e1 = ev[sg][1][i], e2 = ev[sg][2][i];
+          const float Ed = dir.w * (gd0 * e0 + gd1 * e1 + gd2 * e2);
+          const float Es = dir.w * (gs0 * e0 + gs1 * e1 + gs2 * e2);
+          const float ndl = brdf_dir_bwd(f, dir.x, dir.y, dir.z, a.F0, Ed, Es, g);
+          const float wt = ndl * dir.w;
+          ds0 = fmaf(wt, e0, ds0); ds1 = fmaf(wt, e1, ds1); ds2 = fmaf(wt, e2, ds2);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+  }
+
+  float gpn[3], gprho;
+  frame_bwd(pooled[3], pooled[4], pooled[5], pooled[6], f, g, gpn, gprho);
+  if (x.active) {
+    const unsigned off = pooled_offset<POOL>(p, a.C, a.imW);
+    const size_t plane = (size_t)a.imH * a.imW;
+    float* ga = a.g_albedo + (size_t)b * 3 * plane;
+    float* gn = a.g_normal + (size_t)b * 3 * plane;
+    float* gr = a.g_rough + (size_t)b * plane;
+    scatter_pooled<POOL>(ga, off, a.imW, gD0 * kInvPi * ds0);
+    scatter_pooled<POOL>(ga + plane, off, a.imW, gD1 * kInvPi * ds1);
+    scatter_pooled<POOL>(ga + 2 * plane, off, a.imW, gD2 * kInvPi * ds2);
+    scatter_pooled<POOL>(gn, off, a.imW, gpn[0]);
+    scatter_pooled<POOL>(gn + plane, off, a.imW, gpn[1]);
+    scatter_pooled<POOL>(gn + 2 * plane, off, a.imW, gpn[2]);
+    scatter_pooled<POOL>(gr, off, a.imW, gprho);
+  }
+}
+
 template <int KP, int POOL, bool FROM_SG>
 static int brdf_launch_vec(const Args& a, hipStream_t st) {
   const dim3 grid = wave_grid(a.bn, a.R, a.C), block(kWave);
@@ -121,6 +194,10 @@ static int brdf_launch_vec(const Args& a, hipStream_t st) {
 
 template <int POOL>
 static int brdf_launch(const Args& a, hipStream_t st) {
+  if (a.K == 0 && a.ew == 16 && 3LL * a.R * a.C * a.J * 4 < (1LL << 31) && !getenv("SGR_GENERIC")) {
+    hipLaunchKernelGGL((brdf_bwd_dma_kernel<POOL>), wave_grid(a.bn, a.R, a.C), dim3(kWave), 0, st, a);
+    return (int)hipGetLastError();
+  }
   if (a.K == 0) return brdf_launch_vec<1, POOL, false>(a, st);
   if (a.K <= 4) return brdf_launch_vec<4, POOL, true>(a, st);
   if (a.K <= 12) return brdf_launch_vec<12, POOL, true>(a, st);
@@ -150,7 +227,7 @@ extern "C" int sgr_render_bwd_brdf(const float* g_diffuse, const float* g_spec, 
   a.dirs = reinterpret_cast<const float4*>(dirs); a.view = view;
   a.g_albedo = g_albedo; a.g_normal = g_normal; a.g_rough = g_rough;
   a.bn = bn; a.K = env ? 0 : K; a.R = R; a.C = C; a.J = eh * ew; a.Jpad = sgr_dirs_padded(a.J); a.imH = imH; a.imW = imW;
-  a.F0 = F0; a.premap = premap;
+  a.F0 = F0; a.premap = premap; a.eh = eh; a.ew = ew;
   const hipStream_t st = (hipStream_t)stream;
   return sgr_check(imH == R ? brdf_launch<1>(a, st) : brdf_launch<2>(a, st), "sgr_render_bwd_brdf");
 }

@@ -250,7 +250,11 @@ class _FusedRender(torch.autograd.Function):
             _lib.call("sgr_fused_fwd", _ptr(albedo_c), _ptr(normal_c), _ptr(rough_c), _ptr(axis_c), _ptr(lamb_c),
                       _ptr(weight_c), _ptr(d), _ptr(v), _ptr(env), _ptr(diffuse), _ptr(spec),
                       bn, K, R, C, eh, ew, h, w, float(F0), int(premap), _stream(dev))
-        ctx.save_for_backward(albedo_c, normal_c, rough_c, axis_c, lamb_c, weight_c)
+        # the env image, when it exists, feeds the BRDF-map gradients (the env-given kernel is faster than re-evaluating the SG)
+        if need_env and any(ctx.needs_input_grad[:3]):
+            ctx.save_for_backward(albedo_c, normal_c, rough_c, axis_c, lamb_c, weight_c, env)
+        else:
+            ctx.save_for_backward(albedo_c, normal_c, rough_c, axis_c, lamb_c, weight_c)
         ctx.cfg = (eh, ew, fov, F0, cam, premap)
         ctx.set_materialize_grads(False)
         if need_env:
@@ -259,7 +263,9 @@ class _FusedRender(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        albedo, normal, rough, axis, lamb, weight = ctx.saved_tensors
+        saved = ctx.saved_tensors
+        albedo, normal, rough, axis, lamb, weight = saved[:6]
+        env_saved = saved[6] if len(saved) > 6 else None
         eh, ew, fov, F0, cam, premap = ctx.cfg
         if len(grads) == 3:
             g_env, g_diffuse, g_spec = grads
@@ -285,7 +291,7 @@ class _FusedRender(torch.autograd.Function):
                           _ptr(g_axis), _ptr(g_lamb), _ptr(g_weight),
                           bn, K, R, C, eh, ew, h, w, float(F0), int(premap), _stream(dev))
             if any(ctx.needs_input_grad[:3]):
-                g_alb, g_nrm, g_rgh = _brdf_grads(g_diffuse, g_spec, albedo, normal, rough, None, axis, lamb, weight,
+                g_alb, g_nrm, g_rgh = _brdf_grads(g_diffuse, g_spec, albedo, normal, rough, env_saved, axis, lamb, weight,
                                                   d, v, R, C, eh, ew, F0, premap, ctx.needs_input_grad[:3])
         return (g_alb, g_nrm, g_rgh, g_axis, g_lamb, g_weight) + (None,) * 7
 
