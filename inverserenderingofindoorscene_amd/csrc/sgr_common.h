@@ -342,34 +342,46 @@ __device__ __forceinline__ void swap32(float& d, float& s) {
   s = __uint_as_float(r[1]);
 }
 
-// env tile of a 32-pixel half-wave kernel: [3][32][16 (+4 pad)] floats; the owning lane writes 4 directions at a time,
-// the flush reads it back with 4 lanes per pixel (64-byte segments) and streams it out
-constexpr int kT32Stride = 20;
-constexpr int kT32OutFloats = 3 * kPx * kT32Stride;
+// env tile of a 32-pixel half-wave kernel: [3][32][TD (+4 pad)] floats; the owning lane writes 4 directions at a time,
+// the flush reads it back with TD/4 lanes per pixel and streams it out
+// TD = directions per pixel row of the tile: 16 (one table row, 64-byte segments) or 32 (two rows, 128-byte segments)
+template <int TD> struct T32Out {
+  static constexpr int kStride = TD + 4;
+  static constexpr int kFloats = 3 * kPx * kStride;
+  static constexpr int kLanesPerRow = TD / 4;
+  static constexpr int kRowsPerIt = kWave / kLanesPerRow;
+  static constexpr int kIts = kPx / kRowsPerIt;
+};
+template <int TD>
 __device__ __forceinline__ void tile32_write4(float* tile, int pl, int col, const float (&e0)[4], const float (&e1)[4], const float (&e2)[4]) {
-  *reinterpret_cast<float4*>(tile + (0 * kPx + pl) * kT32Stride + col) = make_float4(e0[0], e0[1], e0[2], e0[3]);
-  *reinterpret_cast<float4*>(tile + (1 * kPx + pl) * kT32Stride + col) = make_float4(e1[0], e1[1], e1[2], e1[3]);
-  *reinterpret_cast<float4*>(tile + (2 * kPx + pl) * kT32Stride + col) = make_float4(e2[0], e2[1], e2[2], e2[3]);
+  using T = T32Out<TD>;
+  *reinterpret_cast<float4*>(tile + (0 * kPx + pl) * T::kStride + col) = make_float4(e0[0], e0[1], e0[2], e0[3]);
+  *reinterpret_cast<float4*>(tile + (1 * kPx + pl) * T::kStride + col) = make_float4(e1[0], e1[1], e1[2], e1[3]);
+  *reinterpret_cast<float4*>(tile + (2 * kPx + pl) * T::kStride + col) = make_float4(e2[0], e2[1], e2[2], e2[3]);
 }
+// flush the first `nd` (16 or TD) directions of every pixel row, starting at direction j0 of the image
+template <int TD>
 __device__ __forceinline__ void tile32_store_global(const float* tile, float* __restrict__ env_img /* [3,RC,J] of image b */, int p0,
-                                                    int RC, int J, int j0, int lane) {
-  const int lrow = lane >> 2, col = (lane & 3) * 4;
+                                                    int RC, int J, int j0, int nd, int lane) {
+  using T = T32Out<TD>;
+  const int lrow = lane / T::kLanesPerRow, col = (lane % T::kLanesPerRow) * 4;
   const unsigned lane_off = (unsigned)(lrow * J + col);
   const int rows_valid = RC - p0;
-  float4 v[3][2];
+  float4 v[3][T::kIts];
 #pragma unroll
   for (int c = 0; c < 3; ++c)
 #pragma unroll
-    for (int it = 0; it < 2; ++it) v[c][it] = *reinterpret_cast<const float4*>(tile + (c * kPx + it * 16 + lrow) * kT32Stride + col);
-  const bool full = rows_valid >= kPx;       // wave-uniform
+    for (int it = 0; it < T::kIts; ++it)
+      v[c][it] = *reinterpret_cast<const float4*>(tile + (c * kPx + it * T::kRowsPerIt + lrow) * T::kStride + col);
+  const bool full = rows_valid >= kPx && nd == TD;       // wave-uniform
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     float* cbase = env_img + ((size_t)c * RC + p0) * J + j0;   // wave-uniform
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      float* dst = cbase + (size_t)(it * 16) * J;               // uniform
+    for (int it = 0; it < T::kIts; ++it) {
+      float* dst = cbase + (size_t)(it * T::kRowsPerIt) * J;    // uniform
       f32x4 nv = {v[c][it].x, v[c][it].y, v[c][it].z, v[c][it].w};
-      if (full || it * 16 + lrow < rows_valid) stream_store(nv, reinterpret_cast<f32x4*>(dst + lane_off));
+      if (full || (it * T::kRowsPerIt + lrow < rows_valid && col < nd)) stream_store(nv, reinterpret_cast<f32x4*>(dst + lane_off));
     }
   }
 }

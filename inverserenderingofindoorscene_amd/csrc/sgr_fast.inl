@@ -16,6 +16,9 @@
 #ifndef SGR_TABLE_PREFETCH
 #define SGR_TABLE_PREFETCH 1   // half-wave backward: scalar table entries requested one iteration ahead (324 -> 312 us; no gain in the forward)
 #endif
+#ifndef SGR_HALF_TD
+#define SGR_HALF_TD 32   // half-wave forward: directions per flushed tile row (16: 64-byte segments, 32: 128-byte)
+#endif
 #ifndef SGR_FWD_DIRECT
 #define SGR_FWD_DIRECT 0
 #endif
@@ -315,7 +318,8 @@ __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
 template <int POOL, bool WRITE_ENV, bool DO_RENDER, int OCC>
 __global__ __launch_bounds__(kWave, OCC) void fwd_half_kernel(const Args a) {
   constexpr int EW = 16, HALF = 8, NQ = 2, KPW = 6;
-  __shared__ __attribute__((aligned(16))) float tile[WRITE_ENV ? kT32OutFloats : 4];
+  constexpr int TD = SGR_HALF_TD;                   // directions per flushed tile row: two table rows -> 128-byte segments
+  __shared__ __attribute__((aligned(16))) float tile[WRITE_ENV ? T32Out<TD>::kFloats : 4];
 
   const int lane = threadIdx.x, half = lane >> 5, pl = lane & 31;
   const int own = 1 - half;                         // the half row (sign) whose totals this half-wave ends up holding
@@ -444,11 +448,12 @@ __global__ __launch_bounds__(kWave, OCC) void fwd_half_kernel(const Args a) {
             s2 = fmaf(sw, tot[2][i], s2);
           }
         }
-        if (WRITE_ENV) tile32_write4(tile, pl, own * HALF + aq * 4, tot[0], tot[1], tot[2]);
+        if (WRITE_ENV) tile32_write4<TD>(tile, pl, (e % (TD / EW)) * EW + own * HALF + aq * 4, tot[0], tot[1], tot[2]);
       }
-      if (WRITE_ENV) {
+      if (WRITE_ENV && ((e + 1) % (TD / EW) == 0 || e + 1 == eh)) {
+        const int rows_in_tile = e % (TD / EW) + 1;
         __syncthreads();
-        tile32_store_global(tile, a.env_out + img, x.p0, RC, a.J, e * EW, lane);
+        tile32_store_global<TD>(tile, a.env_out + img, x.p0, RC, a.J, (e + 1 - rows_in_tile) * EW, rows_in_tile * EW, lane);
         __syncthreads();
       }
     }
