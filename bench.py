@@ -149,6 +149,33 @@ def main() -> None:
     barrier()
     loss_step_ms = (time.perf_counter() - t1) / args.steps * 1e3
 
+    # informational: the same two-kernel step captured once in a HIP graph and replayed (no per-launch host work, no
+    # event markers between the kernels); per-kernel timing is not possible inside a graph, so the contract line above
+    # stays the eager loop
+    graph_ms = None
+    try:
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_grads = step()
+        graph.replay()
+        barrier()
+        t3 = time.perf_counter()
+        for _ in range(args.steps):
+            graph.replay()
+        barrier()
+        graph_ms = (time.perf_counter() - t3) / args.steps * 1e3
+        del static_grads, graph
+    except Exception as exc:       # informational leg: never fail the bench over it
+        graph_ms = None
+        if rank == 0:
+            print(f"# hip-graph leg skipped: {str(exc)[:160]}", file=sys.stderr)
+
     # informational: the whole cascade-0 light objective (render loss + 10 x env reconstruction loss,
     # wrapperBRDFLight.py:167-207) -- fused (env image never written, sgr.light_objective) and unfused
     obj_ms = obj_unfused_ms = None
@@ -232,6 +259,7 @@ def main() -> None:
                        "shaded_px_per_step_per_gpu": P, "image_px_per_step_per_gpu": img_px, "q": q,
                        "Mshade_per_s": round(world * P / (dt / args.steps) / 1e6, 1),
                        "ms_per_step_with_render_loss": round(loss_step_ms, 4),
+                       "ms_per_step_hipgraph_replay": None if graph_ms is None else round(graph_ms, 4),
                        "ms_per_step_light_objective_fused": None if obj_ms is None else round(obj_ms, 4),
                        "ms_per_step_light_objective_unfused": None if obj_unfused_ms is None else round(obj_unfused_ms, 4),
                        "parallelism": f"batch-sharded x{world}"},
