@@ -34,35 +34,43 @@ struct Lobes {   // raw or folded SG parameters of the lane's pixel
 };
 
 // FOLD: ax,ay,az are pre-multiplied by lp = lam*log2e (forward); otherwise unit axes (backward).
+// Two passes: every load of every lobe is in flight before anything consumes one -- one trip to memory per wave
+// instead of one per lobe (the pre-map's conditional stores would otherwise fence the next lobe's loads behind
+// them).  Lobes past K re-read lobe K-1 and get zero weights.
 template <int KP, bool FOLD>
 __device__ __forceinline__ void load_lobes(const Args& a, const Pix& x, int kg, Lobes<KP>& L, bool write_tan) {
   const int RC = a.R * a.C, K = a.K;
 #pragma unroll
   for (int k = 0; k < KP; ++k) {
-    L.ax[k] = L.ay[k] = L.az[k] = L.lp[k] = L.w0[k] = L.w1[k] = L.w2[k] = 0.0f;
-    if (kg + k < K) {
-      const size_t ab = ((size_t)(x.b * K + kg + k) * 3) * RC;   // wave-uniform plane bases
-      const size_t lb = (size_t)(x.b * K + kg + k) * RC;
-      const unsigned up = (unsigned)x.p;                          // the lane's 32-bit offset
-      float ax = (a.axis + ab)[up], ay = (a.axis + ab + RC)[up], az = (a.axis + ab + 2 * (size_t)RC)[up];
-      float l = (a.lamb + lb)[up];
-      float t0 = (a.weight + ab)[up], t1 = (a.weight + ab + RC)[up], t2 = (a.weight + ab + 2 * (size_t)RC)[up];
-      if (a.premap) {
-        l = premap(l);
-        t0 = premap(t0); t1 = premap(t1); t2 = premap(t2);
-        if (write_tan && x.active) {
-          if (a.lamb_tan) (a.lamb_tan + lb)[up] = l;
-          if (a.weight_tan) {
-            (a.weight_tan + ab)[up] = t0; (a.weight_tan + ab + RC)[up] = t1; (a.weight_tan + ab + 2 * (size_t)RC)[up] = t2;
-          }
+    const int kk = min(kg + k, K - 1);
+    const size_t ab = ((size_t)(x.b * K + kk) * 3) * RC;   // wave-uniform plane bases
+    const size_t lb = (size_t)(x.b * K + kk) * RC;
+    const unsigned up = (unsigned)x.p;                      // the lane's 32-bit offset
+    L.ax[k] = (a.axis + ab)[up]; L.ay[k] = (a.axis + ab + RC)[up]; L.az[k] = (a.axis + ab + 2 * (size_t)RC)[up];
+    L.lp[k] = (a.lamb + lb)[up];
+    L.w0[k] = (a.weight + ab)[up]; L.w1[k] = (a.weight + ab + RC)[up]; L.w2[k] = (a.weight + ab + 2 * (size_t)RC)[up];
+  }
+#pragma unroll
+  for (int k = 0; k < KP; ++k) {
+    const bool live = kg + k < K;
+    float l = L.lp[k], t0 = L.w0[k], t1 = L.w1[k], t2 = L.w2[k];
+    if (a.premap) {
+      l = premap(l);
+      t0 = premap(t0); t1 = premap(t1); t2 = premap(t2);
+      if (write_tan && live && x.active) {
+        const size_t ab = ((size_t)(x.b * K + kg + k) * 3) * RC;
+        const size_t lb = (size_t)(x.b * K + kg + k) * RC;
+        const unsigned up = (unsigned)x.p;
+        if (a.lamb_tan) (a.lamb_tan + lb)[up] = l;
+        if (a.weight_tan) {
+          (a.weight_tan + ab)[up] = t0; (a.weight_tan + ab + RC)[up] = t1; (a.weight_tan + ab + 2 * (size_t)RC)[up] = t2;
         }
       }
-      const float lp = l * kLog2e;
-      L.lp[k] = lp;
-      if (FOLD) { ax *= lp; ay *= lp; az *= lp; }
-      L.ax[k] = ax; L.ay[k] = ay; L.az[k] = az;
-      L.w0[k] = t0; L.w1[k] = t1; L.w2[k] = t2;
     }
+    const float lp = l * kLog2e;
+    L.lp[k] = lp;
+    if (FOLD) { L.ax[k] *= lp; L.ay[k] *= lp; L.az[k] *= lp; }
+    L.w0[k] = live ? t0 : 0.0f; L.w1[k] = live ? t1 : 0.0f; L.w2[k] = live ? t2 : 0.0f;
   }
 }
 
