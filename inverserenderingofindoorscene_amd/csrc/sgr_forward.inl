@@ -186,10 +186,10 @@ static inline int fwd_mode() {     // 0 one pixel per lane, 2 / 3 half-wave kern
 }
 template <bool WRITE_ENV, bool DO_RENDER>
 static int fwd_fast_launch(const Args& a, hipStream_t st) {
-  // measured at config 2 (full / half2 us, two sessions): env only 178 / 149 (both); env + render 223 / 209 and 214 / 219
-  // (a wash: both halves of a wave pay for the pixel's frame and row context); render only 165 / 175
-  // -> half-wave by default only for the SG -> env image call (output2env.output2env)
-  const int mode = fwd_mode() >= 0 ? fwd_mode() : ((WRITE_ENV && !DO_RENDER) ? 2 : 0);
+  // measured at config 2, one pixel per lane / half-wave: in the bench loop (working set cycling through HBM) env + render
+  // 239 / 206 us, render only 163 / 172 us; relaunched on the same buffers (tools/kbench, inputs partly cache-resident)
+  // env + render 214-223 / 209-219 us, env only 178 / 149 us  ->  half-wave whenever the env image is written
+  const int mode = fwd_mode() >= 0 ? fwd_mode() : (WRITE_ENV ? 2 : 0);
   if (a.ew == 16 && a.K > 6 && a.K <= 12 && mode != 0)
     return mode == 3 ? fwd_half_launch<WRITE_ENV, DO_RENDER, 3>(a, st) : fwd_half_launch<WRITE_ENV, DO_RENDER, 2>(a, st);
   if (a.ew == 16) {
