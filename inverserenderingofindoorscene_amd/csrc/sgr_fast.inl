@@ -323,11 +323,15 @@ __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
 // lanes 32..63 that of half row 0, so each half then shades / stores / takes statistics for 4 of the 8 directions.
 // Same arithmetic per pixel as fwd_fast_kernel plus 12 swaps + 12 adds per quad, but the work unit is half as long
 // (9600 instead of 4800 waves at config 2: half the ramp/tail) and the register footprint allows 3 waves per SIMD.
-template <int POOL, bool WRITE_ENV, bool DO_RENDER, int OCC>
+// HAS_GT: the statistics of the fused objective (see fwd_fast_kernel), each half-wave against the ground truth of the half
+// row it owns; the 32-pixel ground-truth row (6 KB) sits in a single early-requested LDS-DMA tile.
+template <int POOL, bool WRITE_ENV, bool DO_RENDER, int OCC, bool HAS_GT = false>
 __global__ __launch_bounds__(kWave, OCC) void fwd_half_kernel(const Args a) {
+  static_assert(!(HAS_GT && WRITE_ENV), "the statistics variant does not write the env image");
   constexpr int EW = 16, HALF = 8, NQ = 2, KPW = 6;
   constexpr int TD = SGR_HALF_TD;                   // directions per flushed tile row: two table rows -> 128-byte segments
   __shared__ __attribute__((aligned(16))) float tile[WRITE_ENV ? T32Out<TD>::kFloats : 4];
+  __shared__ __attribute__((aligned(16))) float gtile[HAS_GT ? kT32Floats : 4];
 
   const int lane = threadIdx.x, half = lane >> 5, pl = lane & 31;
   const int own = 1 - half;                         // the half row (sign) whose totals this half-wave ends up holding
@@ -342,6 +346,10 @@ __global__ __launch_bounds__(kWave, OCC) void fwd_half_kernel(const Args a) {
     x.p = x.active ? (x.p0 + pl) : (RC - 1);
   }
   const int b = x.b, p = x.p;
+
+  __amdgpu_buffer_rsrc_t gimg = env_rsrc(HAS_GT ? a.env_gt + (size_t)b * 3 * RC * a.J : a.view, RC, a.J);
+  if (HAS_GT) tile32_dma_issue(gtile, gimg, x.p0, RC, a.J, 0, lane);
+  float s_pg = 0.f, s_pp = 0.f, s_g = 0.f;
 
   // this half's lobes, folded (axis pre-multiplied by lam * log2e)
   Lobes<KPW> L;
@@ -457,6 +465,24 @@ __global__ __launch_bounds__(kWave, OCC) void fwd_half_kernel(const Args a) {
           }
         }
         if (WRITE_ENV) tile32_write4<TD>(tile, pl, (e % (TD / EW)) * EW + own * HALF + aq * 4, tot[0], tot[1], tot[2]);
+        if (HAS_GT) {
+          if (aq == 0) wait_vmcnt<0>();       // the row was requested a quad's worth of arithmetic ago
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            float g[3][2];
+            tile32_read_pair(gtile, pl, own * HALF + aq * 4 + 2 * h, g);
+            if (h == 1 && aq == NQ - 1 && e + 1 < eh) tile32_dma_issue(gtile, gimg, x.p0, RC, a.J, (e + 1) * EW, lane);
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+              for (int i = 0; i < 2; ++i) {
+                const float pv = tot[c][2 * h + i], gv = g[c][i];
+                s_pg = fmaf(pv, gv, s_pg);
+                s_pp = fmaf(pv, pv, s_pp);
+                s_g += gv;
+              }
+          }
+        }
       }
       if (WRITE_ENV && ((e + 1) % (TD / EW) == 0 || e + 1 == eh)) {
         const int rows_in_tile = e % (TD / EW) + 1;
@@ -468,6 +494,28 @@ __global__ __launch_bounds__(kWave, OCC) void fwd_half_kernel(const Args a) {
   };
   if (ortho) row_loop(std::true_type{}); else row_loop(std::false_type{});
 
+  if (HAS_GT) {
+    // both halves' shares of the pixel's sums, then the env mask (wrapperBRDFLight.py:172-174) and the wave's partials
+    float v[3] = {s_pg, s_pp, s_g};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float d_ = v[i], s_ = v[i];
+      swap32(d_, s_);
+      v[i] = d_ + s_;
+    }
+    const float not_dark = (v[2] / (3.0f * (float)a.J)) > 0.001f ? 1.0f : 0.0f;
+    const float m = (x.active && half == 0) ? (a.seg_small + (size_t)b * RC)[(unsigned)p] * a.env_ind[b] * not_dark : 0.0f;
+    if (x.active && half == 0) (a.mask + (size_t)b * RC)[(unsigned)p] = m;
+    float r0 = m * m * v[0], r1 = m * m * v[1], r2 = m;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      r0 += __shfl_xor(r0, off, 64); r1 += __shfl_xor(r1, off, 64); r2 += __shfl_xor(r2, off, 64);
+    }
+    if (lane == 0) {
+      float* w = a.ws + (size_t)blockIdx.x * 3;
+      w[0] = r0; w[1] = r1; w[2] = r2;
+    }
+  }
   if (DO_RENDER) {
     // each half integrated one half row: add the two
     float v[6] = {d0, d1, d2, s0, s1, s2};

@@ -23,6 +23,7 @@
 //   each half evaluates loss, reconstruction and render cotangent for the half row it now holds (6 values)
 //   swap(D = g, S = g):  D = cotangent of half row 1 in all lanes, S = cotangent of half row 0 in all lanes
 // 12 VALU swaps + 6 adds per chunk; no LDS traffic, no barrier, no duplicated transcendental.
+#include <string.h>
 #include "sgr_forward.inl"
 #include "sgr_recon_fold.h"
 
@@ -311,9 +312,9 @@ static bool fused_recon_ok(int K, int R, int C, int eh, int ew) {
 extern "C" int sgr_fused_recon_supported(int K, int R, int C, int eh, int ew) { return fused_recon_ok(K, R, C, eh, ew) ? 1 : 0; }
 
 static int recon_tiles32(int RC) { return (RC + kPx - 1) / kPx; }
-// workspace: [bn] per-image mask sums | [4] scale | [bn,tiles64,3] forward partials | [bn,tiles32] loss partials
+// workspace: [bn] per-image mask sums | [4] scale | [bn,tiles,3] forward partials (tiles32 slots) | [bn,tiles32] loss partials
 extern "C" int sgr_fused_recon_workspace_floats(int bn, int R, int C) {
-  return bn + 4 + bn * recon_tiles(R * C) * 3 + bn * recon_tiles32(R * C);
+  return bn + 4 + bn * recon_tiles32(R * C) * 3 + bn * recon_tiles32(R * C);
 }
 
 extern "C" int sgr_fused_fwd_recon(const float* albedo, const float* normal, const float* rough, const float* axis, const float* lamb,
@@ -333,19 +334,28 @@ extern "C" int sgr_fused_fwd_recon(const float* albedo, const float* normal, con
   a.env_gt = env_gt; a.seg_small = seg_small; a.env_ind = env_ind; a.mask = mask;
   set_dims(a, bn, K, R, C, eh, ew, imH, imW);
   a.F0 = F0; a.premap = premap;
-  const int tiles = recon_tiles(R * C);
+  // SGR_F1_MODE=half: half-wave statistics kernel (32-pixel work units); default one pixel per lane
+  static const bool f1_half_env = [] { const char* e = getenv("SGR_F1_MODE"); return e && !strcmp(e, "half"); }();
+  const bool f1_half = f1_half_env && K > 6;
+  const int tiles = f1_half ? recon_tiles32(R * C) : recon_tiles(R * C);
   float* den_img = workspace;
   float* ws0 = workspace + bn + 4;
   a.ws = ws0;
   const hipStream_t st = (hipStream_t)stream;
-  const dim3 grid = wave_grid(bn, R, C), block(kWave);
   const bool p1 = (imH == R && imW == C);
-  if (K <= 6) {
-    if (p1) hipLaunchKernelGGL((fwd_fast_kernel<6, 1, 16, 16, false, true, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((fwd_fast_kernel<6, 2, 16, 16, false, true, true>), grid, block, 0, st, a);
+  if (f1_half) {
+    const dim3 grid((unsigned)(bn * tiles)), block(kWave);
+    if (p1) hipLaunchKernelGGL((fwd_half_kernel<1, false, true, 2, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((fwd_half_kernel<2, false, true, 2, true>), grid, block, 0, st, a);
   } else {
-    if (p1) hipLaunchKernelGGL((fwd_fast_kernel<12, 1, 16, 16, false, true, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((fwd_fast_kernel<12, 2, 16, 16, false, true, true>), grid, block, 0, st, a);
+    const dim3 grid = wave_grid(bn, R, C), block(kWave);
+    if (K <= 6) {
+      if (p1) hipLaunchKernelGGL((fwd_fast_kernel<6, 1, 16, 16, false, true, true>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((fwd_fast_kernel<6, 2, 16, 16, false, true, true>), grid, block, 0, st, a);
+    } else {
+      if (p1) hipLaunchKernelGGL((fwd_fast_kernel<12, 1, 16, 16, false, true, true>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((fwd_fast_kernel<12, 2, 16, 16, false, true, true>), grid, block, 0, st, a);
+    }
   }
   hipLaunchKernelGGL(recon_fold0, dim3(bn), dim3(kRThreads), 0, st, ws0, coef, den_img, tiles);
   hipLaunchKernelGGL(recon_fold1, dim3(1), dim3(kRThreads), 0, st, ws0, den_img, parts, bn, 0);   // parts = (0, local sum of the env mask)
@@ -374,7 +384,7 @@ extern "C" int sgr_fused_bwd_recon(const float* albedo, const float* normal, con
   const int tiles = recon_tiles(R * C), tiles32 = recon_tiles32(R * C);
   float* den_img = workspace;
   float* scale = workspace + bn;
-  float* ws1 = workspace + bn + 4 + (size_t)bn * tiles * 3;
+  float* ws1 = workspace + bn + 4 + (size_t)bn * tiles32 * 3;
   a.ws = ws1; a.rec_scale = scale;
   const hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(recon_scale_kernel, dim3(1), dim3(64), 0, st, den_img, den_global, scale, bn, rec_weight / (3.0f * (float)(eh * ew)));

@@ -5,6 +5,7 @@ knobs (read once per process, hence the subprocesses), must pass the same golden
   SGR_FWD_MODE/SGR_BWD_MODE=half2 half-wave forward for every forward variant, half-wave backward built for 2 waves/SIMD
   SGR_FWD_MODE=full               one-pixel-per-lane forward also for the SG -> env call
   SGR_GENERIC=1                   generic kernels (table-driven, any direction grid) on the reference's grid
+  SGR_F1_MODE=half                half-wave statistics kernel in the fused objective's forward (objective tests)
 """
 import os
 import subprocess
@@ -30,6 +31,17 @@ def test_alternative_kernels_pass_golden_parity(env):
     e.update(env)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-m", "gpu", "-x",
                         "-k", SUBSET, "-p", "no:cacheprovider"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=580)
+    tail = (r.stdout or "")[-1500:] + (r.stderr or "")[-500:]
+    assert r.returncode == 0, tail
+    assert " passed" in r.stdout and "failed" not in r.stdout, tail
+
+
+@pytest.mark.timeout(600)
+def test_half_wave_objective_forward_passes_objective_tests():
+    e = dict(os.environ)
+    e["SGR_F1_MODE"] = "half"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_objective.py"), "-q", "-m", "gpu", "-x",
+                        "-k", "golden or oracle", "-p", "no:cacheprovider"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=580)
     tail = (r.stdout or "")[-1500:] + (r.stderr or "")[-500:]
     assert r.returncode == 0, tail
     assert " passed" in r.stdout and "failed" not in r.stdout, tail

@@ -78,19 +78,35 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   const double Bbrdf = 7 * q * 4, Bsg = 7 * K * 4, Benv = 3 * J * 4, Bout = 24;
 
+  // KBENCH_COLD=1: a 1 GB memset between launches pushes the operands out of L2 / Infinity Cache, like the bench loop's
+  // 1.3 GB working set does; each launch is then timed on its own
+  const bool cold = getenv("KBENCH_COLD") && atoi(getenv("KBENCH_COLD")) != 0;
+  float* scratch = nullptr; const size_t scratch_bytes = (size_t)1 << 30;
+  if (cold) CHECK(hipMalloc(&scratch, scratch_bytes));
   auto bench = [&](const char* name, double bytes_per_px, std::function<int()> fn) {
     int rc = fn(); if (rc) { printf("%-34s FAILED rc=%d\n", name, rc); return; }
     CHECK(hipStreamSynchronize(st));
     for (int i = 0; i < 2; ++i) fn();
-    CHECK(hipEventRecord(e0, st));
-    for (int i = 0; i < reps; ++i) fn();
-    CHECK(hipEventRecord(e1, st)); CHECK(hipEventSynchronize(e1));
-    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    float ms = 0.f;
+    if (cold) {
+      for (int i = 0; i < reps; ++i) {
+        CHECK(hipMemsetAsync(scratch, i, scratch_bytes, st));
+        CHECK(hipEventRecord(e0, st));
+        fn();
+        CHECK(hipEventRecord(e1, st)); CHECK(hipEventSynchronize(e1));
+        float m1; CHECK(hipEventElapsedTime(&m1, e0, e1)); ms += m1;
+      }
+    } else {
+      CHECK(hipEventRecord(e0, st));
+      for (int i = 0; i < reps; ++i) fn();
+      CHECK(hipEventRecord(e1, st)); CHECK(hipEventSynchronize(e1));
+      CHECK(hipEventElapsedTime(&ms, e0, e1));
+    }
     const double us = ms * 1e3 / reps;
     printf("%-34s %9.1f us   %7.1f GB/s algorithmic (%5.1f%% of 8 TB/s)   %7.1f Mshade/s\n", name, us,
            bytes_per_px * P / us * 1e-3, bytes_per_px * P / us * 1e-3 / 80.0, P / us);
   };
-  printf("# %s  bn=%d  K=%d  P=%zu shaded px  reps=%d  SGR_GENERIC=%s\n", libpath, bn, K, P, reps, getenv("SGR_GENERIC") ? "1" : "0");
+  printf("# %s  bn=%d  K=%d  P=%zu shaded px  reps=%d  SGR_GENERIC=%s  %s\n", libpath, bn, K, P, reps, getenv("SGR_GENERIC") ? "1" : "0", cold ? "COLD (1 GB memset between launches)" : "warm (same buffers relaunched)");
   bench("sgr_fused_fwd (env written)", Bbrdf + Bsg + Benv + Bout, [&] { return sgr_fused_fwd_p(albedo, normal, rough, axis, lamb, weight, dirs, view, env, diffuse, spec, bn, K, R, C, eh, ew, imH, imW, F0d, 1, st); });
   bench("sgr_fused_fwd (render only)", Bbrdf + Bsg + Bout, [&] { return sgr_fused_fwd_p(albedo, normal, rough, axis, lamb, weight, dirs, view, (float*)nullptr, diffuse, spec, bn, K, R, C, eh, ew, imH, imW, F0d, 1, st); });
   bench("sgr_sg_to_env_fwd (+tan outputs)", Bsg + Benv + Bsg * 4.0 / 7.0, [&] { return sgr_sg_to_env_fwd_p(axis, lamb, weight, dirs, env, lam_t, w_t, bn, K, R, C, eh, ew, 1, st); });
