@@ -367,20 +367,19 @@ __device__ __forceinline__ void tile32_store_global(const float* tile, float* __
   const int lrow = lane / T::kLanesPerRow, col = (lane % T::kLanesPerRow) * 4;
   const unsigned lane_off = (unsigned)(lrow * J + col);
   const int rows_valid = RC - p0;
-  float4 v[3][T::kIts];
-#pragma unroll
-  for (int c = 0; c < 3; ++c)
+  const bool full = rows_valid >= kPx && nd == TD;       // wave-uniform
+  // one colour at a time when the tile is wide (TD = 64: 8 float4 per colour), all three at once otherwise
+#pragma unroll(TD >= 64 ? 1 : 3)
+  for (int c = 0; c < 3; ++c) {
+    float4 v[T::kIts];
 #pragma unroll
     for (int it = 0; it < T::kIts; ++it)
-      v[c][it] = *reinterpret_cast<const float4*>(tile + (c * kPx + it * T::kRowsPerIt + lrow) * T::kStride + col);
-  const bool full = rows_valid >= kPx && nd == TD;       // wave-uniform
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
+      v[it] = *reinterpret_cast<const float4*>(tile + (c * kPx + it * T::kRowsPerIt + lrow) * T::kStride + col);
     float* cbase = env_img + ((size_t)c * RC + p0) * J + j0;   // wave-uniform
 #pragma unroll
     for (int it = 0; it < T::kIts; ++it) {
       float* dst = cbase + (size_t)(it * T::kRowsPerIt) * J;    // uniform
-      f32x4 nv = {v[c][it].x, v[c][it].y, v[c][it].z, v[c][it].w};
+      f32x4 nv = {v[it].x, v[it].y, v[it].z, v[it].w};
       if (full || (it * T::kRowsPerIt + lrow < rows_valid && col < nd)) stream_store(nv, reinterpret_cast<f32x4*>(dst + lane_off));
     }
   }
