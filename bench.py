@@ -154,6 +154,8 @@ def main() -> None:
     # stays the eager loop
     graph_ms = None
     try:
+        if world > 1:      # stream capture and the process group's watchdog thread do not mix; single-process only
+            raise RuntimeError("skipped under torch.distributed")
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -173,7 +175,7 @@ def main() -> None:
         del static_grads, graph
     except Exception as exc:       # informational leg: never fail the bench over it
         graph_ms = None
-        if rank == 0:
+        if rank == 0 and world == 1:
             print(f"# hip-graph leg skipped: {str(exc)[:160]}", file=sys.stderr)
 
     # informational: the whole cascade-0 light objective (render loss + 10 x env reconstruction loss,
