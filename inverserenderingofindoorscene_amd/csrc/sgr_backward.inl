@@ -254,11 +254,11 @@ static inline bool bwd_split_enabled() {
 
 template <bool HAS_GENV, bool HAS_RENDER>
 static int sgbwd_launch(const Args& a, hipStream_t st) {
-  if (fast_ok(a) && a.ew == 16 && a.K > 6 && a.K <= 12 && bwd_mode() != 0 && !getenv("SGR_GENERIC"))
+  if (fast_ok(a) && a.ew == 16 && a.K > 6 && a.K <= 12 && bwd_mode() != 0 && !sgr_generic_forced())
     return bwd_mode() == 3 ? sgbwd_half_launch<HAS_GENV, HAS_RENDER, 3>(a, st) : sgbwd_half_launch<HAS_GENV, HAS_RENDER, 2>(a, st);
-  if (fast_ok(a) && a.ew == 16 && a.K > 6 && HAS_GENV && bwd_split_enabled() && !getenv("SGR_GENERIC"))   // measured: only pays with the LDS tile
+  if (fast_ok(a) && a.ew == 16 && a.K > 6 && HAS_GENV && bwd_split_enabled() && !sgr_generic_forced())   // measured: only pays with the LDS tile
     return sgbwd_split_launch<HAS_GENV, HAS_RENDER>(a, st);
-  if (fast_ok(a) && !getenv("SGR_GENERIC"))
+  if (fast_ok(a) && !sgr_generic_forced())
     return a.ew == 16 ? sgbwd_fast_launch_pool<16, HAS_GENV, HAS_RENDER>(a, st) : sgbwd_fast_launch_pool<32, HAS_GENV, HAS_RENDER>(a, st);
   if (!HAS_RENDER || (a.imH == a.R && a.imW == a.C)) return sgbwd_launch_k<1, HAS_GENV, HAS_RENDER>(a, st);
   return sgbwd_launch_k<2, HAS_GENV, HAS_RENDER>(a, st);

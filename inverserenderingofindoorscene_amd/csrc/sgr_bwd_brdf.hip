@@ -194,7 +194,7 @@ static int brdf_launch_vec(const Args& a, hipStream_t st) {
 
 template <int POOL>
 static int brdf_launch(const Args& a, hipStream_t st) {
-  if (a.K == 0 && a.ew == 16 && 3LL * a.R * a.C * a.J * 4 < (1LL << 31) && !getenv("SGR_GENERIC")) {
+  if (a.K == 0 && a.ew == 16 && 3LL * a.R * a.C * a.J * 4 < (1LL << 31) && !sgr_generic_forced()) {
     hipLaunchKernelGGL((brdf_bwd_dma_kernel<POOL>), wave_grid(a.bn, a.R, a.C), dim3(kWave), 0, st, a);
     return (int)hipGetLastError();
   }

@@ -221,8 +221,8 @@ static int render_fast_launch(const Args& a, hipStream_t st) {
 
 template <bool FROM_SG, bool WRITE_ENV, bool DO_RENDER>
 static int fwd_launch(const Args& a, hipStream_t st) {
-  if (!FROM_SG && DO_RENDER && fast_ok(a) && !getenv("SGR_GENERIC")) return render_fast_launch(a, st);
-  if (FROM_SG && fast_ok(a) && a.K <= 24 && !getenv("SGR_GENERIC")) return fwd_fast_launch<WRITE_ENV, DO_RENDER>(a, st);
+  if (!FROM_SG && DO_RENDER && fast_ok(a) && !sgr_generic_forced()) return render_fast_launch(a, st);
+  if (FROM_SG && fast_ok(a) && a.K <= 24 && !sgr_generic_forced()) return fwd_fast_launch<WRITE_ENV, DO_RENDER>(a, st);
   if (!DO_RENDER || (a.imH == a.R && a.imW == a.C)) return fwd_launch_k<1, FROM_SG, WRITE_ENV, DO_RENDER>(a, st);
   return fwd_launch_k<2, FROM_SG, WRITE_ENV, DO_RENDER>(a, st);
 }

@@ -25,3 +25,10 @@ int sgr_check(int hip_rc, const char* who);
       return SGR_ERR_UNSUPPORTED;       \
     }                                   \
   } while (0)
+
+// SGR_GENERIC=1 forces the table-driven generic kernels (tuning / test knob); read once per process
+#include <stdlib.h>
+static inline bool sgr_generic_forced() {
+  static const bool on = [] { const char* e = getenv("SGR_GENERIC"); return e != nullptr; }();
+  return on;
+}
