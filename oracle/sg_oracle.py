@@ -1,9 +1,10 @@
 """CPU oracle for the SG x microfacet render path.  TEST INFRASTRUCTURE ONLY.
 
 This module is the *checker* for the HIP kernels: only ``tests/``,
-``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
-it.  The product package (``inverserenderingofindoorscene_amd``) never does and
-has no CPU compute path.
+``__graft_entry__.smoke()`` and ``bench.py``'s baseline legs (``cpu_baseline`` on the
+host cores; ``eager_gpu_baseline``, the same torch code run eagerly on the GPU as
+the GPU-vs-GPU comparison) and synthetic-input generator may import it.  The product
+package (``inverserenderingofindoorscene_amd``) never does and has no CPU compute path.
 
 It is an independent restatement, in plain ``torch`` CPU ops, of the algorithm
 in the reference (file:line are relative to ``/root/reference``):
@@ -17,6 +18,7 @@ in the reference (file:line are relative to ``/root/reference``):
   * 1- and 2-unknown scale regressions ........... models.py:7-21, 23-84
   * pooled masks, masked-L2 render loss .......... wrapperBRDFLight.py:170-171,192,203-207
   * log-L2 reconstruction loss ................... wrapperBRDFLight.py:172-188
+  * light-decoder output heads, packed hand-off .. models.py:336-346, wrapperBRDFLight.py:167-168
 
 The restatement is structured differently from the reference (a loop over lobes
 and over images with [pixels, J] working sets instead of 7-D broadcast
