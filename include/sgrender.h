@@ -215,7 +215,7 @@ int sgr_fused_bwd_recon(const float* albedo, const float* normal, const float* r
                         float offset, float rec_weight, void* stream);
 
 /* Cotangent scaling for gradients produced ahead of the backward call: x[i][0..n[i]) *= *scale / *applied in
- * place (i < count; x, n are HOST arrays of device pointers / lengths), then *applied = *scale.  Skipped on the
+ * place (i < count <= 4; x, n are HOST arrays of device pointers / lengths), then *applied = *scale.  Skipped on the
  * device when the two are equal (the cotangent of a scalar objective is normally 1).  No host sync. */
 int sgr_rescale_inplace(float* const* x, const long long* n, int count, const float* scale, float* applied, void* stream);
 

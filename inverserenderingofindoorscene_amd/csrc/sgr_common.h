@@ -431,7 +431,9 @@ struct Args {
   const float* env_ind;   // [bn]
   const float* coef;      // [bn]      LSregress scale (constant in backward)
   const float* mask_in;   // [bn,R,C]  env mask from the forward pass
-  const float* rec_scale; // [1]       d objective / d num
+  const float* den_img;   // [bn]      per-image sums of the env mask (forward pass)
+  const float* den_global;// [1]       mask sum all-reduced over ranks, or NULL
+  float rec_w3j;          //           reconstruction weight / (3 J)
   float* mask;            // [bn,R,C]
   float* ws;              // per-wave partial sums
   float offset;

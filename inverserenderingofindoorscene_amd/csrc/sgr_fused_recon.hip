@@ -69,7 +69,17 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_kernel(const Args a) {
   // reconstruction side: x = cf p + off;  dnum/dp = 2 m (ln x - ln(gt + off)) cf / x        (coef is a constant)
   const float cf = a.coef[b], off = a.offset;
   const float m = x.active ? (a.mask_in + (size_t)b * RC)[(unsigned)p] : 0.0f;
-  const float grec = 2.0f * m * a.rec_scale[0] * cf * kLn2;     // times dl (in log2 units) / x
+  // d objective / d num = rec_weight / (3 J max(den, 1e-5)), den = the env-mask sum of the (global) batch
+  float den;
+  if (a.den_global) {
+    den = a.den_global[0];
+  } else {
+    double sden = 0.0;
+    for (int i = 0; i < a.bn; ++i) sden += (double)a.den_img[i];
+    den = (float)sden;
+  }
+  const float rec_scale = a.rec_w3j / fmaxf(den, 1e-5f);
+  const float grec = 2.0f * m * rec_scale * cf * kLn2;     // times dl (in log2 units) / x
   float loss = 0.0f;
 
   // this half's lobes: per-lane offsets into the image's SG block (lobe index differs between the halves)
@@ -267,28 +277,15 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_kernel(const Args a) {
   }
 }
 
-// d objective / d num = rec_weight / (3 J max(den, 1e-5)), with den = sum of the env mask over the (global) batch
-__global__ void recon_scale_kernel(const float* __restrict__ den_img, const float* __restrict__ den_global, float* __restrict__ scale,
-                                   int bn, float rec_weight_over_3J) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    float den;
-    if (den_global) {
-      den = den_global[0];
-    } else {
-      double s = 0.0;
-      for (int i = 0; i < bn; ++i) s += (double)den_img[i];
-      den = (float)s;
-    }
-    scale[0] = rec_weight_over_3J / fmaxf(den, 1e-5f);
-  }
-}
-
 // x *= s / applied, skipped entirely when the two are equal (the usual cotangent of a scalar objective is 1)
-__global__ __launch_bounds__(256) void rescale_kernel(float* __restrict__ x, long long n, const float* __restrict__ s,
-                                                      const float* __restrict__ applied) {
+struct RescaleArgs { float* x[4]; long long n[4]; };
+__global__ __launch_bounds__(256) void rescale_kernel(RescaleArgs r, const float* __restrict__ s, const float* __restrict__ applied) {
   const float f = s[0] / applied[0];
   if (f == 1.0f) return;
+  float* __restrict__ x = r.x[blockIdx.y];
+  const long long n = r.n[blockIdx.y];
   const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i0 >= n) return;
   if (i0 + 3 < n) {
     f32x4 v = *reinterpret_cast<f32x4*>(x + i0);
     v *= f;
@@ -383,11 +380,9 @@ extern "C" int sgr_fused_bwd_recon(const float* albedo, const float* normal, con
   a.F0 = F0; a.premap = premap;
   const int tiles = recon_tiles(R * C), tiles32 = recon_tiles32(R * C);
   float* den_img = workspace;
-  float* scale = workspace + bn;
   float* ws1 = workspace + bn + 4 + (size_t)bn * tiles32 * 3;
-  a.ws = ws1; a.rec_scale = scale;
+  a.ws = ws1; a.den_img = den_img; a.den_global = den_global; a.rec_w3j = rec_weight / (3.0f * (float)(eh * ew));
   const hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(recon_scale_kernel, dim3(1), dim3(64), 0, st, den_img, den_global, scale, bn, rec_weight / (3.0f * (float)(eh * ew)));
   const dim3 grid((unsigned)(bn * tiles32)), block(kWave);
   if (imH == R && imW == C) hipLaunchKernelGGL((sg_bwd_recon_kernel<1>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((sg_bwd_recon_kernel<2>), grid, block, 0, st, a);
@@ -401,10 +396,16 @@ extern "C" int sgr_fused_bwd_recon(const float* albedo, const float* normal, con
 extern "C" int sgr_rescale_inplace(float* const* x, const long long* n, int count, const float* scale, float* applied, void* stream) {
   SGR_REQUIRE(x && n && scale && applied && count >= 0, "sgr_rescale_inplace: NULL argument");
   const hipStream_t st = (hipStream_t)stream;
-  for (int i = 0; i < count; ++i) {
-    SGR_REQUIRE(x[i] && n[i] > 0, "sgr_rescale_inplace: empty tensor");
-    const long long blocks = (n[i] + 1023) / 1024;
-    hipLaunchKernelGGL(rescale_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x[i], n[i], scale, applied);
+  SGR_SUPPORTED(count <= 4, "sgr_rescale_inplace: at most 4 tensors per call");
+  if (count > 0) {
+    RescaleArgs r{};
+    long long nmax = 0;
+    for (int i = 0; i < count; ++i) {
+      SGR_REQUIRE(x[i] && n[i] > 0, "sgr_rescale_inplace: empty tensor");
+      r.x[i] = x[i]; r.n[i] = n[i];
+      nmax = n[i] > nmax ? n[i] : nmax;
+    }
+    hipLaunchKernelGGL(rescale_kernel, dim3((unsigned)((nmax + 1023) / 1024), (unsigned)count), dim3(256), 0, st, r, scale, applied);
   }
   hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, st, applied, scale);
   return sgr_check((int)hipGetLastError(), "sgr_rescale_inplace");
