@@ -45,7 +45,8 @@ const char* sgr_last_error(void);
  *   table in separable form (l_j = (s_e ca_a, s_e sa_a, c_e)):
  *   rows[e*8 + ..] = (s_e, c_e, omega_e, s_e^2, 2 s_e c_e, c_e^2, 0, 0)  for e < eh rounded up to even,
  *   cols (8*ew floats): (ca_a, sa_a) for a < ew/2, then at float offset ew (ca_a^2, 2 ca_a sa_a, sa_a^2, 0)
- *   for a < ew/2 (the second half row is the exact negation of the first).
+ *   for a < ew/2 (the second half row is the exact negation of the first), then at float offset 4*ew
+ *   (ca_a, ca_a+1, sa_a, sa_a+1) per azimuth pair a = 0, 2, .. < ew/2 (operands of the packed-fp32 kernels).
  * Host-side helper: fills `out_host` (sgr_dirs_floats(eh, ew) floats of host memory). */
 int sgr_dirs_padded(int J);
 int sgr_dirs_floats(int eh, int ew);

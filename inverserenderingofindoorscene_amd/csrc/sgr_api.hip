@@ -55,6 +55,9 @@ extern "C" int sgr_fill_direction_table(float* out, int eh, int ew) {
     cols[2 * a] = (float)cad; cols[2 * a + 1] = (float)sad;
     float* o = cols + ew + 4 * (size_t)a;
     o[0] = (float)(cad * cad); o[1] = (float)(2.0 * cad * sad); o[2] = (float)(sad * sad);
+    // at float offset 4*ew: [ew/4][4] = (ca_a, ca_a+1, sa_a, sa_a+1) per azimuth pair (packed-math kernels, sgr_pk.inl)
+    float* pr = cols + 4 * (size_t)ew + 4 * (size_t)(a / 2);
+    pr[a & 1] = (float)cad; pr[2 + (a & 1)] = (float)sad;
   }
   for (int e = 0; e < eh; ++e) {
     const double el = (((double)e + 0.5) / (double)eh) * M_PI / 2.0;

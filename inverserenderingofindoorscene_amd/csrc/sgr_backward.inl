@@ -16,7 +16,7 @@
 #include "sgr_common.h"
 #include "sgr_launch.h"
 #include <string.h>
-#include "sgr_fast.inl"
+#include "sgr_pk.inl"
 
 #ifndef SGR_TJ
 #define SGR_TJ 32
@@ -238,9 +238,20 @@ static int sgbwd_half_launch(const Args& a, hipStream_t st) {
     hipLaunchKernelGGL((sg_bwd_half_kernel<2, HAS_GENV, HAS_RENDER, OCC>), grid, block, 0, st, a);
   return (int)hipGetLastError();
 }
-static inline int bwd_mode() {     // 0 split (two waves), 2 / 3 half-wave kernel built for that many waves per SIMD
-  static const int mode = [] {       // measured at config 2 (g_env + gD,gS): split 350 us, half2 328 us, half3 320 us
+// packed-fp32 half-wave backward (envWidth 16, SGNum <= 12), sgr_pk.inl
+template <bool HAS_GENV, bool HAS_RENDER>
+static int sgbwd_pk_launch(const Args& a, hipStream_t st) {
+  const dim3 grid((unsigned)(a.bn * ((a.R * a.C + kPx - 1) / kPx))), block(kWave);
+  if (!HAS_RENDER || (a.imH == a.R && a.imW == a.C))
+    hipLaunchKernelGGL((sg_bwd_pk_kernel<1, HAS_GENV, HAS_RENDER>), grid, block, 0, st, a);
+  else
+    hipLaunchKernelGGL((sg_bwd_pk_kernel<2, HAS_GENV, HAS_RENDER>), grid, block, 0, st, a);
+  return (int)hipGetLastError();
+}
+static inline int bwd_mode() {     // 4 packed half-wave (default), 0 split (two waves), 2 / 3 scalar half-wave kernel built for that many waves per SIMD
+  static const int mode = [] {       // round 1, config 2 (g_env + gD,gS): split 350 us, half2 328 us, half3 320 us
     const char* e = getenv("SGR_BWD_MODE");
+    if (!e || !strcmp(e, "pk")) return 4;
     if (e && !strcmp(e, "half2")) return 2;
     if (e && !strcmp(e, "split")) return 0;
     return 3;
@@ -254,6 +265,8 @@ static inline bool bwd_split_enabled() {
 
 template <bool HAS_GENV, bool HAS_RENDER>
 static int sgbwd_launch(const Args& a, hipStream_t st) {
+  if (fast_ok(a) && a.ew == 16 && a.K > 6 && a.K <= 12 && bwd_mode() == 4 && !sgr_generic_forced())
+    return sgbwd_pk_launch<HAS_GENV, HAS_RENDER>(a, st);
   if (fast_ok(a) && a.ew == 16 && a.K > 6 && a.K <= 12 && bwd_mode() != 0 && !sgr_generic_forced())
     return bwd_mode() == 3 ? sgbwd_half_launch<HAS_GENV, HAS_RENDER, 3>(a, st) : sgbwd_half_launch<HAS_GENV, HAS_RENDER, 2>(a, st);
   if (fast_ok(a) && a.ew == 16 && a.K > 6 && HAS_GENV && bwd_split_enabled() && !sgr_generic_forced())   // measured: only pays with the LDS tile

@@ -5,7 +5,7 @@
 #include "sgr_common.h"
 #include "sgr_launch.h"
 #include <string.h>
-#include "sgr_fast.inl"
+#include "sgr_pk.inl"
 
 #ifndef SGR_TJ
 #define SGR_TJ 32
@@ -174,9 +174,21 @@ static int fwd_half_launch(const Args& a, hipStream_t st) {
     hipLaunchKernelGGL((fwd_half_kernel<2, WRITE_ENV, DO_RENDER, OCC>), grid, block, 0, st, a);
   return (int)hipGetLastError();
 }
-static inline int fwd_mode() {     // 0 one pixel per lane, 2 / 3 half-wave kernel built for that many waves per SIMD, -1 default
+// packed-fp32 forward (envWidth 16, SGNum <= 12): one pixel per lane, arithmetic in azimuth pairs (sgr_pk.inl)
+template <int KP, bool WRITE_ENV, bool DO_RENDER>
+static int fwd_pk_launch(const Args& a, hipStream_t st) {
+  const dim3 grid = wave_grid(a.bn, a.R, a.C), block(kWave);
+  if (!DO_RENDER || (a.imH == a.R && a.imW == a.C))
+    hipLaunchKernelGGL((fwd_pk_kernel<KP, 1, WRITE_ENV, DO_RENDER>), grid, block, 0, st, a);
+  else
+    hipLaunchKernelGGL((fwd_pk_kernel<KP, 2, WRITE_ENV, DO_RENDER>), grid, block, 0, st, a);
+  return (int)hipGetLastError();
+}
+static inline int fwd_mode() {     // 4 packed (default), 0 scalar one pixel per lane, 2 / 3 scalar half-wave kernel, -1 round-1 default
   static const int mode = [] {
     const char* e = getenv("SGR_FWD_MODE");
+    if (!e || !strcmp(e, "pk")) return 4;
+    if (e && !strcmp(e, "scalar")) return -1;
     if (e && !strcmp(e, "full")) return 0;
     if (e && !strcmp(e, "half2")) return 2;
     if (e && !strcmp(e, "half3")) return 3;
@@ -189,7 +201,9 @@ static int fwd_fast_launch(const Args& a, hipStream_t st) {
   // measured at config 2, one pixel per lane / half-wave: in the bench loop (working set cycling through HBM) env + render
   // 239 / 206 us, render only 163 / 172 us; relaunched on the same buffers (tools/kbench, inputs partly cache-resident)
   // env + render 214-223 / 209-219 us, env only 178 / 149 us  ->  half-wave whenever the env image is written
-  const int mode = fwd_mode() >= 0 ? fwd_mode() : (WRITE_ENV ? 2 : 0);
+  if (fwd_mode() == 4 && a.ew == 16 && a.K <= 12)
+    return a.K <= 6 ? fwd_pk_launch<6, WRITE_ENV, DO_RENDER>(a, st) : fwd_pk_launch<12, WRITE_ENV, DO_RENDER>(a, st);
+  const int mode = (fwd_mode() >= 0 && fwd_mode() != 4) ? fwd_mode() : (WRITE_ENV ? 2 : 0);
   if (a.ew == 16 && a.K > 6 && a.K <= 12 && mode != 0)
     return mode == 3 ? fwd_half_launch<WRITE_ENV, DO_RENDER, 3>(a, st) : fwd_half_launch<WRITE_ENV, DO_RENDER, 2>(a, st);
   if (a.ew == 16) {

@@ -1,0 +1,463 @@
+// Packed-fp32 kernels for the reference's 8x16 direction grid (envWidth 16), round 2.
+//
+// Why: on gfx950 a VALU instruction issued next to transcendentals costs ~4 cycles of its SIMD whatever it is
+// and however many waves are resident (tools/ubench5: `1 v_exp + 6 v_fmac` = 31.6 cycles at 1..4 waves per SIMD,
+// `1 v_exp + 3 v_pk_fma_f32` = 20.4; the two-wave dual issue that gives pure FMA streams 2.1 cycles per
+// instruction is lost as soon as v_exp/v_rcp/v_rsq/v_permlane are in the stream, however they are grouped).
+// So the lever is the instruction COUNT: every FMA of the inner loops is issued as one half of a v_pk_fma_f32.
+//
+// Packing axis: two neighbouring azimuths (a, a+1) of one table row and one sign.  With the separable table
+//     lam (a_k . l_j - 1) = +-s_e U_ka + C_ke,   U_ka = lam (ax ca_a + ay sa_a),
+// (U_k,a , U_k,a+1) is one v_pk_mul + one v_pk_fma from the SGPR pairs (ca_a, ca_a+1), (sa_a, sa_a+1), the two
+// exponents of a sign are one v_pk_fma, the three colour accumulations one v_pk_fma each, and the accumulators
+// come out as (env[.., a], env[.., a+1]) pairs -- the order the env image, its LDS tiles (ds_write_b128 /
+// ds_read_b64) and the cotangent rows already use.  The microfacet terms are evaluated for the same two
+// directions at a time (brdf_ortho_pair).  Degenerate shading frames (wave-uniform test) take the scalar
+// Gram-matrix path of sgr_fast.inl.
+#pragma once
+#include "sgr_fast.inl"
+
+namespace sgr {
+
+__device__ __forceinline__ f32x2 splat2(float x) { return f32x2{x, x}; }
+__device__ __forceinline__ f32x2 pfma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+// One half of a register pair as both operands of a packed instruction: folds into the op_sel / op_sel_hi bits of the
+// consuming v_pk_* instruction -- PROVIDED the shuffle is selected in the same basic block as its use.  Hoisted out of
+// a loop (LICM) it becomes a materialised (x, x) pair, i.e. a second register per scalar.  Hence FENCE2 below: an
+// empty asm that redefines the pair inside the loop body, at no cost in instructions.
+#define SGR_LO(P) __builtin_shufflevector(P, P, 0, 0)
+#define SGR_HI(P) __builtin_shufflevector(P, P, 1, 1)
+#define SGR_FENCE2(P) asm volatile("" : "+v"(P))
+__device__ __forceinline__ f32x2 half_of(f32x2 p, int i) { return i ? SGR_HI(p) : SGR_LO(p); }
+typedef const f32x4 __attribute__((address_space(4))) * PairTable;   // per azimuth pair: (ca_a, ca_a+1, sa_a, sa_a+1)
+__device__ __forceinline__ PairTable as_pair_table(const float* cols, int ew) { return (PairTable)(cols + 4 * ew); }
+
+// SG parameters of the lane's pixel in register pairs (KP even; lobes past K carry zero weights).
+// FOLD: axis pre-multiplied by lp = lam * log2e (forward); unit axes otherwise (backward).
+template <int KP>
+struct LobesPk {
+  f32x2 axy[KP];        // (ax, ay)
+  f32x2 w01[KP];        // (w0, w1)
+  f32x2 w2p[KP / 2];    // (w2 of lobe 2m, w2 of lobe 2m+1)
+  f32x2 azp[KP / 2];    // (az, az)  likewise
+  f32x2 lpp[KP / 2];    // (lp, lp)  likewise
+};
+// Loads (and pre-maps) the lobes straight into pairs; same two-pass structure as load_lobes (sgr_fast.inl): every load
+// of every lobe is in flight before the pre-map consumes any.  `kg` = first lobe (may differ between the two halves of
+// a wave, so the lobe planes are addressed by 32-bit per-lane offsets into the image's SG block); lobes past K re-read
+// lobe K-1 and get zero weights.
+template <int KP, bool FOLD>
+__device__ __forceinline__ void load_lobes_pk(const Args& a, int b, unsigned up, bool active, int kg, LobesPk<KP>& P, bool write_tan) {
+  static_assert(KP % 2 == 0, "lobes are packed in pairs");
+  const int RC = a.R * a.C, K = a.K;
+  const float* axis_b = a.axis + (size_t)b * K * 3 * RC;
+  const float* lamb_b = a.lamb + (size_t)b * K * RC;
+  const float* weight_b = a.weight + (size_t)b * K * 3 * RC;
+  float ax[KP], ay[KP], az[KP], lp[KP], w0[KP], w1[KP], w2[KP];
+#pragma unroll
+  for (int k = 0; k < KP; ++k) {
+    const int kk = min(kg + k, K - 1);
+    const unsigned o3 = (unsigned)(kk * 3 * RC) + up, o1 = (unsigned)(kk * RC) + up;
+    ax[k] = axis_b[o3]; ay[k] = axis_b[o3 + RC]; az[k] = axis_b[o3 + 2 * RC];
+    lp[k] = lamb_b[o1];
+    w0[k] = weight_b[o3]; w1[k] = weight_b[o3 + RC]; w2[k] = weight_b[o3 + 2 * RC];
+  }
+#pragma unroll
+  for (int k = 0; k < KP; ++k) {
+    const bool live = kg + k < K;
+    float l = lp[k], t0 = w0[k], t1 = w1[k], t2 = w2[k];
+    if (a.premap) {
+      l = premap(l);
+      t0 = premap(t0); t1 = premap(t1); t2 = premap(t2);
+      if (write_tan && live && active) {
+        const unsigned o3 = (unsigned)((kg + k) * 3 * RC) + up, o1 = (unsigned)((kg + k) * RC) + up;
+        if (a.lamb_tan) (a.lamb_tan + (size_t)b * K * RC)[o1] = l;
+        if (a.weight_tan) {
+          float* wt_b = a.weight_tan + (size_t)b * K * 3 * RC;
+          wt_b[o3] = t0; wt_b[o3 + RC] = t1; wt_b[o3 + 2 * RC] = t2;
+        }
+      }
+    }
+    const float lpk = l * kLog2e;
+    lp[k] = lpk;
+    if (FOLD) { ax[k] *= lpk; ay[k] *= lpk; az[k] *= lpk; }
+    w0[k] = live ? t0 : 0.0f; w1[k] = live ? t1 : 0.0f; w2[k] = live ? t2 : 0.0f;
+  }
+#pragma unroll
+  for (int k = 0; k < KP; ++k) {
+    P.axy[k] = f32x2{ax[k], ay[k]};
+    P.w01[k] = f32x2{w0[k], w1[k]};
+  }
+#pragma unroll
+  for (int m = 0; m < KP / 2; ++m) {
+    P.w2p[m] = f32x2{w2[2 * m], w2[2 * m + 1]};
+    P.azp[m] = f32x2{az[2 * m], az[2 * m + 1]};
+    P.lpp[m] = f32x2{lp[2 * m], lp[2 * m + 1]};
+  }
+}
+template <int KP>
+__device__ __forceinline__ void fence_lobes(LobesPk<KP>& P) {
+#pragma unroll
+  for (int k = 0; k < KP; ++k) { SGR_FENCE2(P.axy[k]); SGR_FENCE2(P.w01[k]); }
+#pragma unroll
+  for (int m = 0; m < KP / 2; ++m) SGR_FENCE2(P.w2p[m]);
+}
+
+// Per-pixel and per-(pixel, table row) constants of the orthonormal microfacet path, in pairs (see brdf_ortho_dir)
+struct OrthoPix { f32x2 vB, ff, vvk; };       // (vBx, vBy), (fb, fa), (vv, -)
+struct OrthoRow { f32x2 nwc, cvc; };          // (nw, rowc), (Cv, c1n2)
+__device__ __forceinline__ OrthoPix make_ortho_pix(const PixLocal& q) {
+  OrthoPix o;
+  o.vB = f32x2{q.vBx, q.vBy}; o.ff = f32x2{q.fb, q.fa}; o.vvk = f32x2{q.vv, 0.0f};
+  return o;
+}
+__device__ __forceinline__ OrthoRow make_ortho_row(const RowOrtho& r) {
+  OrthoRow o;
+  o.nwc = f32x2{r.nw, r.rowc}; o.cvc = f32x2{r.Cv, r.c1n2};
+  return o;
+}
+// spec of the directions (ss ca_i, ss sa_i, c_e), i = 0, 1: brdf_ortho_dir (sgr_math.h), two azimuths per instruction.
+// Pv = vBx ca + vBy sa.  `ss` = +-s_e (wave-uniform).
+__device__ __forceinline__ f32x2 brdf_ortho_pair(const OrthoPix& q, const OrthoRow& r, float ss, f32x2 ca, f32x2 sa, f32x2 Pv) {
+  const f32x2 sv = splat2(ss);
+  const f32x2 tx = pfma(sv, ca, SGR_LO(q.vB)), ty = pfma(sv, sa, SGR_HI(q.vB));
+  const f32x2 T2 = pfma(tx, tx, ty * ty);
+  const f32x2 hh4 = pfma(SGR_LO(r.nwc), SGR_LO(r.nwc), T2);
+  const f32x2 Hm = {fmaxf(hh4.x, 4e-6f), fmaxf(hh4.y, 4e-6f)};
+  const f32x2 r4 = {frsq(Hm.x), frsq(Hm.y)};
+  const f32x2 vdh = (SGR_LO(q.vvk) + pfma(sv, Pv, SGR_LO(r.cvc))) * r4;
+  const f32x2 pa = pfma(splat2(-5.55472f), vdh, splat2(-6.98316f)) * vdh;
+  const f32x2 pw = {fexp2(pa.x), fexp2(pa.y)};
+  const f32x2 nom0 = ((T2 + (Hm - hh4)) + SGR_HI(r.nwc)) * (r4 * r4);
+  const f32x2 nr = (nom0 * nom0) * SGR_HI(r.cvc);
+  const f32x2 rn = {frcp(clampf(nr.x, 1e-6f, kFourPi)), frcp(clampf(nr.y, 1e-6f, kFourPi))};
+  return pfma(SGR_LO(q.ff), pw, SGR_HI(q.ff)) * rn;
+}
+
+// (weight, spec) of two directions: packed orthonormal path, or two scalar evaluations of the Gram-matrix path
+template <bool ORTHO>
+__device__ __forceinline__ void shade_pair(const PixLocal& q, const OrthoPix& oq, const RowCtx& rc, const OrthoRow& orow, int sg, f32x2 ca,
+                                           f32x2 sa, f32x2 Pv, XTable xt, int a0, f32x2& wt, f32x2& sp) {
+  if (ORTHO) {
+    sp = brdf_ortho_pair(oq, orow, sg ? -rc.sr : rc.sr, ca, sa, Pv);
+    wt = splat2(rc.ro.wt);
+  } else {
+    float w0, w1, s0, s1;
+    shade_dir<false>(q, rc, sg, ca.x, sa.x, xt, a0, w0, s0);
+    shade_dir<false>(q, rc, sg, ca.y, sa.y, xt, a0 + 1, w1, s1);
+    wt = f32x2{w0, w1};
+    sp = f32x2{s0, s1};
+  }
+}
+
+// ============================== forward, one pixel per lane, packed ===============================
+// fwd_fast_kernel's work decomposition (64 pixels per wave, all K <= KP lobes in registers, env rows leave through
+// the 64 x 16 LDS tile) with the arithmetic in azimuth pairs.  Per lobe and azimuth quad: 8 packed U/exponent
+// instructions, 8 v_exp_f32, 12 packed accumulations -- against 40 scalar instructions + 8 v_exp_f32.
+template <int KP, int POOL, bool WRITE_ENV, bool DO_RENDER>
+__global__ __launch_bounds__(kWave, 2) void fwd_pk_kernel(const Args a) {
+  constexpr int EW = 16, TJ = 16, HALF = 8, NQ = 2;
+  __shared__ __attribute__((aligned(16))) float tile[WRITE_ENV ? Tile<TJ>::kFloats : 4];
+
+  const Pix x = locate(a);
+  const int lane = x.lane, b = x.b, p = x.p;
+  const int RC = a.R * a.C;
+
+  LobesPk<KP> P;
+  load_lobes_pk<KP, true>(a, b, (unsigned)p, x.active, 0, P, true);
+
+  PixLocal q;
+  OrthoPix oq;
+  float alb[3] = {0.f, 0.f, 0.f};
+  bool ortho = true;
+  if (DO_RENDER) {
+    const Frame f = load_frame<POOL>(a, x, alb);
+    q = make_local(f, a.F0);
+    oq = make_ortho_pix(q);
+    ortho = __all(frame_is_orthonormal(q));
+  }
+  const SepTable rows = as_sep_table(a.rows);
+  const PairTable cpt = as_pair_table(a.cols, EW);
+  const XTable xt = (XTable)(a.cols + EW);
+  const size_t img = (size_t)b * 3 * RC * a.J;
+  const int eh = a.eh;
+  f32x2 dacc[3] = {splat2(0.f), splat2(0.f), splat2(0.f)}, sacc[3] = {splat2(0.f), splat2(0.f), splat2(0.f)};
+
+  auto row_loop = [&](auto ortho_c) {
+    constexpr bool ORTHO = decltype(ortho_c)::value;
+    for (int e = 0; e < eh; ++e) {
+      if (DO_RENDER && !ORTHO) fence_row_invariants(q);
+      const f32x8 row = rows[e];
+      const float sr = row[0];
+      f32x2 Ck[KP / 2];
+#pragma unroll
+      for (int m = 0; m < KP / 2; ++m) Ck[m] = pfma(P.azp[m], splat2(row[1]), -P.lpp[m]);
+      const RowCtx rc = make_row_ctx(q, row, DO_RENDER);
+      OrthoRow orow = make_ortho_row(rc.ro);
+#pragma unroll 1
+      for (int aq = 0; aq < NQ; ++aq) {
+        fence_lobes<KP>(P);
+#pragma unroll
+        for (int m = 0; m < KP / 2; ++m) SGR_FENCE2(Ck[m]);
+        if (DO_RENDER && ORTHO) { SGR_FENCE2(oq.vB); SGR_FENCE2(oq.ff); SGR_FENCE2(oq.vvk); SGR_FENCE2(orow.nwc); SGR_FENCE2(orow.cvc); }
+        const f32x4 t0 = cpt[2 * aq], t1 = cpt[2 * aq + 1];
+        const f32x2 ca[2] = {f32x2{t0[0], t0[1]}, f32x2{t1[0], t1[1]}}, sa[2] = {f32x2{t0[2], t0[3]}, f32x2{t1[2], t1[3]}};
+        f32x2 acc[2][3][2];   // [sign][colour][azimuth pair of the quad]
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) acc[sg][c][0] = acc[sg][c][1] = splat2(0.f);
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+          const f32x2 ck = half_of(Ck[k / 2], k & 1), w2 = half_of(P.w2p[k / 2], k & 1);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const f32x2 U = pfma(SGR_HI(P.axy[k]), sa[h], SGR_LO(P.axy[k]) * ca[h]);
+            const f32x2 tp = pfma(splat2(sr), U, ck);
+            const f32x2 tm = pfma(splat2(-sr), U, ck);
+            const f32x2 ep = {fexp2(tp.x), fexp2(tp.y)};
+            const f32x2 em = {fexp2(tm.x), fexp2(tm.y)};
+            acc[0][0][h] = pfma(SGR_LO(P.w01[k]), ep, acc[0][0][h]);
+            acc[0][1][h] = pfma(SGR_HI(P.w01[k]), ep, acc[0][1][h]);
+            acc[0][2][h] = pfma(w2, ep, acc[0][2][h]);
+            acc[1][0][h] = pfma(SGR_LO(P.w01[k]), em, acc[1][0][h]);
+            acc[1][1][h] = pfma(SGR_HI(P.w01[k]), em, acc[1][1][h]);
+            acc[1][2][h] = pfma(w2, em, acc[1][2][h]);
+          }
+        }
+        if (DO_RENDER) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const f32x2 Pv = pfma(SGR_HI(oq.vB), sa[h], SGR_LO(oq.vB) * ca[h]);
+#pragma unroll
+            for (int sg = 0; sg < 2; ++sg) {
+              f32x2 wt, sp;
+              shade_pair<ORTHO>(q, oq, rc, orow, sg, ca[h], sa[h], Pv, xt, aq * 4 + 2 * h, wt, sp);
+              const f32x2 sw = sp * wt;
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                dacc[c] = pfma(wt, acc[sg][c][h], dacc[c]);
+                sacc[c] = pfma(sw, acc[sg][c][h], sacc[c]);
+              }
+            }
+          }
+        }
+        if (WRITE_ENV) {
+#pragma unroll
+          for (int sg = 0; sg < 2; ++sg) {
+            float e0[4], e1[4], e2[4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              e0[2 * h] = acc[sg][0][h].x; e0[2 * h + 1] = acc[sg][0][h].y;
+              e1[2 * h] = acc[sg][1][h].x; e1[2 * h + 1] = acc[sg][1][h].y;
+              e2[2 * h] = acc[sg][2][h].x; e2[2 * h + 1] = acc[sg][2][h].y;
+            }
+            tile_row_write<TJ>(tile, lane, sg * HALF + aq * 4, e0, e1, e2);
+          }
+        }
+      }
+      if (WRITE_ENV) {
+        __syncthreads();
+        tile_store_global<TJ, true>(tile, a.env_out + img, x.p0, RC, a.J, e * EW, lane);
+        __syncthreads();
+      }
+    }
+  };
+  if (ortho) row_loop(std::true_type{}); else row_loop(std::false_type{});
+
+  if (DO_RENDER && x.active) {
+    const size_t o = (size_t)b * 3 * RC;
+    const unsigned up = (unsigned)p;
+    (a.diffuse + o)[up] = (alb[0] * kInvPi) * (dacc[0].x + dacc[0].y);
+    (a.diffuse + o + RC)[up] = (alb[1] * kInvPi) * (dacc[1].x + dacc[1].y);
+    (a.diffuse + o + 2 * (size_t)RC)[up] = (alb[2] * kInvPi) * (dacc[2].x + dacc[2].y);
+    (a.spec + o)[up] = sacc[0].x + sacc[0].y;
+    (a.spec + o + RC)[up] = sacc[1].x + sacc[1].y;
+    (a.spec + o + 2 * (size_t)RC)[up] = sacc[2].x + sacc[2].y;
+  }
+}
+
+
+// ============================== backward w.r.t. the SG parameters, half-wave, packed ===============
+// sg_bwd_half_kernel's decomposition (one wave = 32 pixels x 2 groups of 6 lobes; the env cotangent arrives one table
+// row at a time by double-buffered LDS-DMA; each half evaluates the microfacet terms of one half row and the halves
+// trade them with v_permlane32_swap) with the arithmetic in azimuth pairs: the cotangent pairs are the ds_read_b64
+// results as they come, every gradient accumulator is a pair over the azimuth's parity, folded at the end.
+// Per lobe and azimuth pair (4 directions): 27 packed instructions + 4 v_exp_f32, against 58 scalar + 4 v_exp_f32.
+//   g[c,j] = gEnv[c,j] + omega_j ndl_j (gD_c A_c/pi + gS_c spec_j);  T = (g . w) E:
+//   dL/dw_c = sum g_c E,   dL/dlam = sum T t,   dL/da = lam (sum_a ca_a A_a, sum_a sa_a A_a, sum T c_e),  A_a = sum_e s_e (T+ - T-)
+__device__ __forceinline__ void tile32_read_two_pairs2(const float* tile, int pl, int jjA, int jjB, f32x2 (&gA)[3], f32x2 (&gB)[3]) {
+  const unsigned base = lds_addr(tile) + (unsigned)(pl * 64);
+  const unsigned aA = base + (unsigned)((((jjA >> 2) ^ ((pl >> 2) & 3)) * 4 + (jjA & 3)) * 4);
+  const unsigned aB = base + (unsigned)((((jjB >> 2) ^ ((pl >> 2) & 3)) * 4 + (jjB & 3)) * 4);
+  asm volatile("ds_read_b64 %0, %1" : "=v"(gA[0]) : "v"(aA) : "memory");
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(gA[1]) : "v"(aA), "n"(1 * kPx * 64) : "memory");
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(gA[2]) : "v"(aA), "n"(2 * kPx * 64) : "memory");
+  asm volatile("ds_read_b64 %0, %1" : "=v"(gB[0]) : "v"(aB) : "memory");
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(gB[1]) : "v"(aB), "n"(1 * kPx * 64) : "memory");
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(gB[2]) : "v"(aB), "n"(2 * kPx * 64) : "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int POOL, bool HAS_GENV, bool HAS_RENDER>
+__global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
+  constexpr int EW = 16, HALF = 8, NP = 4, KPW = 6;
+  __shared__ __attribute__((aligned(16))) float tile[HAS_GENV ? 2 * kT32Floats : 4];
+
+  const int lane = threadIdx.x, half = lane >> 5, pl = lane & 31;
+  const int own = 1 - half;                         // the half row (sign) whose BRDF terms this half-wave evaluates
+  const int RC = a.R * a.C, K = a.K;
+  Pix x;
+  x.lane = lane;
+  {
+    const int tiles = (RC + kPx - 1) / kPx;
+    x.b = blockIdx.x / tiles;
+    x.p0 = (blockIdx.x - x.b * tiles) * kPx;
+    x.active = (x.p0 + pl) < RC;
+    x.p = x.active ? (x.p0 + pl) : (RC - 1);
+  }
+  const int b = x.b, p = x.p;
+
+  __amdgpu_buffer_rsrc_t gimg = env_rsrc(HAS_GENV ? a.g_env + (size_t)b * 3 * RC * a.J : a.view, RC, a.J);
+  if (HAS_GENV) tile32_dma_issue(tile, gimg, x.p0, RC, a.J, 0, lane);
+
+  PixLocal q;
+  OrthoPix oq;
+  bool ortho = true;
+  f32x2 gds[3] = {splat2(0.f), splat2(0.f), splat2(0.f)};     // (gD_c A_c / pi, gS_c)
+  if (HAS_RENDER) {
+    float alb[3];
+    const Frame f = load_frame<POOL>(a, x, alb);
+    q = make_local(f, a.F0);
+    oq = make_ortho_pix(q);
+    ortho = __all(frame_is_orthonormal(q));
+    const size_t o = (size_t)b * 3 * RC;
+    const unsigned up = (unsigned)p;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      gds[c] = f32x2{(a.g_diffuse + o + (size_t)c * RC)[up] * (alb[c] * kInvPi), (a.g_spec + o + (size_t)c * RC)[up]};
+  }
+
+  LobesPk<KPW> P;      // unit axes, lp = lam * log2e, post-tan weights
+  load_lobes_pk<KPW, false>(a, b, (unsigned)p, x.active, half * KPW, P, false);
+
+  f32x2 gw0[KPW], gw1[KPW], gw2[KPW], gl[KPW], gz[KPW], gx[KPW], gy[KPW];
+#pragma unroll
+  for (int k = 0; k < KPW; ++k) gw0[k] = gw1[k] = gw2[k] = gl[k] = gz[k] = gx[k] = gy[k] = splat2(0.f);
+
+  const SepTable rows = as_sep_table(a.rows);
+  const PairTable cpt = as_pair_table(a.cols, EW);
+  const XTable xt = (XTable)(a.cols + EW);
+  const int eh = a.eh;
+
+  auto row_loop = [&](auto ortho_c) {
+    constexpr bool ORTHO = decltype(ortho_c)::value;
+    for (int e = 0; e < eh; ++e) {
+      const float* cur = tile + (HAS_GENV ? (e & 1) * kT32Floats : 0);
+      if (HAS_GENV) {
+        if (e + 1 < eh) {
+          tile32_dma_issue(tile + ((e + 1) & 1) * kT32Floats, gimg, x.p0, RC, a.J, (e + 1) * EW, lane);
+          wait_vmcnt<6>();        // row e has landed; row e+1 stays in flight
+        } else {
+          wait_vmcnt<0>();
+        }
+      }
+      if (HAS_RENDER && !ORTHO) fence_row_invariants(q);
+      const f32x8 row = rows[e];
+      const float sr = row[0], cr = row[1];
+      f32x2 czr[KPW / 2];
+#pragma unroll
+      for (int m = 0; m < KPW / 2; ++m) czr[m] = pfma(P.azp[m], splat2(cr), splat2(-1.0f));
+      const RowCtx rc = make_row_ctx(q, row, HAS_RENDER);
+      OrthoRow orow = make_ortho_row(rc.ro);
+
+#pragma unroll 1
+      for (int ap = 0; ap < NP; ++ap) {
+        fence_lobes<KPW>(P);
+#pragma unroll
+        for (int m = 0; m < KPW / 2; ++m) { SGR_FENCE2(czr[m]); SGR_FENCE2(P.lpp[m]); }
+        if (HAS_RENDER) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) SGR_FENCE2(gds[c]);
+          if (ORTHO) { SGR_FENCE2(oq.vB); SGR_FENCE2(oq.ff); SGR_FENCE2(oq.vvk); SGR_FENCE2(orow.nwc); SGR_FENCE2(orow.cvc); }
+        }
+        const f32x4 cs = cpt[ap];
+        const f32x2 ca = {cs[0], cs[1]}, sa = {cs[2], cs[3]};
+        f32x2 g[2][3];            // [sign][colour], the azimuth pair (2 ap, 2 ap + 1)
+        if (HAS_GENV) {
+          tile32_read_two_pairs2(cur, pl, ap * 2, HALF + ap * 2, g[0], g[1]);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) g[0][c] = g[1][c] = splat2(0.f);
+        }
+        if (HAS_RENDER) {
+          // the render term of the half row this half-wave owns, then both halves' terms to all lanes
+          const f32x2 Pv = pfma(SGR_HI(oq.vB), sa, SGR_LO(oq.vB) * ca);
+          f32x2 wt, sp;
+          shade_pair<ORTHO>(q, oq, rc, orow, own, ca, sa, Pv, xt, ap * 2, wt, sp);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const f32x2 r_ = wt * pfma(SGR_HI(gds[c]), sp, SGR_LO(gds[c]));
+            float dx = r_.x, sx = r_.x, dy = r_.y, sy = r_.y;
+            swap32(dx, sx);
+            swap32(dy, sy);
+            g[1][c] += f32x2{dx, dy};     // evaluated by lanes 0..31
+            g[0][c] += f32x2{sx, sy};     // evaluated by lanes 32..63
+          }
+        }
+        const f32x2 srv = splat2(sr);
+        const f32x2 sca = srv * ca, ssa = srv * sa;
+#pragma unroll
+        for (int k = 0; k < KPW; ++k) {
+          const f32x2 cz = half_of(czr[k / 2], k & 1), lpk = half_of(P.lpp[k / 2], k & 1), w2 = half_of(P.w2p[k / 2], k & 1);
+          const f32x2 u = pfma(SGR_HI(P.axy[k]), sa, SGR_LO(P.axy[k]) * ca);
+          const f32x2 tp = pfma(srv, u, cz), tm = pfma(-srv, u, cz);
+          const f32x2 xp = lpk * tp, xm = lpk * tm;
+          const f32x2 ep = {fexp2(xp.x), fexp2(xp.y)}, em = {fexp2(xm.x), fexp2(xm.y)};
+          gw0[k] = pfma(g[0][0], ep, gw0[k]); gw1[k] = pfma(g[0][1], ep, gw1[k]); gw2[k] = pfma(g[0][2], ep, gw2[k]);
+          gw0[k] = pfma(g[1][0], em, gw0[k]); gw1[k] = pfma(g[1][1], em, gw1[k]); gw2[k] = pfma(g[1][2], em, gw2[k]);
+          const f32x2 Tp = pfma(g[0][2], w2, pfma(g[0][1], SGR_HI(P.w01[k]), g[0][0] * SGR_LO(P.w01[k]))) * ep;
+          const f32x2 Tm = pfma(g[1][2], w2, pfma(g[1][1], SGR_HI(P.w01[k]), g[1][0] * SGR_LO(P.w01[k]))) * em;
+          gl[k] = pfma(Tp, tp, gl[k]);
+          gl[k] = pfma(Tm, tm, gl[k]);
+          const f32x2 Ts = Tp + Tm, Td = Tp - Tm;
+          gz[k] = pfma(splat2(cr), Ts, gz[k]);
+          gx[k] = pfma(sca, Td, gx[k]);
+          gy[k] = pfma(ssa, Td, gy[k]);
+        }
+      }
+    }
+  };
+  if (ortho) row_loop(std::true_type{}); else row_loop(std::false_type{});
+
+  if (x.active) {
+    float* g_axis_b = a.g_axis + (size_t)b * K * 3 * RC;
+    float* g_lamb_b = a.g_lamb + (size_t)b * K * RC;
+    float* g_weight_b = a.g_weight + (size_t)b * K * 3 * RC;
+#pragma unroll
+    for (int k = 0; k < KPW; ++k) {
+      const int kk = half * KPW + k;
+      if (kk < K) {
+        const unsigned o3 = (unsigned)(kk * 3 * RC + p), o1 = (unsigned)(kk * RC + p);
+        const float lpk = (k & 1) ? P.lpp[k / 2].y : P.lpp[k / 2].x;
+        const float w0 = P.w01[k].x, w1 = P.w01[k].y, w2 = (k & 1) ? P.w2p[k / 2].y : P.w2p[k / 2].x;
+        const float lam = lpk * kLn2;
+        g_axis_b[o3] = lam * (gx[k].x + gx[k].y);
+        g_axis_b[o3 + RC] = lam * (gy[k].x + gy[k].y);
+        g_axis_b[o3 + 2 * RC] = lam * (gz[k].x + gz[k].y);
+        float glk = gl[k].x + gl[k].y, q0 = gw0[k].x + gw0[k].y, q1 = gw1[k].x + gw1[k].y, q2 = gw2[k].x + gw2[k].y;
+        if (a.premap) {
+          glk *= premap_grad(lam);
+          q0 *= premap_grad(w0); q1 *= premap_grad(w1); q2 *= premap_grad(w2);
+        }
+        g_lamb_b[o1] = glk;
+        g_weight_b[o3] = q0;
+        g_weight_b[o3 + RC] = q1;
+        g_weight_b[o3 + 2 * RC] = q2;
+      }
+    }
+  }
+}
+
+}  // namespace sgr

@@ -27,7 +27,8 @@ def direction_table(env_height: int, env_width: int) -> Tuple[np.ndarray, np.nda
 def packed_direction_table(env_height: int, env_width: int) -> np.ndarray:
     """Device layout (flat float32, see include/sgrender.h): ``[Jpad,4] = (lx, ly, lz, omega)`` with zero
     rows up to a multiple of 32, then the separable form ``rows[ehp,8] = (s, c, omega, s^2, 2sc, c^2, 0, 0)``
-    and the azimuth factors of the first half row (``(ca, sa)`` pairs, then ``(ca^2, 2 ca sa, sa^2, 0)``)."""
+    and the azimuth factors of the first half row (``(ca, sa)`` pairs, then ``(ca^2, 2 ca sa, sa^2, 0)``, then
+    -- at float offset ``4*ew`` of the column block -- ``(ca_a, ca_a+1, sa_a, sa_a+1)`` per azimuth pair)."""
     ls, omega = direction_table(env_height, env_width)
     J = ls.shape[0]
     jpad = (J + 31) // 32 * 32
@@ -51,6 +52,10 @@ def packed_direction_table(env_height: int, env_width: int) -> np.ndarray:
     ext = np.zeros((half, 4))
     ext[:, 0], ext[:, 1], ext[:, 2] = ca * ca, 2 * ca * sa, sa * sa
     cols[env_width:env_width + 4 * half] = ext.reshape(-1)
+    #   at float offset 4*ew: [ew/4][4] = (ca_a, ca_a+1, sa_a, sa_a+1) per azimuth pair (packed-math kernels)
+    if half % 2 == 0:
+        pairs = np.stack([ca[0::2], ca[1::2], sa[0::2], sa[1::2]], axis=1)
+        cols[4 * env_width:4 * env_width + 4 * (half // 2)] = pairs.reshape(-1)
     return np.concatenate([gen.reshape(-1), rows.astype(np.float32).reshape(-1), cols.astype(np.float32)])
 
 
