@@ -47,3 +47,10 @@ extern "C" int sgr_render_env_bwd_env(const float* g_diffuse, const float* g_spe
   }
   return sgr_check((int)hipGetLastError(), "sgr_render_env_bwd_env");
 }
+
+#ifdef SGR_TRACE
+// development builds only (tools/wavetrace): where the per-wave trace records of this translation unit's kernels go
+extern "C" int sgr_debug_trace_bwd(void* device_buffer) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(sgr::g_trace), &device_buffer, sizeof(void*));
+}
+#endif

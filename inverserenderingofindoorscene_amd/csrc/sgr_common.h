@@ -18,6 +18,9 @@ namespace sgr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef SGR_DMA_AUX
+#define SGR_DMA_AUX 0   // cache policy of the LDS-DMA row loads: 0 default, 2 non-temporal (A/B switch)
+#endif
 #ifndef SGR_NT
 #define SGR_NT 1   // non-temporal hint on the streamed env tiles (A/B switch)
 #endif
@@ -198,7 +201,7 @@ __device__ __forceinline__ void tile_dma_issue(float* tile, __amdgpu_buffer_rsrc
     for (int c = 0; c < 3; ++c) {
       const int soff = (int)((((size_t)c * RC + p0) * J + j0) * 4);      // wave-uniform byte offset
       float* dst = tile + (c * kWave + it * D::kRowsPerInstr) * TJ;      // wave-uniform, + lane*16 B implicitly
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)dst, 16, voff, soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)dst, 16, voff, soff, 0, SGR_DMA_AUX);
     }
   }
 }
@@ -271,7 +274,7 @@ __device__ __forceinline__ void tile_dma_issue_part(float* tile, __amdgpu_buffer
     for (int c = 0; c < 3; ++c) {
       const int soff = (int)((((size_t)c * RC + p0) * J + j0) * 4);
       float* dst = tile + (c * kWave + it * D::kRowsPerInstr) * TJ;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)dst, 16, voff, soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)dst, 16, voff, soff, 0, SGR_DMA_AUX);
     }
   }
 }
@@ -291,6 +294,7 @@ template <> __device__ __forceinline__ void wait_vmcnt<24>() { asm volatile("s_w
 // env-sized rows of a 32-pixel tile by LDS-DMA: [3][32][16] floats (6 KB), 16-byte slots XOR-swizzled by (row >> 2) & 3
 constexpr int kPx = 32;
 constexpr int kT32Floats = 3 * kPx * 16;
+template <int AUX = SGR_DMA_AUX>
 __device__ __forceinline__ void tile32_dma_issue(float* tile, __amdgpu_buffer_rsrc_t rsrc, int p0, int RC, int J, int j0, int lane) {
   const int lrow = lane >> 2, slot = lane & 3;
 #pragma unroll
@@ -302,7 +306,7 @@ __device__ __forceinline__ void tile32_dma_issue(float* tile, __amdgpu_buffer_rs
     for (int c = 0; c < 3; ++c) {
       const int soff = (int)((((size_t)c * RC + p0) * J + j0) * 4);      // wave-uniform byte offset
       float* dst = tile + (c * kPx + it * 16) * 16;                      // wave-uniform, + lane*16 B implicitly
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)dst, 16, voff, soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)dst, 16, voff, soff, 0, AUX);
     }
   }
 }

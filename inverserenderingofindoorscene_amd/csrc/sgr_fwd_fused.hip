@@ -19,3 +19,10 @@ extern "C" int sgr_fused_fwd(const float* albedo, const float* normal, const flo
   const hipStream_t st = (hipStream_t)stream;
   return sgr_check(env ? fwd_launch<true, true, true>(a, st) : fwd_launch<true, false, true>(a, st), "sgr_fused_fwd");
 }
+
+#ifdef SGR_TRACE
+// development builds only (tools/wavetrace): where the per-wave trace records of this translation unit's kernels go
+extern "C" int sgr_debug_trace_fwd(void* device_buffer) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(sgr::g_trace), &device_buffer, sizeof(void*));
+}
+#endif

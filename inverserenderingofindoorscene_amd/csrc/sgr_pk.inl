@@ -19,6 +19,26 @@
 
 namespace sgr {
 
+// -DSGR_TRACE (development builds only, tools/wavetrace): every wave of the packed kernels records when and where it ran
+#ifdef SGR_TRACE
+struct TraceRec { unsigned long long t0, t1, tp; unsigned hw, xcc; };
+static __device__ TraceRec* g_trace = nullptr;
+#define SGR_TRACE_BEGIN const unsigned long long trace_t0_ = __builtin_amdgcn_s_memrealtime(); unsigned long long trace_tp_ = 0;
+#define SGR_TRACE_MARK trace_tp_ = __builtin_amdgcn_s_memrealtime();
+#define SGR_TRACE_END                                                                                  \
+  if (threadIdx.x == 0 && g_trace) {                                                                   \
+    unsigned hw_, xcc_;                                                                                \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                                  \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                                \
+    TraceRec r_; r_.t0 = trace_t0_; r_.t1 = __builtin_amdgcn_s_memrealtime(); r_.tp = trace_tp_; r_.hw = hw_; r_.xcc = xcc_; \
+    g_trace[blockIdx.x] = r_;                                                                          \
+  }
+#else
+#define SGR_TRACE_BEGIN
+#define SGR_TRACE_MARK
+#define SGR_TRACE_END
+#endif
+
 __device__ __forceinline__ f32x2 splat2(float x) { return f32x2{x, x}; }
 __device__ __forceinline__ f32x2 pfma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 // One half of a register pair as both operands of a packed instruction: folds into the op_sel / op_sel_hi bits of the
@@ -154,10 +174,17 @@ __device__ __forceinline__ void shade_pair(const PixLocal& q, const OrthoPix& oq
 // fwd_fast_kernel's work decomposition (64 pixels per wave, all K <= KP lobes in registers, env rows leave through
 // the 64 x 16 LDS tile) with the arithmetic in azimuth pairs.  Per lobe and azimuth quad: 8 packed U/exponent
 // instructions, 8 v_exp_f32, 12 packed accumulations -- against 40 scalar instructions + 8 v_exp_f32.
+#ifndef SGR_PK_BWD_AUX
+#define SGR_PK_BWD_AUX 2   // cache policy of the packed backward's cotangent rows: 2 = non-temporal (read once)
+#endif
+#ifndef SGR_PK_TJ
+#define SGR_PK_TJ 16      // directions per flushed env tile row: 16 = one table row (64-byte segments), 32 = two rows (128-byte)
+#endif
 template <int KP, int POOL, bool WRITE_ENV, bool DO_RENDER>
 __global__ __launch_bounds__(kWave, 2) void fwd_pk_kernel(const Args a) {
-  constexpr int EW = 16, TJ = 16, HALF = 8, NQ = 2;
+  constexpr int EW = 16, TJ = SGR_PK_TJ, HALF = 8, NQ = 2, RPT = TJ / EW;
   __shared__ __attribute__((aligned(16))) float tile[WRITE_ENV ? Tile<TJ>::kFloats : 4];
+  SGR_TRACE_BEGIN
 
   const Pix x = locate(a);
   const int lane = x.lane, b = x.b, p = x.p;
@@ -182,6 +209,7 @@ __global__ __launch_bounds__(kWave, 2) void fwd_pk_kernel(const Args a) {
   const size_t img = (size_t)b * 3 * RC * a.J;
   const int eh = a.eh;
   f32x2 dacc[3] = {splat2(0.f), splat2(0.f), splat2(0.f)}, sacc[3] = {splat2(0.f), splat2(0.f), splat2(0.f)};
+  SGR_TRACE_MARK
 
   auto row_loop = [&](auto ortho_c) {
     constexpr bool ORTHO = decltype(ortho_c)::value;
@@ -252,13 +280,13 @@ __global__ __launch_bounds__(kWave, 2) void fwd_pk_kernel(const Args a) {
               e1[2 * h] = acc[sg][1][h].x; e1[2 * h + 1] = acc[sg][1][h].y;
               e2[2 * h] = acc[sg][2][h].x; e2[2 * h + 1] = acc[sg][2][h].y;
             }
-            tile_row_write<TJ>(tile, lane, sg * HALF + aq * 4, e0, e1, e2);
+            tile_row_write<TJ>(tile, lane, (e % RPT) * EW + sg * HALF + aq * 4, e0, e1, e2);
           }
         }
       }
-      if (WRITE_ENV) {
+      if (WRITE_ENV && ((e + 1) % RPT == 0 || e + 1 == eh)) {
         __syncthreads();
-        tile_store_global<TJ, true>(tile, a.env_out + img, x.p0, RC, a.J, e * EW, lane);
+        tile_store_global<TJ, true>(tile, a.env_out + img, x.p0, RC, a.J, (e / RPT) * TJ, lane);
         __syncthreads();
       }
     }
@@ -275,6 +303,7 @@ __global__ __launch_bounds__(kWave, 2) void fwd_pk_kernel(const Args a) {
     (a.spec + o + RC)[up] = sacc[1].x + sacc[1].y;
     (a.spec + o + 2 * (size_t)RC)[up] = sacc[2].x + sacc[2].y;
   }
+  SGR_TRACE_END
 }
 
 
@@ -303,7 +332,11 @@ __device__ __forceinline__ void tile32_read_two_pairs2(const float* tile, int pl
 template <int POOL, bool HAS_GENV, bool HAS_RENDER>
 __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
   constexpr int EW = 16, HALF = 8, NP = 4, KPW = 6;
-  __shared__ __attribute__((aligned(16))) float tile[HAS_GENV ? 2 * kT32Floats : 4];
+  // env cotangent rows: a ring of three one-row LDS-DMA buffers (18 KB).  Rows are requested two at a time, back to back
+  // (the two 64-byte halves of every 128-byte line of the image), one row ahead of their use; non-temporal, since the
+  // cotangent is read exactly once and must not push the SG parameters out of the Infinity Cache
+  __shared__ __attribute__((aligned(16))) float tile[HAS_GENV ? 3 * kT32Floats : 4];
+  SGR_TRACE_BEGIN
 
   const int lane = threadIdx.x, half = lane >> 5, pl = lane & 31;
   const int own = 1 - half;                         // the half row (sign) whose BRDF terms this half-wave evaluates
@@ -320,7 +353,10 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
   const int b = x.b, p = x.p;
 
   __amdgpu_buffer_rsrc_t gimg = env_rsrc(HAS_GENV ? a.g_env + (size_t)b * 3 * RC * a.J : a.view, RC, a.J);
-  if (HAS_GENV) tile32_dma_issue(tile, gimg, x.p0, RC, a.J, 0, lane);
+  if (HAS_GENV) {
+    tile32_dma_issue<SGR_PK_BWD_AUX>(tile, gimg, x.p0, RC, a.J, 0, lane);
+    if (a.eh > 1) tile32_dma_issue<SGR_PK_BWD_AUX>(tile + kT32Floats, gimg, x.p0, RC, a.J, EW, lane);
+  }
 
   PixLocal q;
   OrthoPix oq;
@@ -350,17 +386,18 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
   const PairTable cpt = as_pair_table(a.cols, EW);
   const XTable xt = (XTable)(a.cols + EW);
   const int eh = a.eh;
+  SGR_TRACE_MARK
 
   auto row_loop = [&](auto ortho_c) {
     constexpr bool ORTHO = decltype(ortho_c)::value;
     for (int e = 0; e < eh; ++e) {
-      const float* cur = tile + (HAS_GENV ? (e & 1) * kT32Floats : 0);
+      const float* cur = tile + (HAS_GENV ? (e % 3) * kT32Floats : 0);
       if (HAS_GENV) {
-        if (e + 1 < eh) {
-          tile32_dma_issue(tile + ((e + 1) & 1) * kT32Floats, gimg, x.p0, RC, a.J, (e + 1) * EW, lane);
-          wait_vmcnt<6>();        // row e has landed; row e+1 stays in flight
+        // rows e+1, e+2 (e odd) were requested when row e-1 was done; up to two rows (12 instructions) may stay in flight
+        if ((e & 1) == 0) {
+          if (e + 1 < eh) wait_vmcnt<6>(); else wait_vmcnt<0>();          // in flight at most: row e+1
         } else {
-          wait_vmcnt<0>();
+          if (e + 2 < eh) wait_vmcnt<12>(); else if (e + 1 < eh) wait_vmcnt<6>(); else wait_vmcnt<0>();   // rows e+1, e+2
         }
       }
       if (HAS_RENDER && !ORTHO) fence_row_invariants(q);
@@ -427,6 +464,11 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
           gy[k] = pfma(ssa, Td, gy[k]);
         }
       }
+      if (HAS_GENV && (e & 1) == 0) {
+        // row e is consumed: its buffer and the one of row e-1 are free -> request rows e+2 and e+3 back to back
+        if (e + 2 < eh) tile32_dma_issue<SGR_PK_BWD_AUX>(tile + ((e + 2) % 3) * kT32Floats, gimg, x.p0, RC, a.J, (e + 2) * EW, lane);
+        if (e + 3 < eh) tile32_dma_issue<SGR_PK_BWD_AUX>(tile + ((e + 3) % 3) * kT32Floats, gimg, x.p0, RC, a.J, (e + 3) * EW, lane);
+      }
     }
   };
   if (ortho) row_loop(std::true_type{}); else row_loop(std::false_type{});
@@ -458,6 +500,7 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
       }
     }
   }
+  SGR_TRACE_END
 }
 
 }  // namespace sgr
