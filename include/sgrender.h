@@ -19,7 +19,7 @@
  * Shapes:  bn images; K = SGNum lobes per cell (<= SGR_MAX_LOBES); env grid R x C
  *   (envRow x envCol == the renderingLayer ctor's imHeight x imWidth); J = eh*ew
  *   quadrature directions per cell; BRDF maps are imH x imW with imH/R == imW/C in {1, 2}
- *   (other ratios: pool first with sgr_adaptive_avg_pool2d_fwd and pass R x C maps).
+ *   (other ratios: pool first -- the host layer uses torch's adaptive_avg_pool2d, the reference's own op -- and pass R x C maps).
  */
 #ifndef SGRENDER_H_
 #define SGRENDER_H_
@@ -238,6 +238,30 @@ int sgr_light_heads_bwd(const float* x_axis, const float* x_lamb, const float* x
                         const float* g_axis, const float* g_lamb, const float* g_weight, const float* g_packed,
                         float* gx_axis, float* gx_lamb, float* gx_weight,
                         int bn, int K, int R, int C, void* stream);
+
+/* ---- glue either side of the path ---------------------------------------------- */
+
+/* Floats of workspace for the two calls below. */
+int sgr_glue_workspace_floats(int bn);
+
+/* testReal.py:421-432: the global light / albedo scale after LSregressDiffSpec, kept on the device
+ * (the reference reads four sums back with .item()):
+ *   cDiff = sum(diffuse_scaled) / sum(diffuse),  cSpec = sum(spec_scaled) / sum(spec)      (sums over all n elements)
+ *   cSpec < 1e-3 ?  cAlbedo = 1 / max(albedo), cLight = cDiff / cAlbedo
+ *                :  cLight = cSpec, cAlbedo = clip(cDiff / cLight, 1e-3, 1 / max(albedo)), cLight = cDiff / cAlbedo
+ * out4 = (cLight, cAlbedo, cDiff, cSpec).  n = elements of the four render images, n_albedo = elements of albedo. */
+int sgr_light_albedo_scale(const float* diffuse_scaled, const float* diffuse, const float* spec_scaled, const float* spec,
+                           const float* albedo, float* out4, float* workspace, long long n, long long n_albedo, void* stream);
+
+/* wrapperBRDFLight.py:138-156: input of the light encoder from the BRDF predictions,
+ *   out [bn,11,H,W] = cat( resize(im), resize(albedo / max(mean_b(albedo), 1e-10) / 3), 0.5 (resize(normal) + 1),
+ *                          0.5 (resize(rough) + 1), resize(depth / max(mean_b(depth), 1e-10) / 3) )
+ * with resize = F.interpolate(., [H,W], mode='bilinear') (align_corners=False), the means per image over all channels;
+ * also writes the normalised albedo_norm [bn,3,h,w] and depth_norm [bn,1,h,w] the wrapper returns (:139-147).
+ * im, albedo, normal [bn,3,h,w]; rough, depth [bn,1,h,w].  The reference uses H x W = 480 x 640. */
+int sgr_light_input_fwd(const float* im, const float* albedo, const float* normal, const float* rough, const float* depth,
+                        float* out, float* albedo_norm, float* depth_norm, float* workspace, int bn, int h, int w, int H, int W,
+                        void* stream);
 
 #ifdef __cplusplus
 }

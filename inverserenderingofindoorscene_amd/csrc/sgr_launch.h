@@ -10,8 +10,11 @@ void set_error(const char* msg);
 int sgr_check(int hip_rc, const char* who);
 }  // namespace sgr
 
+// Every entry point starts with SGR_REQUIRE: it also drops a (non-sticky) error some other library left pending on this
+// thread, so that the hipGetLastError() after our own launch reports OUR launch and nothing else.
 #define SGR_REQUIRE(cond, msg)          \
   do {                                  \
+    (void)hipGetLastError();            \
     if (!(cond)) {                      \
       ::sgr::set_error(msg);            \
       return SGR_ERR_BAD_ARG;           \
@@ -29,6 +32,6 @@ int sgr_check(int hip_rc, const char* who);
 // SGR_GENERIC=1 forces the table-driven generic kernels (tuning / test knob); read once per process
 #include <stdlib.h>
 static inline bool sgr_generic_forced() {
-  static const bool on = [] { const char* e = getenv("SGR_GENERIC"); return e != nullptr; }();
+  static const bool on = [] { const char* e = getenv("SGR_GENERIC"); return e != nullptr && e[0] != 0 && !(e[0] == '0' && e[1] == 0); }();
   return on;
 }

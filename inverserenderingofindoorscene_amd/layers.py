@@ -27,7 +27,7 @@ import torch.nn.functional as F
 
 from . import _lib, tables
 
-__all__ = ["light_heads", "unpack_envmaps", "output2env", "renderingLayer", "render_from_sg", "renderLayer", "output_radiance", "predToShading"]
+__all__ = ["light_albedo_scale", "light_encoder_input", "light_heads", "unpack_envmaps", "output2env", "renderingLayer", "render_from_sg", "renderLayer", "output_radiance", "predToShading"]
 
 
 # --------------------------------------------------------------------------- #
@@ -492,6 +492,44 @@ def predToShading(pred, envWidth=32, envHeight=16, SGNum=12):
     if is_np:
         return out[0].cpu().numpy() if bn == 1 else out.cpu().numpy()
     return out
+
+
+def light_albedo_scale(diffuseScaled, diffuse, specScaled, spec, albedoPred):
+    """``(cLight, cAlbedo)`` of testReal.py:421-432 as 0-d device tensors (no ``.item()`` round trips): the global light /
+    albedo scale derived from the ratio of the LSregressDiffSpec-scaled to the unscaled render images, clipped by the
+    brightest albedo.  ``envmapsPredImage * cLight`` (testReal.py:431) then stays an asynchronous device multiply."""
+    dev = _require_hip(diffuseScaled, diffuse, specScaled, spec, albedoPred)
+    dn, d, sn, s = (t.detach().contiguous() for t in (diffuseScaled, diffuse, specScaled, spec))
+    if not (dn.shape == d.shape == sn.shape == s.shape):
+        raise RuntimeError("sgrender: light_albedo_scale needs four render images of one shape")
+    alb = albedoPred.detach().contiguous()
+    out = torch.empty(4, device=dev, dtype=torch.float32)
+    ws = torch.empty(_lib.load().sgr_glue_workspace_floats(1), device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _lib.call("sgr_light_albedo_scale", _ptr(dn), _ptr(d), _ptr(sn), _ptr(s), _ptr(alb), _ptr(out), _ptr(ws),
+                  d.numel(), alb.numel(), _stream(dev))
+    return out[0], out[1]
+
+
+def light_encoder_input(imBatch, albedoPred, normalPred, roughPred, depthPred, size=(480, 640)):
+    """The light encoder's input of wrapperBRDFLight.py:138-156 in two HIP launches: per-image mean-normalisation of
+    albedo and depth, bilinear resize of the five maps to ``size`` and their concatenation.
+    Returns ``(inputBatch [bn,11,H,W], albedoPredNormalised, depthPredNormalised)`` (the wrapper returns the normalised
+    maps, :139-147).  Forward only: the reference feeds ``inputBatch.detach()`` to the encoder (:158-161)."""
+    dev = _require_hip(imBatch, albedoPred, normalPred, roughPred, depthPred)
+    im, alb, nrm, rgh, dep = (t.detach().contiguous() for t in (imBatch, albedoPred, normalPred, roughPred, depthPred))
+    bn, _, h, w = im.shape
+    if tuple(alb.shape) != (bn, 3, h, w) or tuple(nrm.shape) != (bn, 3, h, w) or tuple(rgh.shape) != (bn, 1, h, w) or \
+            tuple(dep.shape) != (bn, 1, h, w) or im.shape[1] != 3:
+        raise RuntimeError("sgrender: light_encoder_input takes im/albedo/normal [bn,3,h,w] and rough/depth [bn,1,h,w]")
+    H, W = int(size[0]), int(size[1])
+    out = torch.empty((bn, 11, H, W), device=dev, dtype=torch.float32)
+    alb_n, dep_n = torch.empty_like(alb), torch.empty_like(dep)
+    ws = torch.empty(_lib.load().sgr_glue_workspace_floats(bn), device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _lib.call("sgr_light_input_fwd", _ptr(im), _ptr(alb), _ptr(nrm), _ptr(rgh), _ptr(dep), _ptr(out), _ptr(alb_n), _ptr(dep_n),
+                  _ptr(ws), bn, h, w, H, W, _stream(dev))
+    return out, alb_n, dep_n
 
 
 # --------------------------------------------------------------------------- #

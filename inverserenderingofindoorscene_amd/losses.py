@@ -37,15 +37,20 @@ def _no_coef_grad(*ts):
     for t in ts:
         if t.requires_grad:
             raise NotImplementedError(
-                "sgrender: the regression coefficients are treated as constants (every reference call site passes "
-                "detached / data tensors for the images that define them, e.g. wrapperBRDFLight.py:197-201); "
-                "detach the first arguments")
+                "sgrender: LSregressDiffSpec treats the regression coefficients as constants -- the trainLight / testReal "
+                "call pattern, which passes detached diffuse / specular images as the first two arguments "
+                "(wrapperBRDFLight.py:197-201).  The reference itself does NOT detach coefDiffuse / coefSpecular "
+                "(models.py:44-63), so call sites that pass live tensors there (trainFineTune*_cascade1.py) differentiate "
+                "through them; that mode is a deliberate restriction of this implementation: detach the first two arguments")
 
 
 def LSregress(pred, gt, origin):
-    """``origin * clamp(<pred,gt> / max(<pred,pred>, 1e-5), 1e-3, 1e3)`` per image (models.py:7-21)."""
+    """``origin * clamp(<pred,gt> / max(<pred,pred>, 1e-5), 1e-3, 1e3)`` per image (models.py:7-21).
+
+    Like the reference, the coefficient is a constant in backward whatever ``pred`` carries (models.py:13 detaches it),
+    so grad-carrying ``pred`` tensors are fine (trainBRDF.py:249-254 passes ``albedoPred * seg``); the gradient flows
+    through ``origin`` only."""
     dev = _require_hip(pred, gt, origin)
-    _no_coef_grad(pred)
     nb = pred.shape[0]
     p, g = pred.detach().contiguous(), gt.detach().contiguous()
     coef = torch.empty(nb, device=dev, dtype=torch.float32)
@@ -57,7 +62,9 @@ def LSregress(pred, gt, origin):
 
 def LSregressDiffSpec(diff, spec, imOrig, diffOrig, specOrig):
     """Two-unknown (diffuse, specular) scale regression, then the one-unknown rescale of the clamped
-    sum (models.py:23-84).  Returns ``(diffScaled, specScaled)``."""
+    sum (models.py:23-84).  Returns ``(diffScaled, specScaled)``.
+
+    Restriction: ``diff`` / ``spec`` must not require grad (see ``_no_coef_grad``); ``imOrig`` may."""
     dev = _require_hip(diff, spec, imOrig, diffOrig, specOrig)
     _no_coef_grad(diff, spec)
     nb = diff.shape[0]
@@ -297,7 +304,13 @@ class _LightObjective(torch.autograd.Function):
         dev = g_axis.device
         gs = (g_axis, g_lamb, g_weight)
         if getattr(ctx, "handed_out", False):      # a second backward through this node (retain_graph): the buffers
-            f = g_obj.detach() / applied[0]        # may be somebody's .grad by now -- leave them alone
+            # may be somebody's .grad by now -- leave them alone.  If the first backward came with a zero cotangent the
+            # stored gradients were scaled to zero in place and cannot be recovered: say so instead of returning inf/NaN
+            # (rare path, so the host sync is acceptable)
+            if float(applied[0].item()) == 0.0:
+                raise RuntimeError("sgrender: light_objective was first back-propagated with a zero cotangent; its stored "
+                                   "gradients are gone -- re-evaluate the objective instead of reusing the graph")
+            f = g_obj.detach() / applied[0]
             return tuple([None] * 3 + [g * f if ctx.needs_input_grad[3 + i] else None for i, g in enumerate(gs)] + [None] * 9)
         ctx.handed_out = True
         ptrs = (ctypes.c_void_p * 3)(*[g.data_ptr() for g in gs])

@@ -37,8 +37,22 @@ def test_lsregress_functions_vs_golden(sgr, golden):
     m = seg_s[..., None, None].expand_as(env_gt)
     sc = sgr.LSregress(env * m, env_gt * m, env)
     assert rel_l2(sc.cpu(), z["ref32_env_scaled"]) < 1e-5, name
+    # the reference detaches the coefficient itself (models.py:13): a grad-carrying `pred` is a valid input
+    # (trainBRDF.py:249-254 passes albedoPred * seg) and the gradient flows through `origin` only
+    pred_live = (env * m).clone().requires_grad_(True)
+    origin_live = env.clone().requires_grad_(True)
+    sc2 = sgr.LSregress(pred_live, env_gt * m, origin_live)
+    assert torch.equal(sc2.detach(), sc)
+    ct = torch.randn(sc2.shape, generator=torch.Generator().manual_seed(3)).cuda()
+    g_origin, g_pred = torch.autograd.grad((sc2 * ct).sum(), [origin_live, pred_live], allow_unused=True)
+    assert g_pred is None or float(g_pred.abs().max()) == 0.0
+    nb = env.shape[0]
+    pm, gm = (env * m).reshape(nb, -1).double(), (env_gt * m).reshape(nb, -1).double()
+    coef = torch.clamp((pm * gm).sum(1) / torch.clamp((pm * pm).sum(1), min=1e-5), 0.001, 1000.0).reshape(nb, 1, 1, 1, 1, 1)
+    assert rel_l2(g_origin.cpu(), (ct.double() * coef).cpu()) < 1e-5, name
+    # LSregressDiffSpec: the trainLight call pattern (detached first arguments) only -- a deliberate restriction
     with pytest.raises(NotImplementedError):
-        sgr.LSregress(env.clone().requires_grad_(True), env_gt, env)
+        sgr.LSregressDiffSpec(d.clone().requires_grad_(True), s, im_s, d, s)
 
 
 def test_render_loss_vs_golden(sgr, golden):
