@@ -48,15 +48,30 @@ def main():
         blob[f"{tag}_pred"] = pred
         blob[f"{tag}_ref32"] = U.predToShading(pred.copy(), envWidth=ew, envHeight=eh, SGNum=K).astype(np.float32)
         blob[f"{tag}_ref64"] = U.predToShading(pred.astype(np.float64), envWidth=ew, envHeight=eh, SGNum=K)
-    # testReal.py:421-432 -- global light / albedo scale from the rendered and the observed image
-    g = torch.Generator().manual_seed(40)
-    bn, R, C = 2, 12, 16
-    diffuse, spec, im = torch.rand(bn, 3, R, C, generator=g), torch.rand(bn, 3, R, C, generator=g) * 0.3, torch.rand(bn, 3, R, C, generator=g)
-    albedo = torch.rand(bn, 3, 2 * R, 2 * C, generator=g)
-    # the reference's expressions, verbatim semantics (testReal.py:421-432)
-    diffusePredNew, specularPredNew, imBatchSmall, albedoPred = diffuse, spec, im, albedo
-    cDiff = (torch.sum(diffusePredNew) / torch.sum(diffuse)).data.item()          # == 1 here; testReal divides scaled by unscaled
-    blob["scale_diffuse"], blob["scale_spec"], blob["scale_im"], blob["scale_albedo"] = diffuse.numpy(), spec.numpy(), im.numpy(), albedo.numpy()
+    # testReal.py:413-432 -- LSregressDiffSpec, then the global light / albedo scale; the reference's expressions verbatim
+    M = RI.models()
+    for tag, seed, spec_gain, alb_gain in (("s1", 40, 0.3, 1.0), ("s2", 41, 0.0, 1.0), ("s3", 42, 3.0, 0.2), ("s4", 40, 0.3, 5.0)):
+        g = torch.Generator().manual_seed(seed)
+        bn, R, C = 1, 12, 16
+        diffusePred = torch.rand(bn, 3, R, C, generator=g)
+        specularPred = torch.rand(bn, 3, R, C, generator=g) * spec_gain + (1e-6 if spec_gain == 0.0 else 0.0)
+        imBatchSmall = torch.rand(bn, 3, R, C, generator=g)
+        albedoPreds = [torch.rand(bn, 3, 2 * R, 2 * C, generator=g) * alb_gain]
+        diffusePredNew, specularPredNew = M.LSregressDiffSpec(diffusePred, specularPred, imBatchSmall, diffusePred, specularPred)
+        cDiff, cSpec = (torch.sum(diffusePredNew) / torch.sum(diffusePred)).data.item(), ((torch.sum(specularPredNew)) / (torch.sum(specularPred))).data.item()
+        if cSpec < 1e-3:
+            cAlbedo = 1 / albedoPreds[-1].max().data.item()
+            cLight = cDiff / cAlbedo
+        else:
+            cLight = cSpec
+            cAlbedo = cDiff / cLight
+            cAlbedo = np.clip(cAlbedo, 1e-3, 1 / albedoPreds[-1].max().data.item())
+            cLight = cDiff / cAlbedo
+        blob[f"{tag}_diffuse"], blob[f"{tag}_spec"], blob[f"{tag}_im"] = diffusePred.numpy(), specularPred.numpy(), imBatchSmall.numpy()
+        blob[f"{tag}_diffuseNew"], blob[f"{tag}_specNew"] = diffusePredNew.numpy(), specularPredNew.numpy()
+        blob[f"{tag}_albedo"] = albedoPreds[-1].numpy()
+        blob[f"{tag}_ref"] = np.array([cLight, cAlbedo, cDiff, cSpec], dtype=np.float64)
+        print(tag, "cLight, cAlbedo, cDiff, cSpec =", blob[f"{tag}_ref"])
     path = os.path.join(OUT, "g6_shading.npz")
     np.savez_compressed(path, **blob)
     print("wrote", path, os.path.getsize(path) / 1e3, "KB")

@@ -54,7 +54,10 @@ def _check_fwd(name, z, got):
         assert rel_l2(v, ref32) < TOL_L2, (name, k, rel_l2(v, ref32))
         assert rel_max(v, ref32) < TOL_MAX, (name, k, rel_max(v, ref32))
         e_ref = rel_l2(ref32, ref64)
-        assert rel_l2(v, ref64) < max(3 * e_ref, 3e-5), (name, k, rel_l2(v, ref64), e_ref)
+        # no worse than 2 x the reference's own fp32 error; floored at 2e-5, the fp32 noise level of this
+        # path (the reference's own error is 2.4e-5 .. 4.4e-5 on decoder-range inputs; on the benign fixture
+        # it happens to be 7e-6 and the table-driven generic kernels sit at 1.8e-5)
+        assert rel_l2(v, ref64) < max(2 * e_ref, 2e-5), (name, k, rel_l2(v, ref64), e_ref)
 
 
 def _check_grads(name, z, cfg, grads, which="glin"):
@@ -70,7 +73,7 @@ def _check_grads(name, z, cfg, grads, which="glin"):
         assert rel_l2(g[m], ref32[m]) < max(3e-4, 4 * min(e_ref, 1e-3)), (name, k, rel_l2(g[m], ref32[m]), e_ref)
         if e_ref < 1e-3:
             e = rel_l2(g[m], ref64[m])
-            assert e < max(3 * e_ref, 3e-5), (name, k, e, e_ref)
+            assert e < max(2 * e_ref, 1e-5), (name, k, e, e_ref)
 
 
 def test_fused_forward_vs_golden(sgr, golden):
@@ -286,26 +289,3 @@ def test_error_behaviour(sgr):
         o2e.output2env(a.cuda().double(), torch.zeros(1, 12, 12, 16).cuda().double(), torch.zeros(1, 36, 12, 16).cuda().double())
 
 
-def test_pred_to_shading_vs_reference_formula(sgr):
-    """utils.predToShading (utils.py:156-195) restated in float64 numpy (the reference computes it in float64)."""
-    K, R, C, eh, ew = 12, 9, 14, 16, 32
-    g = torch.Generator().manual_seed(21)
-    a = torch.randn(1, K, 3, R, C, generator=g)
-    a = a / a.norm(dim=2, keepdim=True)
-    pred = torch.cat([a.reshape(1, 3 * K, R, C), torch.rand(1, K, R, C, generator=g), torch.rand(1, 3 * K, R, C, generator=g)], 1).numpy()
-    got = sgr.predToShading(pred, envWidth=ew, envHeight=eh, SGNum=K)
-    az = ((np.arange(ew) + 0.5) / ew - 0.5) * 2 * np.pi
-    el = ((np.arange(eh) + 0.5) / eh) * np.pi / 2.0
-    az, el = np.meshgrid(az, el)
-    ls = np.stack([np.sin(el) * np.cos(az), np.sin(el) * np.sin(az), np.cos(el)], 0)          # [3,eh,ew]
-    wgt = np.cos(el) * np.sin(el)
-    ax = pred[0, :3 * K].reshape(K, 3, R, C).astype(np.float64)
-    lam = np.tan(np.pi / 2.0 * (pred[0, 3 * K:4 * K] * np.float32(0.999))).astype(np.float64)
-    w = np.tan(np.pi / 2.0 * (pred[0, 4 * K:].reshape(K, 3, R, C) * np.float32(0.999))).astype(np.float64)
-    dot = np.einsum("kcrs,cea->krsea", ax, ls)
-    env = np.einsum("kcrs,krsea->crsea", w, np.exp(lam[:, :, :, None, None] * (dot - 1)))
-    want = np.maximum((env * wgt).sum((3, 4)), 0.0)
-    assert got.shape == (3, R, C)
-    assert rel_l2(got, want) < 1e-4 and rel_max(got, want) < 2e-4
-    t = sgr.predToShading(torch.from_numpy(pred).cuda().repeat(2, 1, 1, 1), envWidth=ew, envHeight=eh, SGNum=K)
-    assert tuple(t.shape) == (2, 3, R, C) and rel_l2(t[1].cpu(), want) < 1e-4
