@@ -24,6 +24,8 @@
 #ifndef SGRENDER_H_
 #define SGRENDER_H_
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -102,6 +104,32 @@ int sgr_fused_bwd_sg(const float* g_env /* nullable */, const float* g_diffuse, 
                      float* g_axis, float* g_lamb, float* g_weight,
                      int bn, int K, int R, int C, int eh, int ew, int imH, int imW, float F0,
                      int premap, void* stream);
+
+/* The same two calls (wrapperBRDFLight.py:177+194 and their autograd) with a caller-owned workspace of
+ * sgr_span_workspace_bytes() bytes of device memory.  With it, and when the batch holds more work units than the
+ * chip has wave slots, the kernels are launched as one wave per slot, each taking an equally long run of
+ * (pixel group, table row) items ("row spans"), so no slot idles in a last partial round: at 16 images of
+ * 120 x 160 cells that is worth 15-20 % of the kernel time.  A group shared by two waves is finished by the wave
+ * that owns its first rows, which adds the other wave's partial sums (handed over through the workspace) to its
+ * own: results are deterministic for a given device; for shared groups they differ from the one-group-per-wave
+ * launch by the rounding of one extra addition (diffuse/spec and the SG gradients; the env image is bit-identical).
+ *   workspace contract: zero-filled before its first use; every call leaves it zero-filled where that matters,
+ *   so it can be reused call after call on the SAME stream; calls that may run concurrently (different streams)
+ *   need their own workspaces.  NULL / too small: identical to the calls without _ws.  SGR_SPAN=0 disables. */
+size_t sgr_span_workspace_bytes(void);
+int sgr_fused_fwd_ws(const float* albedo, const float* normal, const float* rough,
+                     const float* axis, const float* lamb, const float* weight,
+                     const float* dirs, const float* view,
+                     float* env /* nullable */, float* diffuse, float* spec,
+                     int bn, int K, int R, int C, int eh, int ew, int imH, int imW, float F0,
+                     int premap, void* workspace /* nullable */, size_t workspace_bytes, void* stream);
+int sgr_fused_bwd_sg_ws(const float* g_env /* nullable */, const float* g_diffuse, const float* g_spec,
+                        const float* albedo, const float* normal, const float* rough,
+                        const float* axis, const float* lamb, const float* weight,
+                        const float* dirs, const float* view,
+                        float* g_axis, float* g_lamb, float* g_weight,
+                        int bn, int K, int R, int C, int eh, int ew, int imH, int imW, float F0,
+                        int premap, void* workspace /* nullable */, size_t workspace_bytes, void* stream);
 
 /* dL/dEnv of renderingLayer.forwardEnv alone (autograd of models.py:511-520):
  *   g_env[b,c,r,cc,j] = omega_j ndl_j (g_diffuse_c A_c/pi + g_spec_c spec_j)   (out, dense) */

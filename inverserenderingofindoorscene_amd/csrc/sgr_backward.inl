@@ -242,10 +242,15 @@ static int sgbwd_half_launch(const Args& a, hipStream_t st) {
 template <bool HAS_GENV, bool HAS_RENDER>
 static int sgbwd_pk_launch(const Args& a, hipStream_t st) {
   const dim3 grid((unsigned)(a.bn * ((a.R * a.C + kPx - 1) / kPx))), block(kWave);
-  if (!HAS_RENDER || (a.imH == a.R && a.imW == a.C))
-    hipLaunchKernelGGL((sg_bwd_pk_kernel<1, HAS_GENV, HAS_RENDER>), grid, block, 0, st, a);
-  else
-    hipLaunchKernelGGL((sg_bwd_pk_kernel<2, HAS_GENV, HAS_RENDER>), grid, block, 0, st, a);
+  const bool p1 = !HAS_RENDER || (a.imH == a.R && a.imW == a.C);
+  if (span_enabled(a, (int)grid.x)) {      // row-span launch, see fwd_pk_launch
+    const dim3 sgrid((unsigned)a.span_waves);
+    if (p1) hipLaunchKernelGGL((sg_bwd_pk_span_kernel<1, HAS_GENV, HAS_RENDER>), sgrid, block, 0, st, a);
+    else hipLaunchKernelGGL((sg_bwd_pk_span_kernel<2, HAS_GENV, HAS_RENDER>), sgrid, block, 0, st, a);
+    return (int)hipGetLastError();
+  }
+  if (p1) hipLaunchKernelGGL((sg_bwd_pk_kernel<1, HAS_GENV, HAS_RENDER>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((sg_bwd_pk_kernel<2, HAS_GENV, HAS_RENDER>), grid, block, 0, st, a);
   return (int)hipGetLastError();
 }
 static inline int bwd_mode() {     // 4 packed half-wave (default), 0 split (two waves), 2 / 3 scalar half-wave kernel built for that many waves per SIMD

@@ -457,6 +457,10 @@ struct Args {
   int bn, K, R, C, J, Jpad, imH, imW, eh, ew;
   float F0;
   int premap;
+  // row-span launches of the packed kernels (sgr_pk.inl); span_flags == NULL: one group per workgroup
+  unsigned* span_flags;   // [span_waves]  zero on entry, zero again on exit
+  float* span_part;       // [span_waves][42][64] partial results handed from a wave to its predecessor
+  int span_waves;         // workgroups in the grid (the chip's wave slots at two waves per SIMD)
 };
 
 // Which pixel does this lane own?  One wave = 64 consecutive cells of one image.

@@ -178,10 +178,15 @@ static int fwd_half_launch(const Args& a, hipStream_t st) {
 template <int KP, bool WRITE_ENV, bool DO_RENDER>
 static int fwd_pk_launch(const Args& a, hipStream_t st) {
   const dim3 grid = wave_grid(a.bn, a.R, a.C), block(kWave);
-  if (!DO_RENDER || (a.imH == a.R && a.imW == a.C))
-    hipLaunchKernelGGL((fwd_pk_kernel<KP, 1, WRITE_ENV, DO_RENDER>), grid, block, 0, st, a);
-  else
-    hipLaunchKernelGGL((fwd_pk_kernel<KP, 2, WRITE_ENV, DO_RENDER>), grid, block, 0, st, a);
+  const bool p1 = !DO_RENDER || (a.imH == a.R && a.imW == a.C);
+  if (KP == 12 && span_enabled(a, (int)grid.x)) {      // row-span launch: one wave per wave slot of the chip (workspace given, more groups than slots)
+    const dim3 sgrid((unsigned)a.span_waves);
+    if (p1) hipLaunchKernelGGL((fwd_pk_span_kernel<KP, 1, WRITE_ENV, DO_RENDER>), sgrid, block, 0, st, a);
+    else hipLaunchKernelGGL((fwd_pk_span_kernel<KP, 2, WRITE_ENV, DO_RENDER>), sgrid, block, 0, st, a);
+    return (int)hipGetLastError();
+  }
+  if (p1) hipLaunchKernelGGL((fwd_pk_kernel<KP, 1, WRITE_ENV, DO_RENDER>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((fwd_pk_kernel<KP, 2, WRITE_ENV, DO_RENDER>), grid, block, 0, st, a);
   return (int)hipGetLastError();
 }
 static inline int fwd_mode() {     // 4 packed (default), 0 scalar one pixel per lane, 2 / 3 scalar half-wave kernel, -1 round-1 default
@@ -201,7 +206,7 @@ static int fwd_fast_launch(const Args& a, hipStream_t st) {
   // measured at config 2, one pixel per lane / half-wave: in the bench loop (working set cycling through HBM) env + render
   // 239 / 206 us, render only 163 / 172 us; relaunched on the same buffers (tools/kbench, inputs partly cache-resident)
   // env + render 214-223 / 209-219 us, env only 178 / 149 us  ->  half-wave whenever the env image is written
-  if (fwd_mode() == 4 && a.ew == 16 && a.K <= 12)
+  if (fwd_mode() == 4 && a.ew == 16 && a.K <= 12)      // (K <= 6: fewer than 170 VGPRs, three waves fit a SIMD -> no row spans)
     return a.K <= 6 ? fwd_pk_launch<6, WRITE_ENV, DO_RENDER>(a, st) : fwd_pk_launch<12, WRITE_ENV, DO_RENDER>(a, st);
   const int mode = (fwd_mode() >= 0 && fwd_mode() != 4) ? fwd_mode() : (WRITE_ENV ? 2 : 0);
   if (a.ew == 16 && a.K > 6 && a.K <= 12 && mode != 0)

@@ -52,6 +52,35 @@ __device__ __forceinline__ f32x2 half_of(f32x2 p, int i) { return i ? SGR_HI(p) 
 typedef const f32x4 __attribute__((address_space(4))) * PairTable;   // per azimuth pair: (ca_a, ca_a+1, sa_a, sa_a+1)
 __device__ __forceinline__ PairTable as_pair_table(const float* cols, int ew) { return (PairTable)(cols + 4 * ew); }
 
+// ---- row-span hand-off between two consecutive waves (agent scope: the waves may sit on different XCDs) ----------
+// flags[w] is 0 on entry to the kernel, set by wave w once its partial results are in span_part, and cleared again by
+// wave w - 1 after it has read them: the workspace leaves every launch as it entered it.
+__device__ __forceinline__ void span_publish(unsigned* flags, int w) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  if (threadIdx.x == 0) __hip_atomic_store(flags + w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void span_acquire(unsigned* flags, int w) {
+  while (__hip_atomic_load(flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+__device__ __forceinline__ void span_release(unsigned* flags, int w) {
+  if (threadIdx.x == 0) __hip_atomic_store(flags + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the PX-pixel group `g` of the batch (PX = 64: one pixel per lane; 32: lanes l and l + 32 share a pixel)
+template <int PX>
+__device__ __forceinline__ Pix locate_group(const Args& a, int g) {
+  Pix x;
+  x.lane = threadIdx.x;
+  const int RC = a.R * a.C;
+  const int tiles = (RC + PX - 1) / PX;
+  const int pl = x.lane & (PX - 1);
+  x.b = g / tiles;
+  x.p0 = (g - x.b * tiles) * PX;
+  x.active = (x.p0 + pl) < RC;
+  x.p = x.active ? (x.p0 + pl) : (RC - 1);
+  return x;
+}
+
 // SG parameters of the lane's pixel in register pairs (KP even; lobes past K carry zero weights).
 // FOLD: axis pre-multiplied by lp = lam * log2e (forward); unit axes otherwise (backward).
 template <int KP>
@@ -180,18 +209,20 @@ __device__ __forceinline__ void shade_pair(const PixLocal& q, const OrthoPix& oq
 #ifndef SGR_PK_TJ
 #define SGR_PK_TJ 16      // directions per flushed env tile row: 16 = one table row (64-byte segments), 32 = two rows (128-byte)
 #endif
-template <int KP, int POOL, bool WRITE_ENV, bool DO_RENDER>
-__global__ __launch_bounds__(kWave, 2) void fwd_pk_kernel(const Args a) {
-  constexpr int EW = 16, TJ = SGR_PK_TJ, HALF = 8, NQ = 2, RPT = TJ / EW;
-  __shared__ __attribute__((aligned(16))) float tile[WRITE_ENV ? Tile<TJ>::kFloats : 4];
-  SGR_TRACE_BEGIN
-
-  const Pix x = locate(a);
+// One work item of the packed forward: table rows [r0, r1) of the 64-pixel group `g`.  SPAN = false: the whole group
+// (r0 = 0, r1 = eh), results stored directly.  SPAN = true (row-span kernels below): a group may be shared by two
+// consecutive waves; the wave that owns its last rows publishes its partial radiance sums, the wave that owns row 0 adds
+// them to its own and stores.
+template <int KP, int POOL, int TJ, bool WRITE_ENV, bool DO_RENDER, bool SPAN>
+__device__ __forceinline__ void fwd_pk_group(const Args& a, float* tile, const int g, const int r0, const int r1, const int w) {
+  constexpr int EW = 16, HALF = 8, NQ = 2, RPT = TJ / EW;
+  static_assert(!SPAN || RPT == 1, "row spans flush one table row at a time");
+  const Pix x = locate_group<kWave>(a, g);
   const int lane = x.lane, b = x.b, p = x.p;
   const int RC = a.R * a.C;
 
   LobesPk<KP> P;
-  load_lobes_pk<KP, true>(a, b, (unsigned)p, x.active, 0, P, true);
+  load_lobes_pk<KP, true>(a, b, (unsigned)p, x.active, 0, P, r0 == 0);
 
   PixLocal q;
   OrthoPix oq;
@@ -207,13 +238,11 @@ __global__ __launch_bounds__(kWave, 2) void fwd_pk_kernel(const Args a) {
   const PairTable cpt = as_pair_table(a.cols, EW);
   const XTable xt = (XTable)(a.cols + EW);
   const size_t img = (size_t)b * 3 * RC * a.J;
-  const int eh = a.eh;
   f32x2 dacc[3] = {splat2(0.f), splat2(0.f), splat2(0.f)}, sacc[3] = {splat2(0.f), splat2(0.f), splat2(0.f)};
-  SGR_TRACE_MARK
 
   auto row_loop = [&](auto ortho_c) {
     constexpr bool ORTHO = decltype(ortho_c)::value;
-    for (int e = 0; e < eh; ++e) {
+    for (int e = r0; e < r1; ++e) {
       if (DO_RENDER && !ORTHO) fence_row_invariants(q);
       const f32x8 row = rows[e];
       const float sr = row[0];
@@ -284,7 +313,7 @@ __global__ __launch_bounds__(kWave, 2) void fwd_pk_kernel(const Args a) {
           }
         }
       }
-      if (WRITE_ENV && ((e + 1) % RPT == 0 || e + 1 == eh)) {
+      if (WRITE_ENV && ((e + 1) % RPT == 0 || e + 1 == r1)) {
         __syncthreads();
         tile_store_global<TJ, true>(tile, a.env_out + img, x.p0, RC, a.J, (e / RPT) * TJ, lane);
         __syncthreads();
@@ -293,15 +322,64 @@ __global__ __launch_bounds__(kWave, 2) void fwd_pk_kernel(const Args a) {
   };
   if (ortho) row_loop(std::true_type{}); else row_loop(std::false_type{});
 
-  if (DO_RENDER && x.active) {
-    const size_t o = (size_t)b * 3 * RC;
-    const unsigned up = (unsigned)p;
-    (a.diffuse + o)[up] = (alb[0] * kInvPi) * (dacc[0].x + dacc[0].y);
-    (a.diffuse + o + RC)[up] = (alb[1] * kInvPi) * (dacc[1].x + dacc[1].y);
-    (a.diffuse + o + 2 * (size_t)RC)[up] = (alb[2] * kInvPi) * (dacc[2].x + dacc[2].y);
-    (a.spec + o)[up] = sacc[0].x + sacc[0].y;
-    (a.spec + o + RC)[up] = sacc[1].x + sacc[1].y;
-    (a.spec + o + 2 * (size_t)RC)[up] = sacc[2].x + sacc[2].y;
+  if (DO_RENDER) {
+    float o6[6] = {(alb[0] * kInvPi) * (dacc[0].x + dacc[0].y), (alb[1] * kInvPi) * (dacc[1].x + dacc[1].y),
+                   (alb[2] * kInvPi) * (dacc[2].x + dacc[2].y), sacc[0].x + sacc[0].y, sacc[1].x + sacc[1].y, sacc[2].x + sacc[2].y};
+    if (SPAN && r0 > 0) {
+      // the group's last rows (first item of this wave's span): hand the partial sums to wave w - 1
+      float* part = a.span_part + (size_t)w * (6 * kWave) + lane;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) part[i * kWave] = o6[i];
+      span_publish(a.span_flags, w);
+      return;
+    }
+    if (SPAN && r1 < a.eh) {
+      // the group's first rows (last item of this wave's span): wave w + 1 published the rest long ago
+      span_acquire(a.span_flags, w + 1);
+      const float* part = a.span_part + (size_t)(w + 1) * (6 * kWave) + lane;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) o6[i] += part[i * kWave];
+      span_release(a.span_flags, w + 1);
+    }
+    if (x.active) {
+      const size_t o = (size_t)b * 3 * RC;
+      const unsigned up = (unsigned)p;
+      (a.diffuse + o)[up] = o6[0];
+      (a.diffuse + o + RC)[up] = o6[1];
+      (a.diffuse + o + 2 * (size_t)RC)[up] = o6[2];
+      (a.spec + o)[up] = o6[3];
+      (a.spec + o + RC)[up] = o6[4];
+      (a.spec + o + 2 * (size_t)RC)[up] = o6[5];
+    }
+  }
+}
+
+// one 64-pixel group per single-wave workgroup
+template <int KP, int POOL, bool WRITE_ENV, bool DO_RENDER>
+__global__ __launch_bounds__(kWave, 2) void fwd_pk_kernel(const Args a) {
+  constexpr int TJ = SGR_PK_TJ;
+  __shared__ __attribute__((aligned(16))) float tile[WRITE_ENV ? Tile<TJ>::kFloats : 4];
+  SGR_TRACE_BEGIN
+  fwd_pk_group<KP, POOL, TJ, WRITE_ENV, DO_RENDER, false>(a, tile, (int)blockIdx.x, 0, a.eh, 0);
+  SGR_TRACE_END
+}
+
+// Row-span ("stream-K") launch: a.span_waves single-wave workgroups -- as many as the chip holds at two per SIMD -- each
+// take a contiguous, equally long run of the (group, table row) sequence, so every wave slot is busy for the whole
+// kernel whatever the number of groups (at 16 images the 4800 groups are 2.34 per slot: one group per workgroup leaves
+// the slots idle for 22 % of the kernel).  Runs are at least eh rows long, so a group is shared by at most two waves.
+template <int KP, int POOL, bool WRITE_ENV, bool DO_RENDER>
+__global__ __launch_bounds__(kWave, 2) void fwd_pk_span_kernel(const Args a) {
+  __shared__ __attribute__((aligned(16))) float tile[WRITE_ENV ? Tile<16>::kFloats : 4];
+  SGR_TRACE_BEGIN
+  const int eh = a.eh, w = (int)blockIdx.x;
+  const long long U = (long long)a.bn * ((a.R * a.C + kWave - 1) / kWave) * eh;
+  int u = (int)(U * w / a.span_waves);
+  const int u1 = (int)(U * (w + 1) / a.span_waves);
+  while (u < u1) {
+    const int g = u / eh, r0 = u - g * eh, r1 = min(eh, r0 + (u1 - u));
+    fwd_pk_group<KP, POOL, 16, WRITE_ENV, DO_RENDER, true>(a, tile, g, r0, r1, w);
+    u += r1 - r0;
   }
   SGR_TRACE_END
 }
@@ -329,33 +407,24 @@ __device__ __forceinline__ void tile32_read_two_pairs2(const float* tile, int pl
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int POOL, bool HAS_GENV, bool HAS_RENDER>
-__global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
+// One work item of the packed backward: table rows [r0, r1) of the 32-pixel group `g` (see fwd_pk_group for SPAN).
+// `tile`: a ring of three one-row LDS-DMA buffers (18 KB).  Rows are requested two at a time, back to back (the two
+// 64-byte halves of every 128-byte line of the image), one row ahead of their use; non-temporal, since the cotangent is
+// read exactly once and must not push the SG parameters out of the Infinity Cache
+template <int POOL, bool HAS_GENV, bool HAS_RENDER, bool SPAN>
+__device__ __forceinline__ void sg_bwd_pk_group(const Args& a, float* tile, const int g, const int r0, const int r1, const int w) {
   constexpr int EW = 16, HALF = 8, NP = 4, KPW = 6;
-  // env cotangent rows: a ring of three one-row LDS-DMA buffers (18 KB).  Rows are requested two at a time, back to back
-  // (the two 64-byte halves of every 128-byte line of the image), one row ahead of their use; non-temporal, since the
-  // cotangent is read exactly once and must not push the SG parameters out of the Infinity Cache
-  __shared__ __attribute__((aligned(16))) float tile[HAS_GENV ? 3 * kT32Floats : 4];
-  SGR_TRACE_BEGIN
-
   const int lane = threadIdx.x, half = lane >> 5, pl = lane & 31;
   const int own = 1 - half;                         // the half row (sign) whose BRDF terms this half-wave evaluates
   const int RC = a.R * a.C, K = a.K;
-  Pix x;
-  x.lane = lane;
-  {
-    const int tiles = (RC + kPx - 1) / kPx;
-    x.b = blockIdx.x / tiles;
-    x.p0 = (blockIdx.x - x.b * tiles) * kPx;
-    x.active = (x.p0 + pl) < RC;
-    x.p = x.active ? (x.p0 + pl) : (RC - 1);
-  }
+  const Pix x = locate_group<kPx>(a, g);
   const int b = x.b, p = x.p;
+  const int nr = r1 - r0;
 
   __amdgpu_buffer_rsrc_t gimg = env_rsrc(HAS_GENV ? a.g_env + (size_t)b * 3 * RC * a.J : a.view, RC, a.J);
   if (HAS_GENV) {
-    tile32_dma_issue<SGR_PK_BWD_AUX>(tile, gimg, x.p0, RC, a.J, 0, lane);
-    if (a.eh > 1) tile32_dma_issue<SGR_PK_BWD_AUX>(tile + kT32Floats, gimg, x.p0, RC, a.J, EW, lane);
+    tile32_dma_issue<SGR_PK_BWD_AUX>(tile, gimg, x.p0, RC, a.J, r0 * EW, lane);
+    if (nr > 1) tile32_dma_issue<SGR_PK_BWD_AUX>(tile + kT32Floats, gimg, x.p0, RC, a.J, (r0 + 1) * EW, lane);
   }
 
   PixLocal q;
@@ -385,19 +454,18 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
   const SepTable rows = as_sep_table(a.rows);
   const PairTable cpt = as_pair_table(a.cols, EW);
   const XTable xt = (XTable)(a.cols + EW);
-  const int eh = a.eh;
-  SGR_TRACE_MARK
 
   auto row_loop = [&](auto ortho_c) {
     constexpr bool ORTHO = decltype(ortho_c)::value;
-    for (int e = 0; e < eh; ++e) {
-      const float* cur = tile + (HAS_GENV ? (e % 3) * kT32Floats : 0);
+    for (int i = 0; i < nr; ++i) {
+      const int e = r0 + i;
+      const float* cur = tile + (HAS_GENV ? (i % 3) * kT32Floats : 0);
       if (HAS_GENV) {
-        // rows e+1, e+2 (e odd) were requested when row e-1 was done; up to two rows (12 instructions) may stay in flight
-        if ((e & 1) == 0) {
-          if (e + 1 < eh) wait_vmcnt<6>(); else wait_vmcnt<0>();          // in flight at most: row e+1
+        // rows i+1, i+2 (i odd) were requested when row i-1 was done; up to two rows (12 instructions) may stay in flight
+        if ((i & 1) == 0) {
+          if (i + 1 < nr) wait_vmcnt<6>(); else wait_vmcnt<0>();          // in flight at most: row i+1
         } else {
-          if (e + 2 < eh) wait_vmcnt<12>(); else if (e + 1 < eh) wait_vmcnt<6>(); else wait_vmcnt<0>();   // rows e+1, e+2
+          if (i + 2 < nr) wait_vmcnt<12>(); else if (i + 1 < nr) wait_vmcnt<6>(); else wait_vmcnt<0>();   // rows i+1, i+2
         }
       }
       if (HAS_RENDER && !ORTHO) fence_row_invariants(q);
@@ -464,15 +532,52 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
           gy[k] = pfma(ssa, Td, gy[k]);
         }
       }
-      if (HAS_GENV && (e & 1) == 0) {
-        // row e is consumed: its buffer and the one of row e-1 are free -> request rows e+2 and e+3 back to back
-        if (e + 2 < eh) tile32_dma_issue<SGR_PK_BWD_AUX>(tile + ((e + 2) % 3) * kT32Floats, gimg, x.p0, RC, a.J, (e + 2) * EW, lane);
-        if (e + 3 < eh) tile32_dma_issue<SGR_PK_BWD_AUX>(tile + ((e + 3) % 3) * kT32Floats, gimg, x.p0, RC, a.J, (e + 3) * EW, lane);
+      if (HAS_GENV && (i & 1) == 0) {
+        // row i is consumed: its buffer and the one of row i-1 are free -> request rows i+2 and i+3 back to back
+        if (i + 2 < nr) tile32_dma_issue<SGR_PK_BWD_AUX>(tile + ((i + 2) % 3) * kT32Floats, gimg, x.p0, RC, a.J, (e + 2) * EW, lane);
+        if (i + 3 < nr) tile32_dma_issue<SGR_PK_BWD_AUX>(tile + ((i + 3) % 3) * kT32Floats, gimg, x.p0, RC, a.J, (e + 3) * EW, lane);
       }
     }
   };
   if (ortho) row_loop(std::true_type{}); else row_loop(std::false_type{});
 
+  // the lane's 42 results (7 per lobe), chain rule of the pre-map included; every one is linear in the accumulators
+  float o[KPW][7];
+#pragma unroll
+  for (int k = 0; k < KPW; ++k) {
+    const float lpk = (k & 1) ? P.lpp[k / 2].y : P.lpp[k / 2].x;
+    const float w0 = P.w01[k].x, w1 = P.w01[k].y, w2 = (k & 1) ? P.w2p[k / 2].y : P.w2p[k / 2].x;
+    const float lam = lpk * kLn2;
+    o[k][0] = lam * (gx[k].x + gx[k].y);
+    o[k][1] = lam * (gy[k].x + gy[k].y);
+    o[k][2] = lam * (gz[k].x + gz[k].y);
+    float glk = gl[k].x + gl[k].y, q0 = gw0[k].x + gw0[k].y, q1 = gw1[k].x + gw1[k].y, q2 = gw2[k].x + gw2[k].y;
+    if (a.premap) {
+      glk *= premap_grad(lam);
+      q0 *= premap_grad(w0); q1 *= premap_grad(w1); q2 *= premap_grad(w2);
+    }
+    o[k][3] = glk; o[k][4] = q0; o[k][5] = q1; o[k][6] = q2;
+  }
+  if (SPAN && r0 > 0) {
+    // the group's last rows (first item of this wave's span): hand the partial gradients to wave w - 1
+    float* part = a.span_part + (size_t)w * (7 * KPW * kWave) + lane;
+#pragma unroll
+    for (int k = 0; k < KPW; ++k)
+#pragma unroll
+      for (int i = 0; i < 7; ++i) part[(k * 7 + i) * kWave] = o[k][i];
+    span_publish(a.span_flags, w);
+    return;
+  }
+  if (SPAN && r1 < a.eh) {
+    // the group's first rows (last item of this wave's span): wave w + 1 published the rest long ago
+    span_acquire(a.span_flags, w + 1);
+    const float* part = a.span_part + (size_t)(w + 1) * (7 * KPW * kWave) + lane;
+#pragma unroll
+    for (int k = 0; k < KPW; ++k)
+#pragma unroll
+      for (int i = 0; i < 7; ++i) o[k][i] += part[(k * 7 + i) * kWave];
+    span_release(a.span_flags, w + 1);
+  }
   if (x.active) {
     float* g_axis_b = a.g_axis + (size_t)b * K * 3 * RC;
     float* g_lamb_b = a.g_lamb + (size_t)b * K * RC;
@@ -482,25 +587,72 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
       const int kk = half * KPW + k;
       if (kk < K) {
         const unsigned o3 = (unsigned)(kk * 3 * RC + p), o1 = (unsigned)(kk * RC + p);
-        const float lpk = (k & 1) ? P.lpp[k / 2].y : P.lpp[k / 2].x;
-        const float w0 = P.w01[k].x, w1 = P.w01[k].y, w2 = (k & 1) ? P.w2p[k / 2].y : P.w2p[k / 2].x;
-        const float lam = lpk * kLn2;
-        g_axis_b[o3] = lam * (gx[k].x + gx[k].y);
-        g_axis_b[o3 + RC] = lam * (gy[k].x + gy[k].y);
-        g_axis_b[o3 + 2 * RC] = lam * (gz[k].x + gz[k].y);
-        float glk = gl[k].x + gl[k].y, q0 = gw0[k].x + gw0[k].y, q1 = gw1[k].x + gw1[k].y, q2 = gw2[k].x + gw2[k].y;
-        if (a.premap) {
-          glk *= premap_grad(lam);
-          q0 *= premap_grad(w0); q1 *= premap_grad(w1); q2 *= premap_grad(w2);
-        }
-        g_lamb_b[o1] = glk;
-        g_weight_b[o3] = q0;
-        g_weight_b[o3 + RC] = q1;
-        g_weight_b[o3 + 2 * RC] = q2;
+        g_axis_b[o3] = o[k][0];
+        g_axis_b[o3 + RC] = o[k][1];
+        g_axis_b[o3 + 2 * RC] = o[k][2];
+        g_lamb_b[o1] = o[k][3];
+        g_weight_b[o3] = o[k][4];
+        g_weight_b[o3 + RC] = o[k][5];
+        g_weight_b[o3 + 2 * RC] = o[k][6];
       }
     }
   }
+}
+
+// one 32-pixel group per single-wave workgroup
+template <int POOL, bool HAS_GENV, bool HAS_RENDER>
+__global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
+  __shared__ __attribute__((aligned(16))) float tile[HAS_GENV ? 3 * kT32Floats : 4];
+  SGR_TRACE_BEGIN
+  sg_bwd_pk_group<POOL, HAS_GENV, HAS_RENDER, false>(a, tile, (int)blockIdx.x, 0, a.eh, 0);
   SGR_TRACE_END
 }
+
+// row-span launch (see fwd_pk_span_kernel): 9600 groups at 16 images are 4.7 per wave slot
+template <int POOL, bool HAS_GENV, bool HAS_RENDER>
+__global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_span_kernel(const Args a) {
+  __shared__ __attribute__((aligned(16))) float tile[HAS_GENV ? 3 * kT32Floats : 4];
+  SGR_TRACE_BEGIN
+  const int eh = a.eh, w = (int)blockIdx.x;
+  const long long U = (long long)a.bn * ((a.R * a.C + kPx - 1) / kPx) * eh;
+  int u = (int)(U * w / a.span_waves);
+  const int u1 = (int)(U * (w + 1) / a.span_waves);
+  while (u < u1) {
+    const int g = u / eh, r0 = u - g * eh, r1 = min(eh, r0 + (u1 - u));
+    sg_bwd_pk_group<POOL, HAS_GENV, HAS_RENDER, true>(a, tile, g, r0, r1, w);
+    u += r1 - r0;
+  }
+  SGR_TRACE_END
+}
+
+// ---- host side of the row-span launches -------------------------------------------------------------------------
+// Workspace = [16 KB of flags][slots x 42 x 64 floats of partial results]; slots = CUs x 4 SIMDs x 2 resident waves (the
+// span kernels need more than 170 VGPRs, so exactly two fit a SIMD and `slots` workgroups occupy every SIMD evenly).
+constexpr size_t kSpanFlagBytes = 16384;
+constexpr int kSpanPartFloats = 42 * kWave;
+static inline int span_slots() {
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 0;
+    cus[dev] = n;
+  }
+  return cus[dev] * 8;
+}
+static inline size_t span_workspace_bytes() { return kSpanFlagBytes + (size_t)span_slots() * kSpanPartFloats * sizeof(float); }
+static inline bool span_env_off() {      // SGR_SPAN=0: one group per workgroup even when a workspace is given (A/B knob)
+  static const bool off = [] { const char* e = getenv("SGR_SPAN"); return e != nullptr && e[0] == '0' && e[1] == 0; }();
+  return off;
+}
+static inline void span_setup(Args& a, void* ws, size_t ws_bytes) {
+  const int slots = span_slots();
+  if (!ws || slots <= 0 || (size_t)slots * sizeof(unsigned) > kSpanFlagBytes || ws_bytes < span_workspace_bytes() || span_env_off()) return;
+  a.span_flags = reinterpret_cast<unsigned*>(ws);
+  a.span_part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + kSpanFlagBytes);
+  a.span_waves = slots;
+}
+static inline bool span_enabled(const Args& a, int groups) { return a.span_flags != nullptr && groups > a.span_waves; }
 
 }  // namespace sgr

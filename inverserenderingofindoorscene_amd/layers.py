@@ -96,6 +96,38 @@ def _view(dev, R: int, C: int, fov: float, cam: Tuple[float, float, float]) -> t
                        lambda: tables.view_vectors(C, R, fov, cam))
 
 
+class _SpanWorkspaces:
+    """Workspace of the row-span launches (include/sgrender.h: sgr_fused_fwd_ws / sgr_fused_bwd_sg_ws): one zero-filled
+    buffer per (device, stream), created on first use and reused -- every call leaves it as it found it.  Inside a
+    HIP-graph capture nothing may be cached (the memory belongs to the graph's pool), so a fresh buffer is made per call
+    and only its flag words are cleared."""
+
+    FLAG_BYTES = 16384
+
+    def __init__(self):
+        self._cache: Dict[Tuple, torch.Tensor] = {}
+
+    def get(self, dev: torch.device) -> Tuple[Optional[torch.Tensor], int]:
+        nbytes = int(_lib.load().sgr_span_workspace_bytes())
+        if nbytes <= self.FLAG_BYTES:
+            return None, 0
+        if torch.cuda.is_current_stream_capturing():
+            ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+            ws[:self.FLAG_BYTES].zero_()
+            return ws, nbytes
+        key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+        ws = self._cache.get(key)
+        if ws is None or ws.numel() < nbytes:
+            if len(self._cache) >= 16:
+                self._cache.pop(next(iter(self._cache)))
+            ws = torch.zeros(nbytes, device=dev, dtype=torch.uint8)
+            self._cache[key] = ws
+        return ws, nbytes
+
+
+_SPAN_WS = _SpanWorkspaces()
+
+
 def _check_sg(axis, lamb, weight, K: Optional[int]):
     if axis.dim() != 5 or axis.shape[2] != 3:
         raise RuntimeError(f"sgrender: axis must be [bn,SGNum,3,envRow,envCol], got {tuple(axis.shape)}")
@@ -247,9 +279,10 @@ class _FusedRender(torch.autograd.Function):
         spec = torch.empty_like(diffuse)
         d, v = _dirs(dev, eh, ew), _view(dev, R, C, fov, cam)
         with torch.cuda.device(dev):
-            _lib.call("sgr_fused_fwd", _ptr(albedo_c), _ptr(normal_c), _ptr(rough_c), _ptr(axis_c), _ptr(lamb_c),
+            ws, ws_bytes = _SPAN_WS.get(dev)
+            _lib.call("sgr_fused_fwd_ws", _ptr(albedo_c), _ptr(normal_c), _ptr(rough_c), _ptr(axis_c), _ptr(lamb_c),
                       _ptr(weight_c), _ptr(d), _ptr(v), _ptr(env), _ptr(diffuse), _ptr(spec),
-                      bn, K, R, C, eh, ew, h, w, float(F0), int(premap), _stream(dev))
+                      bn, K, R, C, eh, ew, h, w, float(F0), int(premap), _ptr(ws), ws_bytes, _stream(dev))
         # the env image, when it exists, feeds the BRDF-map gradients (the env-given kernel is faster than re-evaluating the SG)
         if need_env and any(ctx.needs_input_grad[:3]):
             ctx.save_for_backward(albedo_c, normal_c, rough_c, axis_c, lamb_c, weight_c, env)
@@ -286,10 +319,11 @@ class _FusedRender(torch.autograd.Function):
         with torch.cuda.device(dev):
             if any(ctx.needs_input_grad[3:6]):
                 g_axis, g_lamb, g_weight = torch.empty_like(axis), torch.empty_like(lamb), torch.empty_like(weight)
-                _lib.call("sgr_fused_bwd_sg", _ptr(g_env), _ptr(g_diffuse), _ptr(g_spec), _ptr(albedo), _ptr(normal),
+                ws, ws_bytes = _SPAN_WS.get(dev)
+                _lib.call("sgr_fused_bwd_sg_ws", _ptr(g_env), _ptr(g_diffuse), _ptr(g_spec), _ptr(albedo), _ptr(normal),
                           _ptr(rough), _ptr(axis), _ptr(lamb), _ptr(weight), _ptr(d), _ptr(v),
                           _ptr(g_axis), _ptr(g_lamb), _ptr(g_weight),
-                          bn, K, R, C, eh, ew, h, w, float(F0), int(premap), _stream(dev))
+                          bn, K, R, C, eh, ew, h, w, float(F0), int(premap), _ptr(ws), ws_bytes, _stream(dev))
             if any(ctx.needs_input_grad[:3]):
                 g_alb, g_nrm, g_rgh = _brdf_grads(g_diffuse, g_spec, albedo, normal, rough, env_saved, axis, lamb, weight,
                                                   d, v, R, C, eh, ew, F0, premap, ctx.needs_input_grad[:3])

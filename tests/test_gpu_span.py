@@ -1,0 +1,101 @@
+"""GPU: the row-span ("stream-K") launches of the packed forward / backward kernels (include/sgrender.h: sgr_fused_fwd_ws,
+sgr_fused_bwd_sg_ws) against the one-group-per-wave launches of the same kernels, called through the C ABI on the same
+device buffers: env image bit-identical; diffuse / spec / SG gradients equal up to the rounding of the one extra addition
+a shared group costs; workspace left zero-filled; results bit-reproducible from launch to launch.  (Parity of both launch
+forms against the oracle and the reference fixtures: test_gpu_parity.py, test_gpu_fullsize.py -- the package's autograd
+functions use the workspace form.)"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import inverserenderingofindoorscene_amd as pkg
+    from inverserenderingofindoorscene_amd import _lib, layers
+    _lib.load()
+    return pkg, _lib, layers
+
+
+def _inputs(bn, imH, imW, R, C, K, eh, ew, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    r = lambda *s: torch.rand(*s, device="cuda", generator=g)
+    n = torch.randn(bn, 3, imH, imW, device="cuda", generator=g)
+    n[:, 2] = n[:, 2].abs() + 0.5
+    a = torch.randn(bn, K, 3, R, C, device="cuda", generator=g)
+    return dict(albedo=r(bn, 3, imH, imW), normal=(n / n.norm(dim=1, keepdim=True)).contiguous(), rough=r(bn, 1, imH, imW) * 2 - 1,
+                axis=(a / a.norm(dim=2, keepdim=True)).contiguous(), lamb=r(bn, K, R, C), weight=r(bn, 3 * K, R, C),
+                g_env=torch.randn(bn, 3, R, C, eh, ew, device="cuda", generator=g) * 1e-2,
+                g_d=torch.randn(bn, 3, R, C, device="cuda", generator=g), g_s=torch.randn(bn, 3, R, C, device="cuda", generator=g))
+
+
+def _run(env, x, bn, imH, imW, R, C, K, eh, ew, ws, need_env=True, with_genv=True):
+    pkg, _lib, L = env
+    dev = x["albedo"].device
+    d, v = L._dirs(dev, eh, ew), L._view(dev, R, C, 57.0, (0.0, 0.0, 0.0))
+    P = lambda t: None if t is None else t.data_ptr()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    envim = torch.empty((bn, 3, R, C, eh, ew), device=dev) if need_env else None
+    dif, spc = torch.empty((bn, 3, R, C), device=dev), torch.empty((bn, 3, R, C), device=dev)
+    ga, gl, gw = torch.empty_like(x["axis"]), torch.empty_like(x["lamb"]), torch.empty_like(x["weight"])
+    nb = 0 if ws is None else ws.numel()
+    _lib.call("sgr_fused_fwd_ws", P(x["albedo"]), P(x["normal"]), P(x["rough"]), P(x["axis"]), P(x["lamb"]), P(x["weight"]), P(d), P(v),
+              P(envim), P(dif), P(spc), bn, K, R, C, eh, ew, imH, imW, 0.05, 1, P(ws), nb, st)
+    _lib.call("sgr_fused_bwd_sg_ws", P(x["g_env"] if with_genv else None), P(x["g_d"]), P(x["g_s"]), P(x["albedo"]), P(x["normal"]),
+              P(x["rough"]), P(x["axis"]), P(x["lamb"]), P(x["weight"]), P(d), P(v), P(ga), P(gl), P(gw),
+              bn, K, R, C, eh, ew, imH, imW, 0.05, 1, P(ws), nb, st)
+    torch.cuda.synchronize()
+    return envim, dif, spc, ga, gl, gw
+
+
+def _close(a, b, tol):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item() <= tol
+
+
+CASES = [  # bn, imH, imW, R, C, K, eh  (more groups than the 2048 wave slots of an MI355X in every case)
+    (16, 240, 320, 120, 160, 12, 8),     # BASELINE config 2
+    (140, 30, 33, 30, 33, 9, 8),         # ragged last tile of every image, lobes past K, ratio 1
+    (9, 240, 320, 120, 160, 12, 5),      # odd row count per group: runs break groups at every position
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_span_launch_matches_one_group_per_wave(env, case):
+    pkg, _lib, L = env
+    bn, imH, imW, R, C, K, eh = case
+    ew = 16
+    nbytes = int(_lib.load().sgr_span_workspace_bytes())
+    assert nbytes > 16384
+    x = _inputs(bn, imH, imW, R, C, K, eh, ew, seed=bn + K)
+    ws = torch.zeros(nbytes, device="cuda", dtype=torch.uint8)
+    ref = _run(env, x, bn, imH, imW, R, C, K, eh, ew, None)
+    got = _run(env, x, bn, imH, imW, R, C, K, eh, ew, ws)
+    assert int(ws[:16384].view(torch.int32).abs().sum().item()) == 0, "flags not cleared"
+    assert torch.equal(got[0], ref[0]), "env image must be bit-identical"
+    names = ("diffuse", "spec", "g_axis", "g_lamb", "g_weight")
+    shared = 0
+    for n, a, b in zip(names, got[1:], ref[1:]):
+        assert torch.isfinite(a).all(), n
+        assert _close(a, b, 2e-6), (n, ((a - b).abs().max() / b.abs().max()).item())
+        shared += int((a != b).sum().item())
+    assert shared > 0, "no group was shared between waves: the span launch did not engage"
+    again = _run(env, x, bn, imH, imW, R, C, K, eh, ew, ws)
+    for a, b in zip(again, got):
+        assert torch.equal(a, b), "span launch is not bit-reproducible"
+    # render-only forward and backward without env cotangent
+    ref2 = _run(env, x, bn, imH, imW, R, C, K, eh, ew, None, need_env=False, with_genv=False)
+    got2 = _run(env, x, bn, imH, imW, R, C, K, eh, ew, ws, need_env=False, with_genv=False)
+    for n, a, b in zip(names, got2[1:], ref2[1:]):
+        assert _close(a, b, 2e-6), (n, "no-env variant")
+    assert int(ws[:16384].view(torch.int32).abs().sum().item()) == 0
+
+
+def test_span_small_batches_fall_back(env):
+    """Fewer groups than wave slots: the workspace form launches the ordinary grid (bit-identical results)."""
+    pkg, _lib, L = env
+    bn, imH, imW, R, C, K, eh, ew = 2, 24, 32, 12, 16, 12, 8, 16
+    x = _inputs(bn, imH, imW, R, C, K, eh, ew, seed=3)
+    ws = torch.zeros(int(_lib.load().sgr_span_workspace_bytes()), device="cuda", dtype=torch.uint8)
+    for a, b in zip(_run(env, x, bn, imH, imW, R, C, K, eh, ew, ws), _run(env, x, bn, imH, imW, R, C, K, eh, ew, None)):
+        assert torch.equal(a, b)
