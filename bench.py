@@ -12,8 +12,15 @@ One "step" = one pass of the hot path over one batch of synthetic inputs already
 through the package's autograd functions (i.e. through the drop-in boundary, not around it).
 Workload = BASELINE.json configs[1] per GPU: batch 16, 240x320 BRDF maps, 120x160 env grid,
 12 SG lobes, 8x16 directions.  For N > 1 the driver launches one rank per GPU with torchrun;
-images shard across ranks (weak scaling: 16 images per GPU), the only collective is the
-all-reduce of the loss numerator/denominator pair.
+images shard across ranks (weak scaling: 16 images per GPU) and the timed step additionally runs the
+render loss (LSregressDiffSpec + masked L2, wrapperBRDFLight.py:170-207) with its only collective --
+the all-reduce of the loss numerator/denominator pair over RCCL -- between
+forward and backward, so the N-GPU number contains the exchange north_star names.  The N = 1 line
+carries the same with-loss step as `config.Mpix_per_s_with_render_loss` for a like-for-like ratio.
+
+Timing: `--reps` (default 5) repetitions of the K-step loop, each bracketed by barrier + device
+synchronise on both sides and maximised over ranks; the line reports the MEDIAN repetition
+(`ms_per_step`) and lists all of them (`config.ms_per_step_repetitions`).
 
 Rank 0 prints ONE JSON line; see README/DESIGN.md for the field definitions.
 """
@@ -50,7 +57,9 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU")
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the K-step timed loop; the median is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layer-only", action="store_true", help="skip the informational legs (two streams, HIP graph, light objective, baselines): profiling runs")
     ap.add_argument("--no-env", action="store_true", help="render-only variant (env image never materialised)")
     ap.add_argument("--config", type=int, default=2, choices=(2, 5),
                     help="BASELINE.json configs index: 2 = headline (default); 5 = 480x640, SGNum 24, 16x32 stress (batch 4)")
@@ -94,6 +103,7 @@ def main() -> None:
     layer = pkg.renderingLayer(imWidth=C, imHeight=R, envWidth=ew, envHeight=eh)
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    group = dist.group.WORLD if world > 1 else None
 
     def step(i=None):
         if i is not None:
@@ -107,47 +117,58 @@ def main() -> None:
             ev[i][2].record()
         return grads
 
-    for _ in range(args.warmup):
-        step()
+    # the same step with the render loss in the loop (LSregressDiffSpec + masked L2 kernels, wrapperBRDFLight.py:170-207
+    # around the layer); sharded: the all-reduce of [num, den] sits between forward and backward
+    def step_with_loss(i=None):
+        env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=need_env)
+        err, _ = pkg.render_loss(d, s, x["im"], x["seg"], R, C, group=group)
+        if need_env:
+            grads = torch.autograd.grad([err, env], [x["axis"], x["lamb"], x["weight"]], grad_outputs=[None, ct_env])
+        else:
+            grads = torch.autograd.grad([err], [x["axis"], x["lamb"], x["weight"]])
+        return grads
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+    def timed(fn, with_events=False):
+        """EXACTLY args.steps steps between two barrier + synchronise brackets; seconds, max over ranks."""
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            fn(i if with_events else None)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        return dt
 
-    fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
-    bwd_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
+    def median(v):
+        v = sorted(v)
+        return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
 
-    # informational: the same step with the render loss in the loop (LSregressDiffSpec + masked L2 kernels,
-    # all-reduce of [num, den] when sharded) -- wrapperBRDFLight.py:170-207 around the layer
-    def step_with_loss():
-        env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=need_env)
-        err, _ = pkg.render_loss(d, s, x["im"], x["seg"], R, C)
-        if need_env:
-            torch.autograd.backward([err, env], [None, ct_env])
-        else:
-            err.backward()
-        for k in ("axis", "lamb", "weight"):
-            x[k].grad = None
-
-    step_with_loss()
-    barrier()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.warmup):
+        step()
         step_with_loss()
-    barrier()
-    loss_step_ms = (time.perf_counter() - t1) / args.steps * 1e3
+
+    reps = max(1, args.reps)
+    fwd_acc = bwd_acc = 0.0
+    plain_dts, loss_dts = [], []
+    for _ in range(reps):
+        plain_dts.append(timed(step, with_events=True))
+        fwd_acc += sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
+        bwd_acc += sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
+    for _ in range(reps):
+        loss_dts.append(timed(step_with_loss))
+    fwd_ms, bwd_ms = fwd_acc / reps, bwd_acc / reps
+    plain_ms, loss_step_ms = median(plain_dts) / args.steps * 1e3, median(loss_dts) / args.steps * 1e3
+    # the contract line: single GPU = the layer's forward + backward; sharded = the same plus the loss and its all-reduce
+    headline_dts = plain_dts if world == 1 else loss_dts
+    dt = median(headline_dts)
 
     # informational: the same step with the batch processed as two half-batches on two HIP streams (forward + backward of
     # each half on its own stream), so that one half's kernel tails (a 16-image launch covers the chip's wave slots only
@@ -155,7 +176,7 @@ def main() -> None:
     # overlap, so the contract line stays the single-stream loop.
     two_stream_ms = None
     try:
-        if bn % 2 == 0 and need_env:
+        if bn % 2 == 0 and need_env and not args.layer_only:
             hb = bn // 2
             xs = [{k: (v[i * hb:(i + 1) * hb].detach().requires_grad_(k in ("axis", "lamb", "weight"))) for k, v in x.items()
                    if k in ("albedo", "normal", "rough", "axis", "lamb", "weight")} for i in range(2)]
@@ -193,6 +214,8 @@ def main() -> None:
     try:
         if world > 1:      # stream capture and the process group's watchdog thread do not mix; single-process only
             raise RuntimeError("skipped under torch.distributed")
+        if args.layer_only:
+            raise RuntimeError("skipped (--layer-only)")
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -212,13 +235,13 @@ def main() -> None:
         del static_grads, graph
     except Exception as exc:       # informational leg: never fail the bench over it
         graph_ms = None
-        if rank == 0 and world == 1:
+        if rank == 0 and world == 1 and not args.layer_only:
             print(f"# hip-graph leg skipped: {str(exc)[:160]}", file=sys.stderr)
 
     # informational: the whole cascade-0 light objective (render loss + 10 x env reconstruction loss,
     # wrapperBRDFLight.py:167-207) -- fused (env image never written, sgr.light_objective) and unfused
     obj_ms = obj_unfused_ms = obj_graph_ms = None
-    if args.config == 2 and need_env and pkg.light_objective_supported(K, R, C, eh, ew):
+    if args.config == 2 and need_env and not args.layer_only and pkg.light_objective_supported(K, R, C, eh, ew):
         ind = torch.ones(bn, 1, 1, 1, device=dev)
 
         def clear():
@@ -281,27 +304,27 @@ def main() -> None:
         bwd_bytes = P * (bpp["bwd_sg"] if need_env else bpp["bwd_sg"] - 3 * J * 4)
         fwd_gbps = fwd_bytes / (fwd_ms * 1e-3) / 1e9
         bwd_gbps = bwd_bytes / (bwd_ms * 1e-3) / 1e9
-        dom = ("sg_bwd", bwd_ms, bwd_bytes, bwd_gbps) if bwd_ms >= fwd_ms else ("fwd_fast", fwd_ms, fwd_bytes, fwd_gbps)
-        # HBM bytes per launch from the PMC passes (tools/pmc_traffic.sh -> profiles/traffic.json), if recorded;
-        # the entry is matched by kernel family (the backward is sg_bwd_half_kernel / sg_bwd_split_kernel / sg_bwd_fast_kernel)
-        traffic, dom_name = None, dom[0] + "_kernel"
+        dom = ("bwd", bwd_ms, bwd_bytes, bwd_gbps) if bwd_ms >= fwd_ms else ("fwd", fwd_ms, fwd_bytes, fwd_gbps)
+        # HBM bytes per launch of the dominant kernel from the PMC passes (tools/pmc_traffic.sh -> tools/parse_pmc.py ->
+        # profiles/traffic.json), recorded per WORKLOAD (config, batch, env written or not): a figure measured on another
+        # workload is not reported
+        traffic, dom_name = None, ("sg_bwd" if dom[0] == "bwd" else "fwd") + " kernel (no PMC record for this workload)"
+        tkey = f"config{args.config}_batch{bn}_{'env' if need_env else 'noenv'}"
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        # the headline kernels by template instance: backward with env cotangent + render cotangents
-        # (<.., true, true[, occ]>), forward with env output + render and no ground-truth statistics (<.., true, true, false>)
         import re
-        want = ([r"sg_bwd_half_kernel<\d+, true, true, \d+>", r"sg_bwd_split_kernel<\d+, \d+, true, true>", r"sg_bwd_fast_kernel<.*true, true>"]
-                if dom[0] == "sg_bwd" else [r"fwd_half_kernel<\d+, true, true, \d+>", r"fwd_fast_kernel<[\d, ]+true, true, false>",
-                                             r"fwd_fast_kernel<[\d, ]+true, true>"])
+        want = ([r"sg_bwd_pk_span_kernel<", r"sg_bwd_pk_kernel<", r"sg_bwd_half_kernel<", r"sg_bwd_split_kernel<", r"sg_bwd_fast_kernel<"]
+                if dom[0] == "bwd" else [r"fwd_pk_span_kernel<", r"fwd_pk_kernel<", r"fwd_half_kernel<", r"fwd_fast_kernel<"])
         if os.path.isfile(tpath):
             try:
-                recs = json.load(open(tpath))
+                recs = json.load(open(tpath)).get(tkey, {})
                 for pat in want:
-                    hits = [n for n in recs if re.search("::" + pat + "$", n)]
+                    hits = sorted((n for n in recs if re.search("::" + pat, n)), key=lambda n: -recs[n]["hbm_bytes"])
                     if hits:
-                        traffic, dom_name = recs[hits[0]]["hbm_bytes"], hits[0].split("::")[-1].split("<")[0]
+                        traffic, dom_name = recs[hits[0]]["hbm_bytes"], hits[0].split("::")[-1]
                         break
             except Exception:
                 traffic = None
+        mpix = lambda ms: round(world * img_px / (ms * 1e-3) / 1e6, 1)
         out = {
             "metric": "Mpix/s shaded (fwd+bwd), 240x320x12-SG render layer" if args.config == 2 else "Mpix/s shaded (fwd+bwd), 480x640x24-SG 16x32 render layer (stress config)",
             "value": round(value, 1),
@@ -320,7 +343,11 @@ def main() -> None:
                                    f"({'env image written' if need_env else 'render only'}) + fused bwd (SG grads), trainLight mode",
                        "shaded_px_per_step_per_gpu": P, "image_px_per_step_per_gpu": img_px, "q": q,
                        "Mshade_per_s": round(world * P / (dt / args.steps) / 1e6, 1),
-                       "ms_per_step_with_render_loss": round(loss_step_ms, 4),
+                       "timed_step": "fwd + bwd of the layer" if world == 1 else "fwd + render loss (all-reduce of [num, den] over RCCL) + bwd",
+                       "repetitions": reps, "statistic": "median repetition of the K-step loop, max over ranks",
+                       "ms_per_step_repetitions": [round(t / args.steps * 1e3, 4) for t in headline_dts],
+                       "ms_per_step_layer_only": round(plain_ms, 4), "Mpix_per_s_layer_only": mpix(plain_ms),
+                       "ms_per_step_with_render_loss": round(loss_step_ms, 4), "Mpix_per_s_with_render_loss": mpix(loss_step_ms),
                        "ms_per_step_hipgraph_replay": None if graph_ms is None else round(graph_ms, 4),
                        "ms_per_step_two_half_batches_two_streams": None if two_stream_ms is None else round(two_stream_ms, 4),
                        "ms_per_step_light_objective_fused": None if obj_ms is None else round(obj_ms, 4),
@@ -330,13 +357,19 @@ def main() -> None:
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(dom[3], 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(dom[3] / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": dom[2], "avg_launch_ms": round(dom[1], 4)},
-            "kernels": {"forward (fwd_half_kernel)" if (need_env and args.config == 2) else "forward (fwd_fast_kernel)": {"ms": round(fwd_ms, 4), "GBps": round(fwd_gbps, 1), "frac": round(fwd_gbps / HBM_PEAK_GBPS, 4),
-                                       "bytes": fwd_bytes},
-                        "backward (sg_bwd_half_kernel)": {"ms": round(bwd_ms, 4), "GBps": round(bwd_gbps, 1), "frac": round(bwd_gbps / HBM_PEAK_GBPS, 4),
-                                          "bytes": bwd_bytes}},
+            "kernels": {"forward (sgr_fused_fwd_ws)": {"ms": round(fwd_ms, 4), "GBps": round(fwd_gbps, 1), "frac": round(fwd_gbps / HBM_PEAK_GBPS, 4),
+                                                       "bytes": fwd_bytes},
+                        "backward (sgr_fused_bwd_sg_ws)": {"ms": round(bwd_ms, 4), "GBps": round(bwd_gbps, 1), "frac": round(bwd_gbps / HBM_PEAK_GBPS, 4),
+                                                           "bytes": bwd_bytes}},
         }
-        if world == 1 and not args.no_cpu_baseline and args.config == 2:
-            out["cpu_baseline"] = cpu_baseline(O, 240, 320, 120, 160, 12, 8, 16) if args.config == 2 else None
+        if world == 1 and not args.no_cpu_baseline and not args.layer_only and args.config == 2:
+            out["cpu_baseline"] = cpu_baseline(O, 240, 320, 120, 160, 12, 8, 16)
+            # port vs the UNMODIFIED reference on the same cores, measured where the reference exists (the authoring
+            # container; oracle/calibrate_port_vs_reference.py -> profiles/cpu_calibration.json)
+            try:
+                out["cpu_baseline"]["calibration"] = json.load(open(os.path.join(ROOT, "profiles", "cpu_calibration.json")))
+            except Exception:
+                out["cpu_baseline"]["calibration"] = None
             try:
                 out["eager_gpu_baseline"] = eager_gpu_baseline(O, dev, 240, 320, 120, 160, 12, 8, 16)
             except Exception as exc:       # informational leg: never fail the bench over it

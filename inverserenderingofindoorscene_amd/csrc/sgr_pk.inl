@@ -52,19 +52,33 @@ __device__ __forceinline__ f32x2 half_of(f32x2 p, int i) { return i ? SGR_HI(p) 
 typedef const f32x4 __attribute__((address_space(4))) * PairTable;   // per azimuth pair: (ca_a, ca_a+1, sa_a, sa_a+1)
 __device__ __forceinline__ PairTable as_pair_table(const float* cols, int ew) { return (PairTable)(cols + 4 * ew); }
 
-// ---- row-span hand-off between two consecutive waves (agent scope: the waves may sit on different XCDs) ----------
+// ---- row-span hand-off between two consecutive waves (the waves may sit on different XCDs, whose L2s are not coherent) ----
+// Everything that crosses goes through agent-scope (sc1) accesses: partial results and flag are written through to
+// memory, the consumer's loads bypass its own L2.  No release / acquire FENCE on purpose: at agent scope a fence is
+// buffer_wbl2 / buffer_inv -- a write-back or invalidate of the XCD's whole L2, issued by 2048 waves in the middle of a
+// kernel that streams 0.5 GB through those L2s (measured: 412 instead of 263 us for the backward).  Ordering instead:
+// the producer waits for its partial stores to be acknowledged (vmcnt 0) before it stores the flag; the consumer's
+// partial loads are issued after the flag load has returned the published value.
 // flags[w] is 0 on entry to the kernel, set by wave w once its partial results are in span_part, and cleared again by
 // wave w - 1 after it has read them: the workspace leaves every launch as it entered it.
+__device__ __forceinline__ void span_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float span_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void span_publish(unsigned* flags, int w) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#ifndef SGR_SPAN_NOSYNC
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (threadIdx.x == 0) __hip_atomic_store(flags + w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 }
 __device__ __forceinline__ void span_acquire(unsigned* flags, int w) {
+#ifndef SGR_SPAN_NOSYNC
   while (__hip_atomic_load(flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  asm volatile("" ::: "memory");
+#endif
 }
 __device__ __forceinline__ void span_release(unsigned* flags, int w) {
+#ifndef SGR_SPAN_NOSYNC
   if (threadIdx.x == 0) __hip_atomic_store(flags + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 }
 // the PX-pixel group `g` of the batch (PX = 64: one pixel per lane; 32: lanes l and l + 32 share a pixel)
 template <int PX>
@@ -329,7 +343,7 @@ __device__ __forceinline__ void fwd_pk_group(const Args& a, float* tile, const i
       // the group's last rows (first item of this wave's span): hand the partial sums to wave w - 1
       float* part = a.span_part + (size_t)w * (6 * kWave) + lane;
 #pragma unroll
-      for (int i = 0; i < 6; ++i) part[i * kWave] = o6[i];
+      for (int i = 0; i < 6; ++i) span_store(part + i * kWave, o6[i]);
       span_publish(a.span_flags, w);
       return;
     }
@@ -338,7 +352,7 @@ __device__ __forceinline__ void fwd_pk_group(const Args& a, float* tile, const i
       span_acquire(a.span_flags, w + 1);
       const float* part = a.span_part + (size_t)(w + 1) * (6 * kWave) + lane;
 #pragma unroll
-      for (int i = 0; i < 6; ++i) o6[i] += part[i * kWave];
+      for (int i = 0; i < 6; ++i) o6[i] += span_load(part + i * kWave);
       span_release(a.span_flags, w + 1);
     }
     if (x.active) {
@@ -564,7 +578,7 @@ __device__ __forceinline__ void sg_bwd_pk_group(const Args& a, float* tile, cons
 #pragma unroll
     for (int k = 0; k < KPW; ++k)
 #pragma unroll
-      for (int i = 0; i < 7; ++i) part[(k * 7 + i) * kWave] = o[k][i];
+      for (int i = 0; i < 7; ++i) span_store(part + (k * 7 + i) * kWave, o[k][i]);
     span_publish(a.span_flags, w);
     return;
   }
@@ -575,7 +589,7 @@ __device__ __forceinline__ void sg_bwd_pk_group(const Args& a, float* tile, cons
 #pragma unroll
     for (int k = 0; k < KPW; ++k)
 #pragma unroll
-      for (int i = 0; i < 7; ++i) o[k][i] += part[(k * 7 + i) * kWave];
+      for (int i = 0; i < 7; ++i) o[k][i] += span_load(part + (k * 7 + i) * kWave);
     span_release(a.span_flags, w + 1);
   }
   if (x.active) {

@@ -1,0 +1,75 @@
+"""How fast is the CPU port (oracle/sg_oracle.py, what bench.py's ``cpu_baseline`` times on the GPU box) against the
+UNMODIFIED reference on the same cores?  TEST INFRASTRUCTURE ONLY, authoring container (the reference is not on the GPU box):
+
+    python -m oracle.calibrate_port_vs_reference      # writes profiles/cpu_calibration.json
+
+One image of BASELINE config 2 (240x320 -> 120x160, SGNum 12, 8x16), forward + backward w.r.t. the SG parameters with
+the bench's cotangents, fp32, all cores of this container, best of 3 after one warm-up -- the same protocol as
+``bench.py: cpu_baseline``.  The reference is models.output2env.output2env + models.renderingLayer.forwardEnv
+(models.py:391-404, 461-522) exactly as wrapperBRDFLight.py:177,194 call them."""
+from __future__ import annotations
+
+import json
+import os
+import time
+
+import torch
+
+from oracle import ref_import as RI
+from oracle import sg_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def best_of(fn, n=3):
+    fn()
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return min(ts)
+
+
+def main():
+    if not RI.available():
+        raise SystemExit("reference not mounted")
+    cores = len(os.sched_getaffinity(0))
+    torch.set_num_threads(cores)
+    imH, imW, R, C, K, eh, ew = 240, 320, 120, 160, 12, 8, 16
+    inp = O.synthetic_inputs(1, imH, imW, R, C, K, eh, ew, seed=20202)
+    names = ("albedo", "normal", "rough", "axis", "lamb", "weight")
+    x = {k: inp[k].clone() for k in names}
+    for k in ("axis", "lamb", "weight"):
+        x[k].requires_grad_(True)
+    g = torch.Generator().manual_seed(99)
+    cts = [torch.randn((1, 3, R, C, eh, ew), generator=g) * 1e-3, torch.randn((1, 3, R, C), generator=g), torch.randn((1, 3, R, C), generator=g)]
+    o2e, rl = RI.make_layers(K, R, C, eh, ew)
+
+    def reference():
+        env, _, _, _ = o2e.output2env(x["axis"], x["lamb"], x["weight"])
+        d, s = rl.forwardEnv(x["albedo"], x["normal"], x["rough"], env)
+        torch.autograd.grad([env, d, s], [x["axis"], x["lamb"], x["weight"]], grad_outputs=cts)
+
+    def port():
+        env, d, s = O.render_from_sg(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], eh, ew)
+        torch.autograd.grad([env, d, s], [x["axis"], x["lamb"], x["weight"]], grad_outputs=cts)
+
+    t_ref, t_port = best_of(reference), best_of(port)
+    model = "unknown"
+    for line in open("/proc/cpuinfo"):
+        if line.startswith("model name"):
+            model = line.split(":", 1)[1].strip()
+            break
+    out = {"where": "authoring container (no GPU; /root/reference mounted)", "cpu": model, "cores": cores, "torch": torch.__version__,
+           "sample": "1 image of BASELINE configs[1] (240x320 -> 120x160, SGNum 12, 8x16), fwd + bwd (SG grads), fp32, best of 3",
+           "reference_seconds": round(t_ref, 3), "port_seconds": round(t_port, 3),
+           "reference_Mpix_per_s": round(imH * imW / t_ref / 1e6, 4), "port_Mpix_per_s": round(imH * imW / t_port / 1e6, 4),
+           "port_over_reference_speed": round(t_ref / t_port, 3)}
+    path = os.path.join(ROOT, "profiles", "cpu_calibration.json")
+    json.dump(out, open(path, "w"), indent=1)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -3,7 +3,9 @@
 Units / corrections (MI355X_MICROARCH.md, "HBM" and "rocprofv3 PMC slots"): FETCH_SIZE and WRITE_SIZE
 are in KiB; on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read
 (128-B requests tallied at 64 B) -> the read side is doubled.  WRITE_SIZE is used as reported.
-Writes profiles-style JSON: {kernel: {"fetch_bytes": .., "write_bytes": .., "hbm_bytes": ..}}."""
+Writes <dir>/traffic_raw.json: {kernel: {"fetch_bytes": .., "write_bytes": .., "hbm_bytes": ..}}; with a workload tag
+and a target file as 2nd / 3rd argument the table is also merged into that file under the tag
+(profiles/traffic.json: {"config2_batch16_env": {kernel: ..}, ..} -- what bench.py's roofline.traffic reads)."""
 import csv
 import glob
 import json
@@ -31,3 +33,11 @@ for k in sorted(set(acc["FETCH_SIZE"]) | set(acc["WRITE_SIZE"])):
                   "launches_sampled": [len(fk), len(wk)]}
     print(f"{short:70s} fetch {fetch/1e6:9.1f} MB  write {write/1e6:9.1f} MB  total {(fetch+write)/1e6:9.1f} MB per launch")
 json.dump(out, open(os.path.join(root, "traffic_raw.json"), "w"), indent=1)
+if len(sys.argv) > 3:
+    tag, target = sys.argv[2], sys.argv[3]
+    try:
+        allrec = json.load(open(target))
+    except Exception:
+        allrec = {}
+    allrec[tag] = out
+    json.dump(allrec, open(target, "w"), indent=1)
