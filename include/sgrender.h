@@ -106,17 +106,18 @@ int sgr_fused_bwd_sg(const float* g_env /* nullable */, const float* g_diffuse, 
                      int premap, void* stream);
 
 /* The same two calls (wrapperBRDFLight.py:177+194 and their autograd) with a caller-owned workspace of
- * sgr_span_workspace_bytes() bytes of device memory.  With it, and when the batch holds more work units than the
- * chip has wave slots, the kernels are launched as one wave per slot, each taking an equally long run of
- * (pixel group, table row) items ("row spans"), so no slot idles in a last partial round: at 16 images of
- * 120 x 160 cells that is worth 15-20 % of the kernel time.  A group shared by two waves is finished by the wave
- * that owns its first rows, which adds the other wave's partial sums (handed over through the workspace) to its
- * own: results are deterministic for a given device; for shared groups they differ from the one-group-per-wave
- * launch by the rounding of one extra addition (diffuse/spec and the SG gradients; the env image is bit-identical).
+ * sgr_split_workspace_bytes() bytes of device memory.  With it the launch may run the LAST few pixel groups of the
+ * batch as two workgroups each (half of the table rows per workgroup): shorter work items, dispatched last, that
+ * fill the final round of the chip's wave slots, which one group per workgroup leaves a third full at 16 images of
+ * 120 x 160 cells.  How many groups are split is decided per launch from the group count and the device's slot
+ * count (a list-scheduling estimate; SGR_SPLIT=n forces n, SGR_SPLIT=0 disables).  A split group is finished by the
+ * workgroup that owns its first rows, which adds the other one's partial sums (handed over through the workspace)
+ * to its own: results are deterministic for a given device and batch shape; for split groups diffuse/spec and the
+ * SG gradients differ from the plain launch by the rounding of one extra addition; the env image is bit-identical.
  *   workspace contract: zero-filled before its first use; every call leaves it zero-filled where that matters,
  *   so it can be reused call after call on the SAME stream; calls that may run concurrently (different streams)
- *   need their own workspaces.  NULL / too small: identical to the calls without _ws.  SGR_SPAN=0 disables. */
-size_t sgr_span_workspace_bytes(void);
+ *   need their own workspaces.  NULL / too small: identical to the calls without _ws. */
+size_t sgr_split_workspace_bytes(void);
 int sgr_fused_fwd_ws(const float* albedo, const float* normal, const float* rough,
                      const float* axis, const float* lamb, const float* weight,
                      const float* dirs, const float* view,

@@ -243,10 +243,13 @@ template <bool HAS_GENV, bool HAS_RENDER>
 static int sgbwd_pk_launch(const Args& a, hipStream_t st) {
   const dim3 grid((unsigned)(a.bn * ((a.R * a.C + kPx - 1) / kPx))), block(kWave);
   const bool p1 = !HAS_RENDER || (a.imH == a.R && a.imW == a.C);
-  if (span_enabled(a, (int)grid.x)) {      // row-span launch, see fwd_pk_launch
-    const dim3 sgrid((unsigned)a.span_waves);
-    if (p1) hipLaunchKernelGGL((sg_bwd_pk_span_kernel<1, HAS_GENV, HAS_RENDER>), sgrid, block, 0, st, a);
-    else hipLaunchKernelGGL((sg_bwd_pk_span_kernel<2, HAS_GENV, HAS_RENDER>), sgrid, block, 0, st, a);
+  const int S = split_count(a, (int)grid.x);
+  if (S > 0) {      // tail-split launch, see fwd_pk_launch
+    Args b = a;
+    b.split_groups = S;
+    const dim3 sgrid(grid.x + (unsigned)S);
+    if (p1) hipLaunchKernelGGL((sg_bwd_pk_split_kernel<1, HAS_GENV, HAS_RENDER>), sgrid, block, 0, st, b);
+    else hipLaunchKernelGGL((sg_bwd_pk_split_kernel<2, HAS_GENV, HAS_RENDER>), sgrid, block, 0, st, b);
     return (int)hipGetLastError();
   }
   if (p1) hipLaunchKernelGGL((sg_bwd_pk_kernel<1, HAS_GENV, HAS_RENDER>), grid, block, 0, st, a);

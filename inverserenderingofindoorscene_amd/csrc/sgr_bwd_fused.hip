@@ -20,7 +20,7 @@ extern "C" int sgr_fused_bwd_sg_ws(const float* g_env, const float* g_diffuse, c
   a.g_axis = g_axis; a.g_lamb = g_lamb; a.g_weight = g_weight;
   set_dims_b(a, bn, K, R, C, eh, ew, imH, imW);
   a.F0 = F0; a.premap = premap;
-  span_setup(a, workspace, workspace_bytes);
+  split_setup(a, workspace, workspace_bytes);
   const hipStream_t st = (hipStream_t)stream;
   return sgr_check(g_env ? sgbwd_launch<true, true>(a, st) : sgbwd_launch<false, true>(a, st), "sgr_fused_bwd_sg");
 }

@@ -179,10 +179,13 @@ template <int KP, bool WRITE_ENV, bool DO_RENDER>
 static int fwd_pk_launch(const Args& a, hipStream_t st) {
   const dim3 grid = wave_grid(a.bn, a.R, a.C), block(kWave);
   const bool p1 = !DO_RENDER || (a.imH == a.R && a.imW == a.C);
-  if (KP == 12 && span_enabled(a, (int)grid.x)) {      // row-span launch: one wave per wave slot of the chip (workspace given, more groups than slots)
-    const dim3 sgrid((unsigned)a.span_waves);
-    if (p1) hipLaunchKernelGGL((fwd_pk_span_kernel<KP, 1, WRITE_ENV, DO_RENDER>), sgrid, block, 0, st, a);
-    else hipLaunchKernelGGL((fwd_pk_span_kernel<KP, 2, WRITE_ENV, DO_RENDER>), sgrid, block, 0, st, a);
+  const int S = (KP == 12 && DO_RENDER) ? split_count(a, (int)grid.x) : 0;      // (KP 6: three waves fit a SIMD; no render: nothing to share)
+  if (S > 0) {      // tail-split launch: the last S groups as two workgroups each (workspace given)
+    Args b = a;
+    b.split_groups = S;
+    const dim3 sgrid(grid.x + (unsigned)S);
+    if (p1) hipLaunchKernelGGL((fwd_pk_split_kernel<KP, 1, WRITE_ENV, DO_RENDER>), sgrid, block, 0, st, b);
+    else hipLaunchKernelGGL((fwd_pk_split_kernel<KP, 2, WRITE_ENV, DO_RENDER>), sgrid, block, 0, st, b);
     return (int)hipGetLastError();
   }
   if (p1) hipLaunchKernelGGL((fwd_pk_kernel<KP, 1, WRITE_ENV, DO_RENDER>), grid, block, 0, st, a);
@@ -206,7 +209,7 @@ static int fwd_fast_launch(const Args& a, hipStream_t st) {
   // measured at config 2, one pixel per lane / half-wave: in the bench loop (working set cycling through HBM) env + render
   // 239 / 206 us, render only 163 / 172 us; relaunched on the same buffers (tools/kbench, inputs partly cache-resident)
   // env + render 214-223 / 209-219 us, env only 178 / 149 us  ->  half-wave whenever the env image is written
-  if (fwd_mode() == 4 && a.ew == 16 && a.K <= 12)      // (K <= 6: fewer than 170 VGPRs, three waves fit a SIMD -> no row spans)
+  if (fwd_mode() == 4 && a.ew == 16 && a.K <= 12)
     return a.K <= 6 ? fwd_pk_launch<6, WRITE_ENV, DO_RENDER>(a, st) : fwd_pk_launch<12, WRITE_ENV, DO_RENDER>(a, st);
   const int mode = (fwd_mode() >= 0 && fwd_mode() != 4) ? fwd_mode() : (WRITE_ENV ? 2 : 0);
   if (a.ew == 16 && a.K > 6 && a.K <= 12 && mode != 0)

@@ -2,7 +2,7 @@
 #include "sgr_forward.inl"
 using namespace sgr;
 
-extern "C" size_t sgr_span_workspace_bytes(void) { return span_workspace_bytes(); }
+extern "C" size_t sgr_split_workspace_bytes(void) { return split_workspace_bytes(); }
 
 extern "C" int sgr_fused_fwd_ws(const float* albedo, const float* normal, const float* rough, const float* axis,
                                 const float* lamb, const float* weight, const float* dirs, const float* view,
@@ -18,7 +18,7 @@ extern "C" int sgr_fused_fwd_ws(const float* albedo, const float* normal, const 
   a.dirs = reinterpret_cast<const float4*>(dirs); a.view = view; a.env_out = env; a.diffuse = diffuse; a.spec = spec;
   set_dims(a, bn, K, R, C, eh, ew, imH, imW);
   a.F0 = F0; a.premap = premap;
-  span_setup(a, workspace, workspace_bytes);
+  split_setup(a, workspace, workspace_bytes);
   const hipStream_t st = (hipStream_t)stream;
   return sgr_check(env ? fwd_launch<true, true, true>(a, st) : fwd_launch<true, false, true>(a, st), "sgr_fused_fwd");
 }

@@ -52,33 +52,29 @@ __device__ __forceinline__ f32x2 half_of(f32x2 p, int i) { return i ? SGR_HI(p) 
 typedef const f32x4 __attribute__((address_space(4))) * PairTable;   // per azimuth pair: (ca_a, ca_a+1, sa_a, sa_a+1)
 __device__ __forceinline__ PairTable as_pair_table(const float* cols, int ew) { return (PairTable)(cols + 4 * ew); }
 
-// ---- row-span hand-off between two consecutive waves (the waves may sit on different XCDs, whose L2s are not coherent) ----
+// ---- hand-off between the two waves that share a split group (they may sit on different XCDs, whose L2s are not coherent) ----
 // Everything that crosses goes through agent-scope (sc1) accesses: partial results and flag are written through to
 // memory, the consumer's loads bypass its own L2.  No release / acquire FENCE on purpose: at agent scope a fence is
-// buffer_wbl2 / buffer_inv -- a write-back or invalidate of the XCD's whole L2, issued by 2048 waves in the middle of a
-// kernel that streams 0.5 GB through those L2s (measured: 412 instead of 263 us for the backward).  Ordering instead:
-// the producer waits for its partial stores to be acknowledged (vmcnt 0) before it stores the flag; the consumer's
-// partial loads are issued after the flag load has returned the published value.
-// flags[w] is 0 on entry to the kernel, set by wave w once its partial results are in span_part, and cleared again by
-// wave w - 1 after it has read them: the workspace leaves every launch as it entered it.
-__device__ __forceinline__ void span_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float span_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void span_publish(unsigned* flags, int w) {
-#ifndef SGR_SPAN_NOSYNC
+// buffer_wbl2 / buffer_inv -- a write-back or invalidate of the XCD's whole L2 in the middle of a kernel that streams
+// 0.5 GB through those L2s (measured with 2048 fences per launch: 412 instead of 263 us for the backward).  Ordering
+// instead: the producer waits for its partial stores to be acknowledged (vmcnt 0) before it stores the flag; the
+// consumer's partial loads are issued after the flag load has returned the published value.
+// flags[s] is 0 on entry to the kernel, set by the producer of split group s once its partial results are in
+// split_part, and cleared again by the consumer after it has read them: the workspace leaves every launch as it entered it.
+// No deadlock: the producer has the lower workgroup id, workgroups are dispatched in id order (per XCD), and a producer
+// waits for nothing -- so the lowest-numbered unfinished workgroup can always run.
+__device__ __forceinline__ void split_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float split_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void split_publish(unsigned* flags, int s) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (threadIdx.x == 0) __hip_atomic_store(flags + w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
+  if (threadIdx.x == 0) __hip_atomic_store(flags + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void span_acquire(unsigned* flags, int w) {
-#ifndef SGR_SPAN_NOSYNC
-  while (__hip_atomic_load(flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
+__device__ __forceinline__ void split_acquire(unsigned* flags, int s) {
+  while (__hip_atomic_load(flags + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
   asm volatile("" ::: "memory");
-#endif
 }
-__device__ __forceinline__ void span_release(unsigned* flags, int w) {
-#ifndef SGR_SPAN_NOSYNC
-  if (threadIdx.x == 0) __hip_atomic_store(flags + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
+__device__ __forceinline__ void split_release(unsigned* flags, int s) {
+  if (threadIdx.x == 0) __hip_atomic_store(flags + s, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // the PX-pixel group `g` of the batch (PX = 64: one pixel per lane; 32: lanes l and l + 32 share a pixel)
 template <int PX>
@@ -223,14 +219,14 @@ __device__ __forceinline__ void shade_pair(const PixLocal& q, const OrthoPix& oq
 #ifndef SGR_PK_TJ
 #define SGR_PK_TJ 16      // directions per flushed env tile row: 16 = one table row (64-byte segments), 32 = two rows (128-byte)
 #endif
-// One work item of the packed forward: table rows [r0, r1) of the 64-pixel group `g`.  SPAN = false: the whole group
-// (r0 = 0, r1 = eh), results stored directly.  SPAN = true (row-span kernels below): a group may be shared by two
-// consecutive waves; the wave that owns its last rows publishes its partial radiance sums, the wave that owns row 0 adds
-// them to its own and stores.
-template <int KP, int POOL, int TJ, bool WRITE_ENV, bool DO_RENDER, bool SPAN>
-__device__ __forceinline__ void fwd_pk_group(const Args& a, float* tile, const int g, const int r0, const int r1, const int w) {
+// One work item of the packed forward: table rows [r0, r1) of the 64-pixel group `g`.  SPLIT = false: the whole group
+// (r0 = 0, r1 = eh), results stored directly.  SPLIT = true (fwd_pk_split_kernel below): the group may be shared by two
+// waves; the one that owns its last rows publishes its partial radiance sums in slot `slot` of the workspace, the one
+// that owns row 0 adds them to its own and stores.
+template <int KP, int POOL, int TJ, bool WRITE_ENV, bool DO_RENDER, bool SPLIT>
+__device__ __forceinline__ void fwd_pk_group(const Args& a, float* tile, const int g, const int r0, const int r1, const int slot) {
   constexpr int EW = 16, HALF = 8, NQ = 2, RPT = TJ / EW;
-  static_assert(!SPAN || RPT == 1, "row spans flush one table row at a time");
+  static_assert(!SPLIT || RPT == 1, "split groups flush one table row at a time");
   const Pix x = locate_group<kWave>(a, g);
   const int lane = x.lane, b = x.b, p = x.p;
   const int RC = a.R * a.C;
@@ -339,21 +335,21 @@ __device__ __forceinline__ void fwd_pk_group(const Args& a, float* tile, const i
   if (DO_RENDER) {
     float o6[6] = {(alb[0] * kInvPi) * (dacc[0].x + dacc[0].y), (alb[1] * kInvPi) * (dacc[1].x + dacc[1].y),
                    (alb[2] * kInvPi) * (dacc[2].x + dacc[2].y), sacc[0].x + sacc[0].y, sacc[1].x + sacc[1].y, sacc[2].x + sacc[2].y};
-    if (SPAN && r0 > 0) {
-      // the group's last rows (first item of this wave's span): hand the partial sums to wave w - 1
-      float* part = a.span_part + (size_t)w * (6 * kWave) + lane;
+    if (SPLIT && r0 > 0) {
+      // the group's last rows: hand the partial sums to the wave that owns row 0
+      float* part = a.split_part + (size_t)slot * (6 * kWave) + lane;
 #pragma unroll
-      for (int i = 0; i < 6; ++i) span_store(part + i * kWave, o6[i]);
-      span_publish(a.span_flags, w);
+      for (int i = 0; i < 6; ++i) split_store(part + i * kWave, o6[i]);
+      split_publish(a.split_flags, slot);
       return;
     }
-    if (SPAN && r1 < a.eh) {
-      // the group's first rows (last item of this wave's span): wave w + 1 published the rest long ago
-      span_acquire(a.span_flags, w + 1);
-      const float* part = a.span_part + (size_t)(w + 1) * (6 * kWave) + lane;
+    if (SPLIT && r1 < a.eh) {
+      // the group's first rows: add what the other wave (lower workgroup id, dispatched earlier) publishes
+      split_acquire(a.split_flags, slot);
+      const float* part = a.split_part + (size_t)slot * (6 * kWave) + lane;
 #pragma unroll
-      for (int i = 0; i < 6; ++i) o6[i] += span_load(part + i * kWave);
-      span_release(a.span_flags, w + 1);
+      for (int i = 0; i < 6; ++i) o6[i] += split_load(part + i * kWave);
+      split_release(a.split_flags, slot);
     }
     if (x.active) {
       const size_t o = (size_t)b * 3 * RC;
@@ -378,22 +374,26 @@ __global__ __launch_bounds__(kWave, 2) void fwd_pk_kernel(const Args a) {
   SGR_TRACE_END
 }
 
-// Row-span ("stream-K") launch: a.span_waves single-wave workgroups -- as many as the chip holds at two per SIMD -- each
-// take a contiguous, equally long run of the (group, table row) sequence, so every wave slot is busy for the whole
-// kernel whatever the number of groups (at 16 images the 4800 groups are 2.34 per slot: one group per workgroup leaves
-// the slots idle for 22 % of the kernel).  Runs are at least eh rows long, so a group is shared by at most two waves.
+// Tail-split launch.  One group per single-wave workgroup leaves the chip's wave slots (two per SIMD) badly filled in the
+// last round: at 16 images 4800 groups are 2.34 per slot, and for the last ~50 us a third of the SIMDs hold one lone wave
+// and the rest nothing (profiles/r02b_wavetrace_report.txt).  Here the LAST a.split_groups groups of the grid are each
+// run as two workgroups of eh/2 table rows -- shorter work items, dispatched last, that pack the final round -- and
+// share their radiance sums through the workspace (fwd_pk_group).  Workgroup ids: [0, G - S) whole groups, then for
+// split group s the pair (G - S + 2 s: last rows = producer, G - S + 2 s + 1: first rows = consumer).
+// (A static partition into equal runs of (group, row) items -- one persistent wave per slot -- was measured slower:
+// the SIMD's issue arbitration favours one of its two waves, which then finishes early and leaves the other alone for
+// the last 40 % of the kernel, profiles/r02d_wavetrace_static_row_spans.txt.)
 template <int KP, int POOL, bool WRITE_ENV, bool DO_RENDER>
-__global__ __launch_bounds__(kWave, 2) void fwd_pk_span_kernel(const Args a) {
+__global__ __launch_bounds__(kWave, 2) void fwd_pk_split_kernel(const Args a) {
   __shared__ __attribute__((aligned(16))) float tile[WRITE_ENV ? Tile<16>::kFloats : 4];
   SGR_TRACE_BEGIN
-  const int eh = a.eh, w = (int)blockIdx.x;
-  const long long U = (long long)a.bn * ((a.R * a.C + kWave - 1) / kWave) * eh;
-  int u = (int)(U * w / a.span_waves);
-  const int u1 = (int)(U * (w + 1) / a.span_waves);
-  while (u < u1) {
-    const int g = u / eh, r0 = u - g * eh, r1 = min(eh, r0 + (u1 - u));
-    fwd_pk_group<KP, POOL, 16, WRITE_ENV, DO_RENDER, true>(a, tile, g, r0, r1, w);
-    u += r1 - r0;
+  const int G = a.bn * ((a.R * a.C + kWave - 1) / kWave), whole = G - a.split_groups, id = (int)blockIdx.x;
+  if (id < whole) {
+    fwd_pk_group<KP, POOL, 16, WRITE_ENV, DO_RENDER, false>(a, tile, id, 0, a.eh, 0);
+  } else {
+    const int j = id - whole, s = j >> 1, mid = a.eh >> 1;
+    if ((j & 1) == 0) fwd_pk_group<KP, POOL, 16, WRITE_ENV, DO_RENDER, true>(a, tile, whole + s, mid, a.eh, s);
+    else fwd_pk_group<KP, POOL, 16, WRITE_ENV, DO_RENDER, true>(a, tile, whole + s, 0, mid, s);
   }
   SGR_TRACE_END
 }
@@ -421,12 +421,12 @@ __device__ __forceinline__ void tile32_read_two_pairs2(const float* tile, int pl
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// One work item of the packed backward: table rows [r0, r1) of the 32-pixel group `g` (see fwd_pk_group for SPAN).
+// One work item of the packed backward: table rows [r0, r1) of the 32-pixel group `g` (see fwd_pk_group for SPLIT).
 // `tile`: a ring of three one-row LDS-DMA buffers (18 KB).  Rows are requested two at a time, back to back (the two
 // 64-byte halves of every 128-byte line of the image), one row ahead of their use; non-temporal, since the cotangent is
 // read exactly once and must not push the SG parameters out of the Infinity Cache
-template <int POOL, bool HAS_GENV, bool HAS_RENDER, bool SPAN>
-__device__ __forceinline__ void sg_bwd_pk_group(const Args& a, float* tile, const int g, const int r0, const int r1, const int w) {
+template <int POOL, bool HAS_GENV, bool HAS_RENDER, bool SPLIT>
+__device__ __forceinline__ void sg_bwd_pk_group(const Args& a, float* tile, const int g, const int r0, const int r1, const int slot) {
   constexpr int EW = 16, HALF = 8, NP = 4, KPW = 6;
   const int lane = threadIdx.x, half = lane >> 5, pl = lane & 31;
   const int own = 1 - half;                         // the half row (sign) whose BRDF terms this half-wave evaluates
@@ -572,25 +572,25 @@ __device__ __forceinline__ void sg_bwd_pk_group(const Args& a, float* tile, cons
     }
     o[k][3] = glk; o[k][4] = q0; o[k][5] = q1; o[k][6] = q2;
   }
-  if (SPAN && r0 > 0) {
-    // the group's last rows (first item of this wave's span): hand the partial gradients to wave w - 1
-    float* part = a.span_part + (size_t)w * (7 * KPW * kWave) + lane;
+  if (SPLIT && r0 > 0) {
+    // the group's last rows: hand the partial gradients to the wave that owns row 0
+    float* part = a.split_part + (size_t)slot * (7 * KPW * kWave) + lane;
 #pragma unroll
     for (int k = 0; k < KPW; ++k)
 #pragma unroll
-      for (int i = 0; i < 7; ++i) span_store(part + (k * 7 + i) * kWave, o[k][i]);
-    span_publish(a.span_flags, w);
+      for (int i = 0; i < 7; ++i) split_store(part + (k * 7 + i) * kWave, o[k][i]);
+    split_publish(a.split_flags, slot);
     return;
   }
-  if (SPAN && r1 < a.eh) {
-    // the group's first rows (last item of this wave's span): wave w + 1 published the rest long ago
-    span_acquire(a.span_flags, w + 1);
-    const float* part = a.span_part + (size_t)(w + 1) * (7 * KPW * kWave) + lane;
+  if (SPLIT && r1 < a.eh) {
+    // the group's first rows: add what the other wave (lower workgroup id, dispatched earlier) publishes
+    split_acquire(a.split_flags, slot);
+    const float* part = a.split_part + (size_t)slot * (7 * KPW * kWave) + lane;
 #pragma unroll
     for (int k = 0; k < KPW; ++k)
 #pragma unroll
-      for (int i = 0; i < 7; ++i) o[k][i] += span_load(part + (k * 7 + i) * kWave);
-    span_release(a.span_flags, w + 1);
+      for (int i = 0; i < 7; ++i) o[k][i] += split_load(part + (k * 7 + i) * kWave);
+    split_release(a.split_flags, slot);
   }
   if (x.active) {
     float* g_axis_b = a.g_axis + (size_t)b * K * 3 * RC;
@@ -622,29 +622,28 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
   SGR_TRACE_END
 }
 
-// row-span launch (see fwd_pk_span_kernel): 9600 groups at 16 images are 4.7 per wave slot
+// tail-split launch (see fwd_pk_split_kernel)
 template <int POOL, bool HAS_GENV, bool HAS_RENDER>
-__global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_span_kernel(const Args a) {
+__global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_split_kernel(const Args a) {
   __shared__ __attribute__((aligned(16))) float tile[HAS_GENV ? 3 * kT32Floats : 4];
   SGR_TRACE_BEGIN
-  const int eh = a.eh, w = (int)blockIdx.x;
-  const long long U = (long long)a.bn * ((a.R * a.C + kPx - 1) / kPx) * eh;
-  int u = (int)(U * w / a.span_waves);
-  const int u1 = (int)(U * (w + 1) / a.span_waves);
-  while (u < u1) {
-    const int g = u / eh, r0 = u - g * eh, r1 = min(eh, r0 + (u1 - u));
-    sg_bwd_pk_group<POOL, HAS_GENV, HAS_RENDER, true>(a, tile, g, r0, r1, w);
-    u += r1 - r0;
+  const int G = a.bn * ((a.R * a.C + kPx - 1) / kPx), whole = G - a.split_groups, id = (int)blockIdx.x;
+  if (id < whole) {
+    sg_bwd_pk_group<POOL, HAS_GENV, HAS_RENDER, false>(a, tile, id, 0, a.eh, 0);
+  } else {
+    const int j = id - whole, s = j >> 1, mid = a.eh >> 1;
+    if ((j & 1) == 0) sg_bwd_pk_group<POOL, HAS_GENV, HAS_RENDER, true>(a, tile, whole + s, mid, a.eh, s);
+    else sg_bwd_pk_group<POOL, HAS_GENV, HAS_RENDER, true>(a, tile, whole + s, 0, mid, s);
   }
   SGR_TRACE_END
 }
 
-// ---- host side of the row-span launches -------------------------------------------------------------------------
-// Workspace = [16 KB of flags][slots x 42 x 64 floats of partial results]; slots = CUs x 4 SIMDs x 2 resident waves (the
-// span kernels need more than 170 VGPRs, so exactly two fit a SIMD and `slots` workgroups occupy every SIMD evenly).
-constexpr size_t kSpanFlagBytes = 16384;
-constexpr int kSpanPartFloats = 42 * kWave;
-static inline int span_slots() {
+// ---- host side of the tail-split launches ---------------------------------------------------------------------
+// Workspace = [16 KB of flags][slots x 42 x 64 floats of partial results]; slots = CUs x 4 SIMDs x 2 resident waves (these
+// kernels need more than 170 VGPRs, so exactly two fit a SIMD); at most `slots` groups are ever split.
+constexpr size_t kSplitFlagBytes = 16384;
+constexpr int kSplitPartFloats = 42 * kWave;
+static inline int wave_slots() {
   static int cus[64] = {0};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
@@ -655,18 +654,63 @@ static inline int span_slots() {
   }
   return cus[dev] * 8;
 }
-static inline size_t span_workspace_bytes() { return kSpanFlagBytes + (size_t)span_slots() * kSpanPartFloats * sizeof(float); }
-static inline bool span_env_off() {      // SGR_SPAN=0: one group per workgroup even when a workspace is given (A/B knob)
-  static const bool off = [] { const char* e = getenv("SGR_SPAN"); return e != nullptr && e[0] == '0' && e[1] == 0; }();
-  return off;
+static inline size_t split_workspace_bytes() { return kSplitFlagBytes + (size_t)wave_slots() * kSplitPartFloats * sizeof(float); }
+static inline int split_env() {      // SGR_SPLIT=0: never split (A/B knob); SGR_SPLIT=n > 0: split exactly min(n, groups, slots) groups
+  static const int v = [] { const char* e = getenv("SGR_SPLIT"); return e ? atoi(e) : -1; }();
+  return v;
 }
-static inline void span_setup(Args& a, void* ws, size_t ws_bytes) {
-  const int slots = span_slots();
-  if (!ws || slots <= 0 || (size_t)slots * sizeof(unsigned) > kSpanFlagBytes || ws_bytes < span_workspace_bytes() || span_env_off()) return;
-  a.span_flags = reinterpret_cast<unsigned*>(ws);
-  a.span_part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + kSpanFlagBytes);
-  a.span_waves = slots;
+// How many of the last groups to run as two half-row-range workgroups: list scheduling of the work items on `slots`
+// identical wave slots in dispatch order (whole groups first, then the halves).  Cost of an item = its table rows +
+// kSplitPrologueRows row-equivalents for the prologue every item pays (lobe loads, tan pre-map, shading frame).  After
+// the whole groups the slots stand at two levels (one round apart); the halves are poured on the lower level first.  The
+// candidate with the smallest makespan wins, ties go to fewer splits.  A few hundred flops of host arithmetic per launch.
+constexpr double kSplitPrologueRows = 2.0;
+static inline double split_makespan(int groups, int S, int slots, int eh) {
+  const double whole = eh + kSplitPrologueRows, half = 0.5 * eh + kSplitPrologueRows;
+  const int n = groups - S, full = n / slots, rem = n % slots;
+  double lv[2] = {full * whole, (full + 1) * whole};
+  const long long cnt[2] = {slots - rem, rem};
+  double worst = rem ? lv[1] : lv[0];
+  long long items = 2LL * S;
+  while (items > 0) {
+    const int c = (cnt[1] == 0 || lv[0] <= lv[1]) ? 0 : 1;
+    if (items < cnt[c]) {
+      worst = lv[c] + half > worst ? lv[c] + half : worst;
+      items = 0;
+    } else {
+      lv[c] += half;
+      worst = lv[c] > worst ? lv[c] : worst;
+      items -= cnt[c];
+    }
+  }
+  return worst;
 }
-static inline bool span_enabled(const Args& a, int groups) { return a.span_flags != nullptr && groups > a.span_waves; }
+static inline int choose_split(int groups, int slots, int eh) {
+  if (slots <= 0 || groups <= 0 || eh < 2) return 0;
+  const int forced = split_env();
+  const int cap = groups < slots ? groups : slots;
+  if (forced == 0) return 0;
+  if (forced > 0) return forced < cap ? forced : cap;
+  int best = 0;
+  double best_t = split_makespan(groups, 0, slots, eh);
+  auto consider = [&](int S) {
+    if (S <= 0 || S > cap) return;
+    const double t = split_makespan(groups, S, slots, eh);
+    if (t < best_t - 1e-9 || (t < best_t + 1e-9 && S < best)) { best_t = t; best = S; }
+  };
+  consider(groups % slots);                      // the whole groups then fill complete rounds
+  for (int S = 64; S <= cap; S += 64) consider(S);
+  consider(cap);
+  return best;
+}
+static inline void split_setup(Args& a, void* ws, size_t ws_bytes) {
+  const int slots = wave_slots();
+  if (!ws || slots <= 0 || (size_t)slots * sizeof(unsigned) > kSplitFlagBytes || ws_bytes < split_workspace_bytes()) return;
+  a.split_flags = reinterpret_cast<unsigned*>(ws);
+  a.split_part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + kSplitFlagBytes);
+  a.split_slots = slots;
+}
+// number of groups to split for this launch (0: plain launch)
+static inline int split_count(const Args& a, int groups) { return a.split_flags ? choose_split(groups, a.split_slots, a.eh) : 0; }
 
 }  // namespace sgr

@@ -30,128 +30,9 @@ from . import _lib, tables
 __all__ = ["light_albedo_scale", "light_encoder_input", "light_heads", "unpack_envmaps", "output2env", "renderingLayer", "render_from_sg", "renderLayer", "output_radiance", "predToShading"]
 
 
-# --------------------------------------------------------------------------- #
-# small helpers                                                                #
-# --------------------------------------------------------------------------- #
-def _ptr(t: Optional[torch.Tensor]):
-    return None if t is None else t.data_ptr()
-
-
-def _stream(dev: torch.device):
-    return torch.cuda.current_stream(dev).cuda_stream
-
-
-def _require_hip(*ts: torch.Tensor) -> torch.device:
-    dev = None
-    for t in ts:
-        if t is None:
-            continue
-        if not torch.is_tensor(t):
-            raise TypeError("sgrender: expected torch tensors")
-        if not t.is_cuda:
-            raise RuntimeError(
-                "sgrender: this layer runs only on HIP device tensors (MI355X); there is no CPU path. "
-                "Move the inputs to the GPU (the reference's isCuda=True mode).")
-        if t.dtype != torch.float32:
-            raise RuntimeError(f"sgrender: fp32 tensors required, got {t.dtype}")
-        if dev is None:
-            dev = t.device
-        elif t.device != dev:
-            raise RuntimeError(f"sgrender: tensors on different devices ({dev} vs {t.device})")
-    return dev
-
-
-class _DeviceTables:
-    """Constant tables, created lazily on whichever device the inputs live on.
-
-    The reference keeps them as bare attributes on the layer object, created on the current
-    device when ``isCuda`` (models.py:454-459) and never moved by ``.to()``; keying by device
-    keeps that behaviour while making one object usable from several ranks / devices."""
-
-    MAX_ENTRIES = 64      # testReal.py builds a layer per image size: keep the cache bounded
-
-    def __init__(self):
-        self._cache: Dict[Tuple, torch.Tensor] = {}
-
-    def get(self, key: Tuple, dev: torch.device, make):
-        k = key + (str(dev),)
-        t = self._cache.get(k)
-        if t is None:
-            if len(self._cache) >= self.MAX_ENTRIES:
-                self._cache.pop(next(iter(self._cache)))      # oldest entry
-            t = torch.from_numpy(np.ascontiguousarray(make())).to(dev)
-            self._cache[k] = t
-        return t
-
-
-_TABLES = _DeviceTables()
-
-
-def _dirs(dev, eh: int, ew: int) -> torch.Tensor:
-    return _TABLES.get(("dirs", eh, ew), dev, lambda: tables.packed_direction_table(eh, ew))
-
-
-def _view(dev, R: int, C: int, fov: float, cam: Tuple[float, float, float]) -> torch.Tensor:
-    return _TABLES.get(("view", R, C, float(fov), tuple(float(c) for c in cam)), dev,
-                       lambda: tables.view_vectors(C, R, fov, cam))
-
-
-class _SpanWorkspaces:
-    """Workspace of the row-span launches (include/sgrender.h: sgr_fused_fwd_ws / sgr_fused_bwd_sg_ws): one zero-filled
-    buffer per (device, stream), created on first use and reused -- every call leaves it as it found it.  Inside a
-    HIP-graph capture nothing may be cached (the memory belongs to the graph's pool), so a fresh buffer is made per call
-    and only its flag words are cleared."""
-
-    FLAG_BYTES = 16384
-
-    def __init__(self):
-        self._cache: Dict[Tuple, torch.Tensor] = {}
-
-    def get(self, dev: torch.device) -> Tuple[Optional[torch.Tensor], int]:
-        nbytes = int(_lib.load().sgr_span_workspace_bytes())
-        if nbytes <= self.FLAG_BYTES:
-            return None, 0
-        if torch.cuda.is_current_stream_capturing():
-            ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
-            ws[:self.FLAG_BYTES].zero_()
-            return ws, nbytes
-        key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
-        ws = self._cache.get(key)
-        if ws is None or ws.numel() < nbytes:
-            if len(self._cache) >= 16:
-                self._cache.pop(next(iter(self._cache)))
-            ws = torch.zeros(nbytes, device=dev, dtype=torch.uint8)
-            self._cache[key] = ws
-        return ws, nbytes
-
-
-_SPAN_WS = _SpanWorkspaces()
-
-
-def _check_sg(axis, lamb, weight, K: Optional[int]):
-    if axis.dim() != 5 or axis.shape[2] != 3:
-        raise RuntimeError(f"sgrender: axis must be [bn,SGNum,3,envRow,envCol], got {tuple(axis.shape)}")
-    bn, k, _, R, C = axis.shape
-    if K is not None and k != K:
-        raise RuntimeError(f"sgrender: axis has {k} lobes, layer was built with SGNum={K}")
-    if tuple(lamb.shape) != (bn, k, R, C):
-        raise RuntimeError(f"sgrender: lamb must be [bn,SGNum,envRow,envCol]={(bn, k, R, C)}, got {tuple(lamb.shape)}")
-    if tuple(weight.shape) != (bn, 3 * k, R, C):
-        raise RuntimeError(f"sgrender: weight must be [bn,3*SGNum,envRow,envCol]={(bn, 3 * k, R, C)}, got {tuple(weight.shape)}")
-    if k > 32:
-        raise RuntimeError("sgrender: SGNum > 32 is not supported")
-    return bn, k, R, C
-
-
-def _check_brdf(albedo, normal, rough):
-    if albedo.dim() != 4 or albedo.shape[1] != 3:
-        raise RuntimeError(f"sgrender: diffusePred must be [bn,3,h,w], got {tuple(albedo.shape)}")
-    bn, _, h, w = albedo.shape
-    if tuple(normal.shape) != (bn, 3, h, w):
-        raise RuntimeError(f"sgrender: normalPred must be {(bn, 3, h, w)}, got {tuple(normal.shape)}")
-    if tuple(rough.shape) != (bn, 1, h, w):
-        raise RuntimeError(f"sgrender: roughPred must be {(bn, 1, h, w)}, got {tuple(rough.shape)}")
-    return bn, h, w
+# host-side helpers and the registered operators live in ops.py (torch.ops.sgrender.*); re-exported here for the loss module
+from . import ops  # noqa: E402,F401  (registers the operators)
+from .ops import _check_brdf, _check_sg, _dirs, _ptr, _require_hip, _stream, _view  # noqa: E402,F401
 
 
 def _prepool(albedo, normal, rough, R: int, C: int):
@@ -164,182 +45,6 @@ def _prepool(albedo, normal, rough, R: int, C: int):
         return albedo, normal, rough
     return (F.adaptive_avg_pool2d(albedo, (R, C)), F.adaptive_avg_pool2d(normal, (R, C)),
             F.adaptive_avg_pool2d(rough, (R, C)))
-
-
-# --------------------------------------------------------------------------- #
-# autograd functions: one C-ABI call per direction                             #
-# --------------------------------------------------------------------------- #
-class _SGToEnv(torch.autograd.Function):
-    """sgr_sg_to_env_fwd / sgr_sg_to_env_bwd."""
-
-    @staticmethod
-    def forward(ctx, axis, lamb, weight, eh: int, ew: int, premap: bool, want_tan: bool):
-        dev = _require_hip(axis, lamb, weight)
-        axis_c, lamb_c, weight_c = axis.contiguous(), lamb.contiguous(), weight.contiguous()
-        bn, K, R, C = _check_sg(axis_c, lamb_c, weight_c, None)
-        env = torch.empty((bn, 3, R, C, eh, ew), device=dev, dtype=torch.float32)
-        lam_t = torch.empty_like(lamb_c) if (premap and want_tan) else None
-        w_t = torch.empty_like(weight_c) if (premap and want_tan) else None
-        d = _dirs(dev, eh, ew)
-        with torch.cuda.device(dev):
-            _lib.call("sgr_sg_to_env_fwd", _ptr(axis_c), _ptr(lamb_c), _ptr(weight_c), _ptr(d), _ptr(env),
-                      _ptr(lam_t), _ptr(w_t), bn, K, R, C, eh, ew, int(premap), _stream(dev))
-        ctx.save_for_backward(axis_c, lamb_c, weight_c)
-        ctx.cfg = (eh, ew, premap)
-        ctx.set_materialize_grads(False)
-        if lam_t is None:
-            return env
-        return env, lam_t, w_t
-
-    @staticmethod
-    def backward(ctx, g_env, g_lam_t=None, g_w_t=None):
-        axis, lamb, weight = ctx.saved_tensors
-        eh, ew, premap = ctx.cfg
-        dev = axis.device
-        bn, K, _, R, C = axis.shape
-        g_axis = g_lamb = g_weight = None
-        if g_env is not None:
-            g_env = g_env.contiguous()
-            g_axis, g_lamb, g_weight = torch.empty_like(axis), torch.empty_like(lamb), torch.empty_like(weight)
-            d = _dirs(dev, eh, ew)
-            with torch.cuda.device(dev):
-                _lib.call("sgr_sg_to_env_bwd", _ptr(g_env), _ptr(axis), _ptr(lamb), _ptr(weight), _ptr(d),
-                          _ptr(g_axis), _ptr(g_lamb), _ptr(g_weight), bn, K, R, C, eh, ew, int(premap), _stream(dev))
-        # cotangents of the returned post-tan tensors (nobody in the reference differentiates
-        # through them, wrapperBRDFLight.py:177; handled for completeness with elementwise torch)
-        if g_lam_t is not None or g_w_t is not None:
-            scale = 0.999 * (np.pi / 2)
-            if g_lam_t is not None:
-                y = torch.tan(np.pi / 2 * (0.999 * lamb))
-                extra = g_lam_t * scale * (1 + y * y)
-                g_lamb = extra if g_lamb is None else g_lamb + extra
-            if g_w_t is not None:
-                y = torch.tan(np.pi / 2 * (0.999 * weight))
-                extra = g_w_t * scale * (1 + y * y)
-                g_weight = extra if g_weight is None else g_weight + extra
-        return g_axis, g_lamb, g_weight, None, None, None, None
-
-
-class _RenderEnv(torch.autograd.Function):
-    """sgr_render_env_fwd / sgr_render_env_bwd_env (+ BRDF-map gradients)."""
-
-    @staticmethod
-    def forward(ctx, albedo, normal, rough, env, fov, F0, cam):
-        dev = _require_hip(albedo, normal, rough, env)
-        albedo_c, normal_c, rough_c, env_c = albedo.contiguous(), normal.contiguous(), rough.contiguous(), env.contiguous()
-        bn, h, w = _check_brdf(albedo_c, normal_c, rough_c)
-        if env_c.dim() != 6 or env_c.shape[0] != bn or env_c.shape[1] != 3:
-            raise RuntimeError(f"sgrender: envmap must be [bn,3,envRow,envCol,envHeight,envWidth], got {tuple(env_c.shape)}")
-        _, _, R, C, eh, ew = env_c.shape
-        diffuse = torch.empty((bn, 3, R, C), device=dev, dtype=torch.float32)
-        spec = torch.empty_like(diffuse)
-        d, v = _dirs(dev, eh, ew), _view(dev, R, C, fov, cam)
-        with torch.cuda.device(dev):
-            _lib.call("sgr_render_env_fwd", _ptr(albedo_c), _ptr(normal_c), _ptr(rough_c), _ptr(env_c), _ptr(d), _ptr(v),
-                      _ptr(diffuse), _ptr(spec), bn, R, C, eh, ew, h, w, float(F0), _stream(dev))
-        ctx.save_for_backward(albedo_c, normal_c, rough_c, env_c)
-        ctx.cfg = (fov, F0, cam)
-        return diffuse, spec
-
-    @staticmethod
-    def backward(ctx, g_diffuse, g_spec):
-        albedo, normal, rough, env = ctx.saved_tensors
-        fov, F0, cam = ctx.cfg
-        dev = albedo.device
-        bn, _, h, w = albedo.shape
-        _, _, R, C, eh, ew = env.shape
-        g_diffuse, g_spec = g_diffuse.contiguous(), g_spec.contiguous()
-        d, v = _dirs(dev, eh, ew), _view(dev, R, C, fov, cam)
-        g_env = g_alb = g_nrm = g_rgh = None
-        with torch.cuda.device(dev):
-            if ctx.needs_input_grad[3]:
-                g_env = torch.empty_like(env)
-                _lib.call("sgr_render_env_bwd_env", _ptr(g_diffuse), _ptr(g_spec), _ptr(albedo), _ptr(normal), _ptr(rough),
-                          _ptr(d), _ptr(v), _ptr(g_env), bn, R, C, eh, ew, h, w, float(F0), _stream(dev))
-            if any(ctx.needs_input_grad[:3]):
-                g_alb, g_nrm, g_rgh = _brdf_grads(g_diffuse, g_spec, albedo, normal, rough, env, None, None, None,
-                                                  d, v, R, C, eh, ew, F0, False, ctx.needs_input_grad[:3])
-        return g_alb, g_nrm, g_rgh, g_env, None, None, None
-
-
-class _FusedRender(torch.autograd.Function):
-    """sgr_fused_fwd / sgr_fused_bwd_sg (+ BRDF-map gradients)."""
-
-    @staticmethod
-    def forward(ctx, albedo, normal, rough, axis, lamb, weight, eh, ew, fov, F0, cam, premap, need_env):
-        dev = _require_hip(albedo, normal, rough, axis, lamb, weight)
-        albedo_c, normal_c, rough_c = albedo.contiguous(), normal.contiguous(), rough.contiguous()
-        axis_c, lamb_c, weight_c = axis.contiguous(), lamb.contiguous(), weight.contiguous()
-        bn, K, R, C = _check_sg(axis_c, lamb_c, weight_c, None)
-        bn2, h, w = _check_brdf(albedo_c, normal_c, rough_c)
-        if bn2 != bn:
-            raise RuntimeError("sgrender: BRDF maps and SG parameters disagree on the batch size")
-        env = torch.empty((bn, 3, R, C, eh, ew), device=dev, dtype=torch.float32) if need_env else None
-        diffuse = torch.empty((bn, 3, R, C), device=dev, dtype=torch.float32)
-        spec = torch.empty_like(diffuse)
-        d, v = _dirs(dev, eh, ew), _view(dev, R, C, fov, cam)
-        with torch.cuda.device(dev):
-            ws, ws_bytes = _SPAN_WS.get(dev)
-            _lib.call("sgr_fused_fwd_ws", _ptr(albedo_c), _ptr(normal_c), _ptr(rough_c), _ptr(axis_c), _ptr(lamb_c),
-                      _ptr(weight_c), _ptr(d), _ptr(v), _ptr(env), _ptr(diffuse), _ptr(spec),
-                      bn, K, R, C, eh, ew, h, w, float(F0), int(premap), _ptr(ws), ws_bytes, _stream(dev))
-        # the env image, when it exists, feeds the BRDF-map gradients (the env-given kernel is faster than re-evaluating the SG)
-        if need_env and any(ctx.needs_input_grad[:3]):
-            ctx.save_for_backward(albedo_c, normal_c, rough_c, axis_c, lamb_c, weight_c, env)
-        else:
-            ctx.save_for_backward(albedo_c, normal_c, rough_c, axis_c, lamb_c, weight_c)
-        ctx.cfg = (eh, ew, fov, F0, cam, premap)
-        ctx.set_materialize_grads(False)
-        if need_env:
-            return env, diffuse, spec
-        return diffuse, spec
-
-    @staticmethod
-    def backward(ctx, *grads):
-        saved = ctx.saved_tensors
-        albedo, normal, rough, axis, lamb, weight = saved[:6]
-        env_saved = saved[6] if len(saved) > 6 else None
-        eh, ew, fov, F0, cam, premap = ctx.cfg
-        if len(grads) == 3:
-            g_env, g_diffuse, g_spec = grads
-        else:
-            g_env = None
-            g_diffuse, g_spec = grads
-        dev = albedo.device
-        bn, _, h, w = albedo.shape
-        _, K, _, R, C = axis.shape
-        d, v = _dirs(dev, eh, ew), _view(dev, R, C, fov, cam)
-        zeros = None
-        if g_diffuse is None or g_spec is None:
-            zeros = torch.zeros((bn, 3, R, C), device=dev, dtype=torch.float32)
-        g_diffuse = zeros if g_diffuse is None else g_diffuse.contiguous()
-        g_spec = zeros if g_spec is None else g_spec.contiguous()
-        g_env = None if g_env is None else g_env.contiguous()
-        g_axis = g_lamb = g_weight = g_alb = g_nrm = g_rgh = None
-        with torch.cuda.device(dev):
-            if any(ctx.needs_input_grad[3:6]):
-                g_axis, g_lamb, g_weight = torch.empty_like(axis), torch.empty_like(lamb), torch.empty_like(weight)
-                ws, ws_bytes = _SPAN_WS.get(dev)
-                _lib.call("sgr_fused_bwd_sg_ws", _ptr(g_env), _ptr(g_diffuse), _ptr(g_spec), _ptr(albedo), _ptr(normal),
-                          _ptr(rough), _ptr(axis), _ptr(lamb), _ptr(weight), _ptr(d), _ptr(v),
-                          _ptr(g_axis), _ptr(g_lamb), _ptr(g_weight),
-                          bn, K, R, C, eh, ew, h, w, float(F0), int(premap), _ptr(ws), ws_bytes, _stream(dev))
-            if any(ctx.needs_input_grad[:3]):
-                g_alb, g_nrm, g_rgh = _brdf_grads(g_diffuse, g_spec, albedo, normal, rough, env_saved, axis, lamb, weight,
-                                                  d, v, R, C, eh, ew, F0, premap, ctx.needs_input_grad[:3])
-        return (g_alb, g_nrm, g_rgh, g_axis, g_lamb, g_weight) + (None,) * 7
-
-
-def _brdf_grads(g_diffuse, g_spec, albedo, normal, rough, env, axis, lamb, weight, d, v, R, C, eh, ew, F0, premap, needs):
-    """d/d{albedo, normal, rough}: sgr_render_bwd_brdf (env given, or re-evaluated from the SG)."""
-    dev = albedo.device
-    bn, _, h, w = albedo.shape
-    g_alb, g_nrm, g_rgh = torch.empty_like(albedo), torch.empty_like(normal), torch.empty_like(rough)
-    K = 0 if axis is None else axis.shape[1]
-    _lib.call("sgr_render_bwd_brdf", _ptr(g_diffuse), _ptr(g_spec), _ptr(albedo), _ptr(normal), _ptr(rough),
-              _ptr(env), _ptr(axis), _ptr(lamb), _ptr(weight), _ptr(d), _ptr(v),
-              _ptr(g_alb), _ptr(g_nrm), _ptr(g_rgh), bn, K, R, C, eh, ew, h, w, float(F0), int(premap), _stream(dev))
-    return (g_alb if needs[0] else None, g_nrm if needs[1] else None, g_rgh if needs[2] else None)
 
 
 # --------------------------------------------------------------------------- #
@@ -359,13 +64,15 @@ class output2env:
 
     def fromSGtoIm(self, axis, lamb, weight):
         """models.py:371-389 (lamb / weight already post-tan)."""
-        bn, K, R, C = _check_sg(axis, lamb, weight, self.SGNum)
-        return _SGToEnv.apply(axis, lamb, weight, self.envHeight, self.envWidth, False, False)
+        _require_hip(axis, lamb, weight)
+        _check_sg(axis, lamb, weight, self.SGNum)
+        return torch.ops.sgrender.sg_to_env(axis, lamb, weight, self.envHeight, self.envWidth, False, False)[0]
 
     def output2env(self, axisOrig, lambOrig, weightOrig):
         """models.py:391-404: returns ``(envmaps, axis, lamb_tan, weight_tan)``."""
+        _require_hip(axisOrig, lambOrig, weightOrig)
         _check_sg(axisOrig, lambOrig, weightOrig, self.SGNum)
-        env, lamb, weight = _SGToEnv.apply(axisOrig, lambOrig, weightOrig, self.envHeight, self.envWidth, True, True)
+        env, lamb, weight = torch.ops.sgrender.sg_to_env(axisOrig, lambOrig, weightOrig, self.envHeight, self.envWidth, True, True)
         return env, axisOrig, lamb, weight
 
 
@@ -404,19 +111,19 @@ class renderingLayer:
         self._check_grid(R, C)
         if (eh, ew) != (self.envHeight, self.envWidth):
             raise RuntimeError("sgrender: envmap direction grid does not match the layer's envHeight x envWidth")
+        _require_hip(diffusePred, normalPred, roughPred, envmap)
         a, n, r = _prepool(diffusePred, normalPred, roughPred, R, C)
-        return _RenderEnv.apply(a, n, r, envmap, self.fov_deg, self.F0, self._cam)
+        return torch.ops.sgrender.render_env(a, n, r, envmap, self.fov_deg, float(self.F0), list(self._cam))
 
     def forwardSG(self, diffusePred, normalPred, roughPred, axisOrig, lambOrig, weightOrig, need_env=True, premap=True):
         """Fused ``output2env.output2env`` + ``forwardEnv``: ``(env or None, colorDiffuse, colorSpec)``."""
         bn, K, R, C = _check_sg(axisOrig, lambOrig, weightOrig, None)
         self._check_grid(R, C)
+        _require_hip(diffusePred, normalPred, roughPred, axisOrig, lambOrig, weightOrig)
         a, n, r = _prepool(diffusePred, normalPred, roughPred, R, C)
-        out = _FusedRender.apply(a, n, r, axisOrig, lambOrig, weightOrig, self.envHeight, self.envWidth,
-                                 self.fov_deg, self.F0, self._cam, bool(premap), bool(need_env))
-        if need_env:
-            return out
-        return (None,) + tuple(out)
+        env, d, s = torch.ops.sgrender.fused_render(a, n, r, axisOrig, lambOrig, weightOrig, self.envHeight, self.envWidth,
+                                                    self.fov_deg, float(self.F0), list(self._cam), bool(premap), bool(need_env))
+        return (env if need_env else None), d, s
 
 
 def render_from_sg(albedo, normal, rough, axisOrig, lambOrig, weightOrig, need_env=True, fov=57, F0=0.05,

@@ -91,8 +91,8 @@ def _view(dev, R: int, C: int, fov: float, cam: Sequence[float]) -> Tensor:
     return _TABLES.get(("view", R, C, float(fov), cam), dev, lambda: tables.view_vectors(C, R, fov, cam))
 
 
-class _SpanWorkspaces:
-    """Workspace of the row-span launches (include/sgrender.h: sgr_fused_fwd_ws / sgr_fused_bwd_sg_ws): one zero-filled
+class _SplitWorkspaces:
+    """Workspace of the tail-split launches (include/sgrender.h: sgr_fused_fwd_ws / sgr_fused_bwd_sg_ws): one zero-filled
     buffer per (device, stream), created on first use and reused -- every call leaves it as it found it.  Inside a
     HIP-graph capture nothing may be cached (the memory belongs to the graph's pool), so a fresh buffer is made per call
     and only its flag words are cleared."""
@@ -103,7 +103,7 @@ class _SpanWorkspaces:
         self._cache: Dict[Tuple, Tensor] = {}
 
     def get(self, dev: torch.device) -> Tuple[Optional[Tensor], int]:
-        nbytes = int(_lib.load().sgr_span_workspace_bytes())
+        nbytes = int(_lib.load().sgr_split_workspace_bytes())
         if nbytes <= self.FLAG_BYTES:
             return None, 0
         if torch.cuda.is_current_stream_capturing():
@@ -120,7 +120,7 @@ class _SpanWorkspaces:
         return ws, nbytes
 
 
-_SPAN_WS = _SpanWorkspaces()
+_SPLIT_WS = _SplitWorkspaces()
 
 
 def _check_sg(axis, lamb, weight, K: Optional[int]):
@@ -362,7 +362,7 @@ def fused_render(albedo: Tensor, normal: Tensor, rough: Tensor, axis: Tensor, la
     spec = torch.empty_like(diffuse)
     d, v = _dirs(dev, eh, ew), _view(dev, R, C, fov, cam)
     with torch.cuda.device(dev):
-        ws, ws_bytes = _SPAN_WS.get(dev)
+        ws, ws_bytes = _SPLIT_WS.get(dev)
         _lib.call("sgr_fused_fwd_ws", _ptr(albedo_c), _ptr(normal_c), _ptr(rough_c), _ptr(axis_c), _ptr(lamb_c),
                   _ptr(weight_c), _ptr(d), _ptr(v), _ptr(env) if need_env else None, _ptr(diffuse), _ptr(spec),
                   bn, K, R, C, eh, ew, h, w, float(F0), int(premap), _ptr(ws), ws_bytes, _stream(dev))
@@ -392,7 +392,7 @@ def fused_render_bwd_sg(g_env: Optional[Tensor], g_diffuse: Tensor, g_spec: Tens
     g_axis, g_lamb, g_weight = torch.empty_like(axis), torch.empty_like(lamb), torch.empty_like(weight)
     d, v = _dirs(dev, eh, ew), _view(dev, R, C, fov, cam)
     with torch.cuda.device(dev):
-        ws, ws_bytes = _SPAN_WS.get(dev)
+        ws, ws_bytes = _SPLIT_WS.get(dev)
         _lib.call("sgr_fused_bwd_sg_ws", _ptr(g_env), _ptr(g_diffuse), _ptr(g_spec), _ptr(albedo), _ptr(normal),
                   _ptr(rough), _ptr(axis), _ptr(lamb), _ptr(weight), _ptr(d), _ptr(v),
                   _ptr(g_axis), _ptr(g_lamb), _ptr(g_weight),

@@ -1,9 +1,10 @@
-"""GPU: the row-span ("stream-K") launches of the packed forward / backward kernels (include/sgrender.h: sgr_fused_fwd_ws,
-sgr_fused_bwd_sg_ws) against the one-group-per-wave launches of the same kernels, called through the C ABI on the same
-device buffers: env image bit-identical; diffuse / spec / SG gradients equal up to the rounding of the one extra addition
-a shared group costs; workspace left zero-filled; results bit-reproducible from launch to launch.  (Parity of both launch
-forms against the oracle and the reference fixtures: test_gpu_parity.py, test_gpu_fullsize.py -- the package's autograd
-functions use the workspace form.)"""
+"""GPU: the tail-split launches of the packed forward / backward kernels (include/sgrender.h: sgr_fused_fwd_ws,
+sgr_fused_bwd_sg_ws: the last groups of the grid run as two workgroups of half the table rows each and share their sums
+through the workspace) against the plain one-group-per-workgroup launches of the same kernels, called through the C ABI
+on the same device buffers: env image bit-identical; diffuse / spec / SG gradients equal up to the rounding of the one
+extra addition a split group costs; workspace left zero-filled; results bit-reproducible from launch to launch.
+(Parity of both launch forms against the oracle and the reference fixtures: test_gpu_parity.py, test_gpu_fullsize.py --
+the package's operators use the workspace form.)"""
 import pytest
 import torch
 
@@ -53,19 +54,21 @@ def _close(a, b, tol):
     return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item() <= tol
 
 
-CASES = [  # bn, imH, imW, R, C, K, eh  (more groups than the 2048 wave slots of an MI355X in every case)
-    (16, 240, 320, 120, 160, 12, 8),     # BASELINE config 2
+CASES = [  # bn, imH, imW, R, C, K, eh
+    (16, 240, 320, 120, 160, 12, 8),     # BASELINE config 2: forward splits its last 704 groups, backward none (4.7 rounds)
+    (14, 240, 320, 120, 160, 12, 8),     # backward: 8400 groups = 4 rounds + 208 -> those 208 are split
     (140, 30, 33, 30, 33, 9, 8),         # ragged last tile of every image, lobes past K, ratio 1
-    (9, 240, 320, 120, 160, 12, 5),      # odd row count per group: runs break groups at every position
+    (9, 240, 320, 120, 160, 12, 5),      # odd row count: the halves are 3 + 2 rows
+    (2, 24, 32, 12, 16, 12, 8),          # fewer groups than wave slots: every group is split
 ]
 
 
 @pytest.mark.parametrize("case", CASES)
-def test_span_launch_matches_one_group_per_wave(env, case):
+def test_split_launch_matches_one_group_per_workgroup(env, case):
     pkg, _lib, L = env
     bn, imH, imW, R, C, K, eh = case
     ew = 16
-    nbytes = int(_lib.load().sgr_span_workspace_bytes())
+    nbytes = int(_lib.load().sgr_split_workspace_bytes())
     assert nbytes > 16384
     x = _inputs(bn, imH, imW, R, C, K, eh, ew, seed=bn + K)
     ws = torch.zeros(nbytes, device="cuda", dtype=torch.uint8)
@@ -74,28 +77,20 @@ def test_span_launch_matches_one_group_per_wave(env, case):
     assert int(ws[:16384].view(torch.int32).abs().sum().item()) == 0, "flags not cleared"
     assert torch.equal(got[0], ref[0]), "env image must be bit-identical"
     names = ("diffuse", "spec", "g_axis", "g_lamb", "g_weight")
-    shared = 0
+    differing = {}
     for n, a, b in zip(names, got[1:], ref[1:]):
         assert torch.isfinite(a).all(), n
         assert _close(a, b, 2e-6), (n, ((a - b).abs().max() / b.abs().max()).item())
-        shared += int((a != b).sum().item())
-    assert shared > 0, "no group was shared between waves: the span launch did not engage"
+        differing[n] = int((a != b).sum().item())
+    assert differing["diffuse"] + differing["spec"] > 0, "no group was split in the forward: the split launch did not engage"
+    if bn != 16:
+        assert differing["g_weight"] > 0, "no group was split in the backward"
     again = _run(env, x, bn, imH, imW, R, C, K, eh, ew, ws)
     for a, b in zip(again, got):
-        assert torch.equal(a, b), "span launch is not bit-reproducible"
+        assert torch.equal(a, b), "split launch is not bit-reproducible"
     # render-only forward and backward without env cotangent
     ref2 = _run(env, x, bn, imH, imW, R, C, K, eh, ew, None, need_env=False, with_genv=False)
     got2 = _run(env, x, bn, imH, imW, R, C, K, eh, ew, ws, need_env=False, with_genv=False)
     for n, a, b in zip(names, got2[1:], ref2[1:]):
         assert _close(a, b, 2e-6), (n, "no-env variant")
     assert int(ws[:16384].view(torch.int32).abs().sum().item()) == 0
-
-
-def test_span_small_batches_fall_back(env):
-    """Fewer groups than wave slots: the workspace form launches the ordinary grid (bit-identical results)."""
-    pkg, _lib, L = env
-    bn, imH, imW, R, C, K, eh, ew = 2, 24, 32, 12, 16, 12, 8, 16
-    x = _inputs(bn, imH, imW, R, C, K, eh, ew, seed=3)
-    ws = torch.zeros(int(_lib.load().sgr_span_workspace_bytes()), device="cuda", dtype=torch.uint8)
-    for a, b in zip(_run(env, x, bn, imH, imW, R, C, K, eh, ew, ws), _run(env, x, bn, imH, imW, R, C, K, eh, ew, None)):
-        assert torch.equal(a, b)

@@ -45,7 +45,7 @@ int main(int argc, char** argv) {
   SYM(sgr_fill_direction_table) SYM(sgr_fill_view_vectors) SYM(sgr_dirs_floats)
   SYM(sgr_sg_to_env_fwd) SYM(sgr_render_env_fwd) SYM(sgr_fused_fwd) SYM(sgr_sg_to_env_bwd) SYM(sgr_fused_bwd_sg)
   SYM(sgr_render_env_bwd_env) SYM(sgr_render_bwd_brdf) SYM(sgr_render_loss_fwd) SYM(sgr_render_loss_bwd) SYM(sgr_loss_workspace_floats)
-  SYM(sgr_fused_fwd_ws) SYM(sgr_fused_bwd_sg_ws) SYM(sgr_span_workspace_bytes)
+  SYM(sgr_fused_fwd_ws) SYM(sgr_fused_bwd_sg_ws) SYM(sgr_split_workspace_bytes)
   SYM(sgr_fused_fwd_recon) SYM(sgr_fused_bwd_recon) SYM(sgr_fused_recon_workspace_floats) SYM(sgr_recon_loss_fwd) SYM(sgr_recon_loss_bwd) SYM(sgr_recon_workspace_floats)
   const int K = argc > 4 ? atoi(argv[4]) : 12;
   const int imH = 240, imW = 320, R = 120, C = 160, eh = 8, ew = 16, J = eh * ew, q = 4;
@@ -108,8 +108,8 @@ int main(int argc, char** argv) {
            bytes_per_px * P / us * 1e-3, bytes_per_px * P / us * 1e-3 / 80.0, P / us);
   };
   printf("# %s  bn=%d  K=%d  P=%zu shaded px  reps=%d  SGR_GENERIC=%s  %s\n", libpath, bn, K, P, reps, getenv("SGR_GENERIC") ? "1" : "0", cold ? "COLD (1 GB memset between launches)" : "warm (same buffers relaunched)");
-  // row-span launches (workspace given): the headline pair
-  const size_t span_bytes = sgr_span_workspace_bytes_p();
+  // tail-split launches (workspace given): the headline pair
+  const size_t span_bytes = sgr_split_workspace_bytes_p();
   void* span_ws; CHECK(hipMalloc(&span_ws, span_bytes)); CHECK(hipMemset(span_ws, 0, span_bytes));
   const bool only_pair = getenv("KBENCH_PAIR") && atoi(getenv("KBENCH_PAIR")) != 0;
   bench("sgr_fused_fwd_ws (env written)", Bbrdf + Bsg + Benv + Bout, [&] { return sgr_fused_fwd_ws_p(albedo, normal, rough, axis, lamb, weight, dirs, view, env, diffuse, spec, bn, K, R, C, eh, ew, imH, imW, F0d, 1, span_ws, span_bytes, st); });
