@@ -312,8 +312,8 @@ def main() -> None:
         tkey = f"config{args.config}_batch{bn}_{'env' if need_env else 'noenv'}"
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         import re
-        want = ([r"sg_bwd_pk_span_kernel<", r"sg_bwd_pk_kernel<", r"sg_bwd_half_kernel<", r"sg_bwd_split_kernel<", r"sg_bwd_fast_kernel<"]
-                if dom[0] == "bwd" else [r"fwd_pk_span_kernel<", r"fwd_pk_kernel<", r"fwd_half_kernel<", r"fwd_fast_kernel<"])
+        want = ([r"sg_bwd_pk_kernel<", r"sg_bwd_half_kernel<", r"sg_bwd_split_kernel<", r"sg_bwd_fast_kernel<"]
+                if dom[0] == "bwd" else [r"fwd_pk_kernel<", r"fwd_half_kernel<", r"fwd_fast_kernel<"])
         if os.path.isfile(tpath):
             try:
                 recs = json.load(open(tpath)).get(tkey, {})
@@ -357,9 +357,9 @@ def main() -> None:
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(dom[3], 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(dom[3] / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": dom[2], "avg_launch_ms": round(dom[1], 4)},
-            "kernels": {"forward (sgr_fused_fwd_ws)": {"ms": round(fwd_ms, 4), "GBps": round(fwd_gbps, 1), "frac": round(fwd_gbps / HBM_PEAK_GBPS, 4),
+            "kernels": {"forward (sgr_fused_fwd)": {"ms": round(fwd_ms, 4), "GBps": round(fwd_gbps, 1), "frac": round(fwd_gbps / HBM_PEAK_GBPS, 4),
                                                        "bytes": fwd_bytes},
-                        "backward (sgr_fused_bwd_sg_ws)": {"ms": round(bwd_ms, 4), "GBps": round(bwd_gbps, 1), "frac": round(bwd_gbps / HBM_PEAK_GBPS, 4),
+                        "backward (sgr_fused_bwd_sg)": {"ms": round(bwd_ms, 4), "GBps": round(bwd_gbps, 1), "frac": round(bwd_gbps / HBM_PEAK_GBPS, 4),
                                                            "bytes": bwd_bytes}},
         }
         if world == 1 and not args.no_cpu_baseline and not args.layer_only and args.config == 2:

@@ -24,8 +24,6 @@
 #ifndef SGRENDER_H_
 #define SGRENDER_H_
 
-#include <stddef.h>
-
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -104,33 +102,6 @@ int sgr_fused_bwd_sg(const float* g_env /* nullable */, const float* g_diffuse, 
                      float* g_axis, float* g_lamb, float* g_weight,
                      int bn, int K, int R, int C, int eh, int ew, int imH, int imW, float F0,
                      int premap, void* stream);
-
-/* The same two calls (wrapperBRDFLight.py:177+194 and their autograd) with a caller-owned workspace of
- * sgr_split_workspace_bytes() bytes of device memory.  With it the launch may run the LAST few pixel groups of the
- * batch as two workgroups each (half of the table rows per workgroup): shorter work items, dispatched last, that
- * fill the final round of the chip's wave slots, which one group per workgroup leaves a third full at 16 images of
- * 120 x 160 cells.  How many groups are split is decided per launch from the group count and the device's slot
- * count (a list-scheduling estimate; SGR_SPLIT=n forces n, SGR_SPLIT=0 disables).  A split group is finished by the
- * workgroup that owns its first rows, which adds the other one's partial sums (handed over through the workspace)
- * to its own: results are deterministic for a given device and batch shape; for split groups diffuse/spec and the
- * SG gradients differ from the plain launch by the rounding of one extra addition; the env image is bit-identical.
- *   workspace contract: zero-filled before its first use; every call leaves it zero-filled where that matters,
- *   so it can be reused call after call on the SAME stream; calls that may run concurrently (different streams)
- *   need their own workspaces.  NULL / too small: identical to the calls without _ws. */
-size_t sgr_split_workspace_bytes(void);
-int sgr_fused_fwd_ws(const float* albedo, const float* normal, const float* rough,
-                     const float* axis, const float* lamb, const float* weight,
-                     const float* dirs, const float* view,
-                     float* env /* nullable */, float* diffuse, float* spec,
-                     int bn, int K, int R, int C, int eh, int ew, int imH, int imW, float F0,
-                     int premap, void* workspace /* nullable */, size_t workspace_bytes, void* stream);
-int sgr_fused_bwd_sg_ws(const float* g_env /* nullable */, const float* g_diffuse, const float* g_spec,
-                        const float* albedo, const float* normal, const float* rough,
-                        const float* axis, const float* lamb, const float* weight,
-                        const float* dirs, const float* view,
-                        float* g_axis, float* g_lamb, float* g_weight,
-                        int bn, int K, int R, int C, int eh, int ew, int imH, int imW, float F0,
-                        int premap, void* workspace /* nullable */, size_t workspace_bytes, void* stream);
 
 /* dL/dEnv of renderingLayer.forwardEnv alone (autograd of models.py:511-520):
  *   g_env[b,c,r,cc,j] = omega_j ndl_j (g_diffuse_c A_c/pi + g_spec_c spec_j)   (out, dense) */

@@ -1,6 +1,7 @@
 """MI355X-native SG x microfacet render layer (drop-in for the reference's models.renderingLayer /
 models.output2env call boundary; the compute lives in libsgrender.so, see include/sgrender.h)."""
 from ._lib import SgrenderError, SgrenderUnavailable  # noqa: F401
+from . import ops  # noqa: F401  (torch.ops.sgrender.* registration)
 from .layers import light_albedo_scale, light_encoder_input, light_heads, output2env, output_radiance, predToShading, render_from_sg, renderingLayer, renderLayer, unpack_envmaps  # noqa: F401
 from .losses import (LSregress, LSregressDiffSpec, combine_loss_parts, light_objective,  # noqa: F401
                      light_objective_supported, recon_loss, render_loss)

@@ -43,9 +43,6 @@ SIGNATURES = {
     "sgr_sg_to_env_fwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], c_int),
     "sgr_render_env_fwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P], c_int),
     "sgr_fused_fwd": ([_P] * 11 + [_I] * 8 + [_F, _I, _P], c_int),
-    "sgr_split_workspace_bytes": ([], ctypes.c_size_t),
-    "sgr_fused_fwd_ws": ([_P] * 11 + [_I] * 8 + [_F, _I, _P, ctypes.c_size_t, _P], c_int),
-    "sgr_fused_bwd_sg_ws": ([_P] * 14 + [_I] * 8 + [_F, _I, _P, ctypes.c_size_t, _P], c_int),
     "sgr_sg_to_env_bwd": ([_P] * 8 + [_I] * 7 + [_P], c_int),
     "sgr_fused_bwd_sg": ([_P] * 14 + [_I] * 8 + [_F, _I, _P], c_int),
     "sgr_render_env_bwd_env": ([_P] * 8 + [_I] * 7 + [_F, _P], c_int),

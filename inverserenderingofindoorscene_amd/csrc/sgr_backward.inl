@@ -242,18 +242,10 @@ static int sgbwd_half_launch(const Args& a, hipStream_t st) {
 template <bool HAS_GENV, bool HAS_RENDER>
 static int sgbwd_pk_launch(const Args& a, hipStream_t st) {
   const dim3 grid((unsigned)(a.bn * ((a.R * a.C + kPx - 1) / kPx))), block(kWave);
-  const bool p1 = !HAS_RENDER || (a.imH == a.R && a.imW == a.C);
-  const int S = split_count(a, (int)grid.x);
-  if (S > 0) {      // tail-split launch, see fwd_pk_launch
-    Args b = a;
-    b.split_groups = S;
-    const dim3 sgrid(grid.x + (unsigned)S);
-    if (p1) hipLaunchKernelGGL((sg_bwd_pk_split_kernel<1, HAS_GENV, HAS_RENDER>), sgrid, block, 0, st, b);
-    else hipLaunchKernelGGL((sg_bwd_pk_split_kernel<2, HAS_GENV, HAS_RENDER>), sgrid, block, 0, st, b);
-    return (int)hipGetLastError();
-  }
-  if (p1) hipLaunchKernelGGL((sg_bwd_pk_kernel<1, HAS_GENV, HAS_RENDER>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((sg_bwd_pk_kernel<2, HAS_GENV, HAS_RENDER>), grid, block, 0, st, a);
+  if (!HAS_RENDER || (a.imH == a.R && a.imW == a.C))
+    hipLaunchKernelGGL((sg_bwd_pk_kernel<1, HAS_GENV, HAS_RENDER>), grid, block, 0, st, a);
+  else
+    hipLaunchKernelGGL((sg_bwd_pk_kernel<2, HAS_GENV, HAS_RENDER>), grid, block, 0, st, a);
   return (int)hipGetLastError();
 }
 static inline int bwd_mode() {     // 4 packed half-wave (default), 0 split (two waves), 2 / 3 scalar half-wave kernel built for that many waves per SIMD

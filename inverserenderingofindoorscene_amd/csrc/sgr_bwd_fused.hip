@@ -3,12 +3,11 @@
 #include "sgr_backward.inl"
 using namespace sgr;
 
-extern "C" int sgr_fused_bwd_sg_ws(const float* g_env, const float* g_diffuse, const float* g_spec,
-                                   const float* albedo, const float* normal, const float* rough, const float* axis,
-                                   const float* lamb, const float* weight, const float* dirs, const float* view,
-                                   float* g_axis, float* g_lamb, float* g_weight, int bn, int K, int R, int C, int eh,
-                                   int ew, int imH, int imW, float F0, int premap, void* workspace, size_t workspace_bytes,
-                                   void* stream) {
+extern "C" int sgr_fused_bwd_sg(const float* g_env, const float* g_diffuse, const float* g_spec,
+                                const float* albedo, const float* normal, const float* rough, const float* axis,
+                                const float* lamb, const float* weight, const float* dirs, const float* view,
+                                float* g_axis, float* g_lamb, float* g_weight, int bn, int K, int R, int C, int eh,
+                                int ew, int imH, int imW, float F0, int premap, void* stream) {
   SGR_REQUIRE(g_diffuse && g_spec && albedo && normal && rough && axis && lamb && weight && dirs && view && g_axis &&
                   g_lamb && g_weight, "sgr_fused_bwd_sg: NULL tensor");
   SGR_REQUIRE(bn > 0 && K > 0 && R > 0 && C > 0 && eh > 0 && ew > 0, "sgr_fused_bwd_sg: non-positive size");
@@ -20,18 +19,8 @@ extern "C" int sgr_fused_bwd_sg_ws(const float* g_env, const float* g_diffuse, c
   a.g_axis = g_axis; a.g_lamb = g_lamb; a.g_weight = g_weight;
   set_dims_b(a, bn, K, R, C, eh, ew, imH, imW);
   a.F0 = F0; a.premap = premap;
-  split_setup(a, workspace, workspace_bytes);
   const hipStream_t st = (hipStream_t)stream;
   return sgr_check(g_env ? sgbwd_launch<true, true>(a, st) : sgbwd_launch<false, true>(a, st), "sgr_fused_bwd_sg");
-}
-
-extern "C" int sgr_fused_bwd_sg(const float* g_env, const float* g_diffuse, const float* g_spec,
-                                const float* albedo, const float* normal, const float* rough, const float* axis,
-                                const float* lamb, const float* weight, const float* dirs, const float* view,
-                                float* g_axis, float* g_lamb, float* g_weight, int bn, int K, int R, int C, int eh,
-                                int ew, int imH, int imW, float F0, int premap, void* stream) {
-  return sgr_fused_bwd_sg_ws(g_env, g_diffuse, g_spec, albedo, normal, rough, axis, lamb, weight, dirs, view, g_axis, g_lamb,
-                             g_weight, bn, K, R, C, eh, ew, imH, imW, F0, premap, nullptr, 0, stream);
 }
 
 extern "C" int sgr_render_env_bwd_env(const float* g_diffuse, const float* g_spec, const float* albedo,

@@ -457,11 +457,6 @@ struct Args {
   int bn, K, R, C, J, Jpad, imH, imW, eh, ew;
   float F0;
   int premap;
-  // tail-split launches of the packed kernels (sgr_pk.inl); split_flags == NULL: one group per workgroup
-  unsigned* split_flags;  // [split_slots]  zero on entry, zero again on exit
-  float* split_part;      // [split_slots][42][64] partial results handed from the wave with a group's last rows to the one with its first
-  int split_slots;        // capacity (the chip's wave slots at two waves per SIMD)
-  int split_groups;       // how many of the grid's last groups run as two workgroups (set per launch)
 };
 
 // Which pixel does this lane own?  One wave = 64 consecutive cells of one image.

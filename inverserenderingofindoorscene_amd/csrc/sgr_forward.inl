@@ -178,18 +178,10 @@ static int fwd_half_launch(const Args& a, hipStream_t st) {
 template <int KP, bool WRITE_ENV, bool DO_RENDER>
 static int fwd_pk_launch(const Args& a, hipStream_t st) {
   const dim3 grid = wave_grid(a.bn, a.R, a.C), block(kWave);
-  const bool p1 = !DO_RENDER || (a.imH == a.R && a.imW == a.C);
-  const int S = (KP == 12 && DO_RENDER) ? split_count(a, (int)grid.x) : 0;      // (KP 6: three waves fit a SIMD; no render: nothing to share)
-  if (S > 0) {      // tail-split launch: the last S groups as two workgroups each (workspace given)
-    Args b = a;
-    b.split_groups = S;
-    const dim3 sgrid(grid.x + (unsigned)S);
-    if (p1) hipLaunchKernelGGL((fwd_pk_split_kernel<KP, 1, WRITE_ENV, DO_RENDER>), sgrid, block, 0, st, b);
-    else hipLaunchKernelGGL((fwd_pk_split_kernel<KP, 2, WRITE_ENV, DO_RENDER>), sgrid, block, 0, st, b);
-    return (int)hipGetLastError();
-  }
-  if (p1) hipLaunchKernelGGL((fwd_pk_kernel<KP, 1, WRITE_ENV, DO_RENDER>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((fwd_pk_kernel<KP, 2, WRITE_ENV, DO_RENDER>), grid, block, 0, st, a);
+  if (!DO_RENDER || (a.imH == a.R && a.imW == a.C))
+    hipLaunchKernelGGL((fwd_pk_kernel<KP, 1, WRITE_ENV, DO_RENDER>), grid, block, 0, st, a);
+  else
+    hipLaunchKernelGGL((fwd_pk_kernel<KP, 2, WRITE_ENV, DO_RENDER>), grid, block, 0, st, a);
   return (int)hipGetLastError();
 }
 static inline int fwd_mode() {     // 4 packed (default), 0 scalar one pixel per lane, 2 / 3 scalar half-wave kernel, -1 round-1 default

@@ -2,12 +2,10 @@
 #include "sgr_forward.inl"
 using namespace sgr;
 
-extern "C" size_t sgr_split_workspace_bytes(void) { return split_workspace_bytes(); }
-
-extern "C" int sgr_fused_fwd_ws(const float* albedo, const float* normal, const float* rough, const float* axis,
-                                const float* lamb, const float* weight, const float* dirs, const float* view,
-                                float* env, float* diffuse, float* spec, int bn, int K, int R, int C, int eh, int ew,
-                                int imH, int imW, float F0, int premap, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int sgr_fused_fwd(const float* albedo, const float* normal, const float* rough, const float* axis,
+                             const float* lamb, const float* weight, const float* dirs, const float* view,
+                             float* env, float* diffuse, float* spec, int bn, int K, int R, int C, int eh, int ew,
+                             int imH, int imW, float F0, int premap, void* stream) {
   SGR_REQUIRE(albedo && normal && rough && axis && lamb && weight && dirs && view && diffuse && spec,
               "sgr_fused_fwd: NULL tensor");
   SGR_REQUIRE(bn > 0 && K > 0 && R > 0 && C > 0 && eh > 0 && ew > 0, "sgr_fused_fwd: non-positive size");
@@ -18,17 +16,8 @@ extern "C" int sgr_fused_fwd_ws(const float* albedo, const float* normal, const 
   a.dirs = reinterpret_cast<const float4*>(dirs); a.view = view; a.env_out = env; a.diffuse = diffuse; a.spec = spec;
   set_dims(a, bn, K, R, C, eh, ew, imH, imW);
   a.F0 = F0; a.premap = premap;
-  split_setup(a, workspace, workspace_bytes);
   const hipStream_t st = (hipStream_t)stream;
   return sgr_check(env ? fwd_launch<true, true, true>(a, st) : fwd_launch<true, false, true>(a, st), "sgr_fused_fwd");
-}
-
-extern "C" int sgr_fused_fwd(const float* albedo, const float* normal, const float* rough, const float* axis,
-                             const float* lamb, const float* weight, const float* dirs, const float* view,
-                             float* env, float* diffuse, float* spec, int bn, int K, int R, int C, int eh, int ew,
-                             int imH, int imW, float F0, int premap, void* stream) {
-  return sgr_fused_fwd_ws(albedo, normal, rough, axis, lamb, weight, dirs, view, env, diffuse, spec, bn, K, R, C, eh, ew, imH, imW,
-                          F0, premap, nullptr, 0, stream);
 }
 
 #ifdef SGR_TRACE

@@ -52,45 +52,6 @@ __device__ __forceinline__ f32x2 half_of(f32x2 p, int i) { return i ? SGR_HI(p) 
 typedef const f32x4 __attribute__((address_space(4))) * PairTable;   // per azimuth pair: (ca_a, ca_a+1, sa_a, sa_a+1)
 __device__ __forceinline__ PairTable as_pair_table(const float* cols, int ew) { return (PairTable)(cols + 4 * ew); }
 
-// ---- hand-off between the two waves that share a split group (they may sit on different XCDs, whose L2s are not coherent) ----
-// Everything that crosses goes through agent-scope (sc1) accesses: partial results and flag are written through to
-// memory, the consumer's loads bypass its own L2.  No release / acquire FENCE on purpose: at agent scope a fence is
-// buffer_wbl2 / buffer_inv -- a write-back or invalidate of the XCD's whole L2 in the middle of a kernel that streams
-// 0.5 GB through those L2s (measured with 2048 fences per launch: 412 instead of 263 us for the backward).  Ordering
-// instead: the producer waits for its partial stores to be acknowledged (vmcnt 0) before it stores the flag; the
-// consumer's partial loads are issued after the flag load has returned the published value.
-// flags[s] is 0 on entry to the kernel, set by the producer of split group s once its partial results are in
-// split_part, and cleared again by the consumer after it has read them: the workspace leaves every launch as it entered it.
-// No deadlock: the producer has the lower workgroup id, workgroups are dispatched in id order (per XCD), and a producer
-// waits for nothing -- so the lowest-numbered unfinished workgroup can always run.
-__device__ __forceinline__ void split_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float split_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void split_publish(unsigned* flags, int s) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (threadIdx.x == 0) __hip_atomic_store(flags + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void split_acquire(unsigned* flags, int s) {
-  while (__hip_atomic_load(flags + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
-  asm volatile("" ::: "memory");
-}
-__device__ __forceinline__ void split_release(unsigned* flags, int s) {
-  if (threadIdx.x == 0) __hip_atomic_store(flags + s, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// the PX-pixel group `g` of the batch (PX = 64: one pixel per lane; 32: lanes l and l + 32 share a pixel)
-template <int PX>
-__device__ __forceinline__ Pix locate_group(const Args& a, int g) {
-  Pix x;
-  x.lane = threadIdx.x;
-  const int RC = a.R * a.C;
-  const int tiles = (RC + PX - 1) / PX;
-  const int pl = x.lane & (PX - 1);
-  x.b = g / tiles;
-  x.p0 = (g - x.b * tiles) * PX;
-  x.active = (x.p0 + pl) < RC;
-  x.p = x.active ? (x.p0 + pl) : (RC - 1);
-  return x;
-}
-
 // SG parameters of the lane's pixel in register pairs (KP even; lobes past K carry zero weights).
 // FOLD: axis pre-multiplied by lp = lam * log2e (forward); unit axes otherwise (backward).
 template <int KP>
@@ -219,20 +180,18 @@ __device__ __forceinline__ void shade_pair(const PixLocal& q, const OrthoPix& oq
 #ifndef SGR_PK_TJ
 #define SGR_PK_TJ 16      // directions per flushed env tile row: 16 = one table row (64-byte segments), 32 = two rows (128-byte)
 #endif
-// One work item of the packed forward: table rows [r0, r1) of the 64-pixel group `g`.  SPLIT = false: the whole group
-// (r0 = 0, r1 = eh), results stored directly.  SPLIT = true (fwd_pk_split_kernel below): the group may be shared by two
-// waves; the one that owns its last rows publishes its partial radiance sums in slot `slot` of the workspace, the one
-// that owns row 0 adds them to its own and stores.
-template <int KP, int POOL, int TJ, bool WRITE_ENV, bool DO_RENDER, bool SPLIT>
-__device__ __forceinline__ void fwd_pk_group(const Args& a, float* tile, const int g, const int r0, const int r1, const int slot) {
-  constexpr int EW = 16, HALF = 8, NQ = 2, RPT = TJ / EW;
-  static_assert(!SPLIT || RPT == 1, "split groups flush one table row at a time");
-  const Pix x = locate_group<kWave>(a, g);
+template <int KP, int POOL, bool WRITE_ENV, bool DO_RENDER>
+__global__ __launch_bounds__(kWave, 2) void fwd_pk_kernel(const Args a) {
+  constexpr int EW = 16, TJ = SGR_PK_TJ, HALF = 8, NQ = 2, RPT = TJ / EW;
+  __shared__ __attribute__((aligned(16))) float tile[WRITE_ENV ? Tile<TJ>::kFloats : 4];
+  SGR_TRACE_BEGIN
+
+  const Pix x = locate(a);
   const int lane = x.lane, b = x.b, p = x.p;
   const int RC = a.R * a.C;
 
   LobesPk<KP> P;
-  load_lobes_pk<KP, true>(a, b, (unsigned)p, x.active, 0, P, r0 == 0);
+  load_lobes_pk<KP, true>(a, b, (unsigned)p, x.active, 0, P, true);
 
   PixLocal q;
   OrthoPix oq;
@@ -248,11 +207,13 @@ __device__ __forceinline__ void fwd_pk_group(const Args& a, float* tile, const i
   const PairTable cpt = as_pair_table(a.cols, EW);
   const XTable xt = (XTable)(a.cols + EW);
   const size_t img = (size_t)b * 3 * RC * a.J;
+  const int eh = a.eh;
   f32x2 dacc[3] = {splat2(0.f), splat2(0.f), splat2(0.f)}, sacc[3] = {splat2(0.f), splat2(0.f), splat2(0.f)};
+  SGR_TRACE_MARK
 
   auto row_loop = [&](auto ortho_c) {
     constexpr bool ORTHO = decltype(ortho_c)::value;
-    for (int e = r0; e < r1; ++e) {
+    for (int e = 0; e < eh; ++e) {
       if (DO_RENDER && !ORTHO) fence_row_invariants(q);
       const f32x8 row = rows[e];
       const float sr = row[0];
@@ -323,7 +284,7 @@ __device__ __forceinline__ void fwd_pk_group(const Args& a, float* tile, const i
           }
         }
       }
-      if (WRITE_ENV && ((e + 1) % RPT == 0 || e + 1 == r1)) {
+      if (WRITE_ENV && ((e + 1) % RPT == 0 || e + 1 == eh)) {
         __syncthreads();
         tile_store_global<TJ, true>(tile, a.env_out + img, x.p0, RC, a.J, (e / RPT) * TJ, lane);
         __syncthreads();
@@ -332,68 +293,15 @@ __device__ __forceinline__ void fwd_pk_group(const Args& a, float* tile, const i
   };
   if (ortho) row_loop(std::true_type{}); else row_loop(std::false_type{});
 
-  if (DO_RENDER) {
-    float o6[6] = {(alb[0] * kInvPi) * (dacc[0].x + dacc[0].y), (alb[1] * kInvPi) * (dacc[1].x + dacc[1].y),
-                   (alb[2] * kInvPi) * (dacc[2].x + dacc[2].y), sacc[0].x + sacc[0].y, sacc[1].x + sacc[1].y, sacc[2].x + sacc[2].y};
-    if (SPLIT && r0 > 0) {
-      // the group's last rows: hand the partial sums to the wave that owns row 0
-      float* part = a.split_part + (size_t)slot * (6 * kWave) + lane;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) split_store(part + i * kWave, o6[i]);
-      split_publish(a.split_flags, slot);
-      return;
-    }
-    if (SPLIT && r1 < a.eh) {
-      // the group's first rows: add what the other wave (lower workgroup id, dispatched earlier) publishes
-      split_acquire(a.split_flags, slot);
-      const float* part = a.split_part + (size_t)slot * (6 * kWave) + lane;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) o6[i] += split_load(part + i * kWave);
-      split_release(a.split_flags, slot);
-    }
-    if (x.active) {
-      const size_t o = (size_t)b * 3 * RC;
-      const unsigned up = (unsigned)p;
-      (a.diffuse + o)[up] = o6[0];
-      (a.diffuse + o + RC)[up] = o6[1];
-      (a.diffuse + o + 2 * (size_t)RC)[up] = o6[2];
-      (a.spec + o)[up] = o6[3];
-      (a.spec + o + RC)[up] = o6[4];
-      (a.spec + o + 2 * (size_t)RC)[up] = o6[5];
-    }
-  }
-}
-
-// one 64-pixel group per single-wave workgroup
-template <int KP, int POOL, bool WRITE_ENV, bool DO_RENDER>
-__global__ __launch_bounds__(kWave, 2) void fwd_pk_kernel(const Args a) {
-  constexpr int TJ = SGR_PK_TJ;
-  __shared__ __attribute__((aligned(16))) float tile[WRITE_ENV ? Tile<TJ>::kFloats : 4];
-  SGR_TRACE_BEGIN
-  fwd_pk_group<KP, POOL, TJ, WRITE_ENV, DO_RENDER, false>(a, tile, (int)blockIdx.x, 0, a.eh, 0);
-  SGR_TRACE_END
-}
-
-// Tail-split launch.  One group per single-wave workgroup leaves the chip's wave slots (two per SIMD) badly filled in the
-// last round: at 16 images 4800 groups are 2.34 per slot, and for the last ~50 us a third of the SIMDs hold one lone wave
-// and the rest nothing (profiles/r02b_wavetrace_report.txt).  Here the LAST a.split_groups groups of the grid are each
-// run as two workgroups of eh/2 table rows -- shorter work items, dispatched last, that pack the final round -- and
-// share their radiance sums through the workspace (fwd_pk_group).  Workgroup ids: [0, G - S) whole groups, then for
-// split group s the pair (G - S + 2 s: last rows = producer, G - S + 2 s + 1: first rows = consumer).
-// (A static partition into equal runs of (group, row) items -- one persistent wave per slot -- was measured slower:
-// the SIMD's issue arbitration favours one of its two waves, which then finishes early and leaves the other alone for
-// the last 40 % of the kernel, profiles/r02d_wavetrace_static_row_spans.txt.)
-template <int KP, int POOL, bool WRITE_ENV, bool DO_RENDER>
-__global__ __launch_bounds__(kWave, 2) void fwd_pk_split_kernel(const Args a) {
-  __shared__ __attribute__((aligned(16))) float tile[WRITE_ENV ? Tile<16>::kFloats : 4];
-  SGR_TRACE_BEGIN
-  const int G = a.bn * ((a.R * a.C + kWave - 1) / kWave), whole = G - a.split_groups, id = (int)blockIdx.x;
-  if (id < whole) {
-    fwd_pk_group<KP, POOL, 16, WRITE_ENV, DO_RENDER, false>(a, tile, id, 0, a.eh, 0);
-  } else {
-    const int j = id - whole, s = j >> 1, mid = a.eh >> 1;
-    if ((j & 1) == 0) fwd_pk_group<KP, POOL, 16, WRITE_ENV, DO_RENDER, true>(a, tile, whole + s, mid, a.eh, s);
-    else fwd_pk_group<KP, POOL, 16, WRITE_ENV, DO_RENDER, true>(a, tile, whole + s, 0, mid, s);
+  if (DO_RENDER && x.active) {
+    const size_t o = (size_t)b * 3 * RC;
+    const unsigned up = (unsigned)p;
+    (a.diffuse + o)[up] = (alb[0] * kInvPi) * (dacc[0].x + dacc[0].y);
+    (a.diffuse + o + RC)[up] = (alb[1] * kInvPi) * (dacc[1].x + dacc[1].y);
+    (a.diffuse + o + 2 * (size_t)RC)[up] = (alb[2] * kInvPi) * (dacc[2].x + dacc[2].y);
+    (a.spec + o)[up] = sacc[0].x + sacc[0].y;
+    (a.spec + o + RC)[up] = sacc[1].x + sacc[1].y;
+    (a.spec + o + 2 * (size_t)RC)[up] = sacc[2].x + sacc[2].y;
   }
   SGR_TRACE_END
 }
@@ -421,24 +329,33 @@ __device__ __forceinline__ void tile32_read_two_pairs2(const float* tile, int pl
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// One work item of the packed backward: table rows [r0, r1) of the 32-pixel group `g` (see fwd_pk_group for SPLIT).
-// `tile`: a ring of three one-row LDS-DMA buffers (18 KB).  Rows are requested two at a time, back to back (the two
-// 64-byte halves of every 128-byte line of the image), one row ahead of their use; non-temporal, since the cotangent is
-// read exactly once and must not push the SG parameters out of the Infinity Cache
-template <int POOL, bool HAS_GENV, bool HAS_RENDER, bool SPLIT>
-__device__ __forceinline__ void sg_bwd_pk_group(const Args& a, float* tile, const int g, const int r0, const int r1, const int slot) {
+template <int POOL, bool HAS_GENV, bool HAS_RENDER>
+__global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
   constexpr int EW = 16, HALF = 8, NP = 4, KPW = 6;
+  // env cotangent rows: a ring of three one-row LDS-DMA buffers (18 KB).  Rows are requested two at a time, back to back
+  // (the two 64-byte halves of every 128-byte line of the image), one row ahead of their use; non-temporal, since the
+  // cotangent is read exactly once and must not push the SG parameters out of the Infinity Cache
+  __shared__ __attribute__((aligned(16))) float tile[HAS_GENV ? 3 * kT32Floats : 4];
+  SGR_TRACE_BEGIN
+
   const int lane = threadIdx.x, half = lane >> 5, pl = lane & 31;
   const int own = 1 - half;                         // the half row (sign) whose BRDF terms this half-wave evaluates
   const int RC = a.R * a.C, K = a.K;
-  const Pix x = locate_group<kPx>(a, g);
+  Pix x;
+  x.lane = lane;
+  {
+    const int tiles = (RC + kPx - 1) / kPx;
+    x.b = blockIdx.x / tiles;
+    x.p0 = (blockIdx.x - x.b * tiles) * kPx;
+    x.active = (x.p0 + pl) < RC;
+    x.p = x.active ? (x.p0 + pl) : (RC - 1);
+  }
   const int b = x.b, p = x.p;
-  const int nr = r1 - r0;
 
   __amdgpu_buffer_rsrc_t gimg = env_rsrc(HAS_GENV ? a.g_env + (size_t)b * 3 * RC * a.J : a.view, RC, a.J);
   if (HAS_GENV) {
-    tile32_dma_issue<SGR_PK_BWD_AUX>(tile, gimg, x.p0, RC, a.J, r0 * EW, lane);
-    if (nr > 1) tile32_dma_issue<SGR_PK_BWD_AUX>(tile + kT32Floats, gimg, x.p0, RC, a.J, (r0 + 1) * EW, lane);
+    tile32_dma_issue<SGR_PK_BWD_AUX>(tile, gimg, x.p0, RC, a.J, 0, lane);
+    if (a.eh > 1) tile32_dma_issue<SGR_PK_BWD_AUX>(tile + kT32Floats, gimg, x.p0, RC, a.J, EW, lane);
   }
 
   PixLocal q;
@@ -468,18 +385,19 @@ __device__ __forceinline__ void sg_bwd_pk_group(const Args& a, float* tile, cons
   const SepTable rows = as_sep_table(a.rows);
   const PairTable cpt = as_pair_table(a.cols, EW);
   const XTable xt = (XTable)(a.cols + EW);
+  const int eh = a.eh;
+  SGR_TRACE_MARK
 
   auto row_loop = [&](auto ortho_c) {
     constexpr bool ORTHO = decltype(ortho_c)::value;
-    for (int i = 0; i < nr; ++i) {
-      const int e = r0 + i;
-      const float* cur = tile + (HAS_GENV ? (i % 3) * kT32Floats : 0);
+    for (int e = 0; e < eh; ++e) {
+      const float* cur = tile + (HAS_GENV ? (e % 3) * kT32Floats : 0);
       if (HAS_GENV) {
-        // rows i+1, i+2 (i odd) were requested when row i-1 was done; up to two rows (12 instructions) may stay in flight
-        if ((i & 1) == 0) {
-          if (i + 1 < nr) wait_vmcnt<6>(); else wait_vmcnt<0>();          // in flight at most: row i+1
+        // rows e+1, e+2 (e odd) were requested when row e-1 was done; up to two rows (12 instructions) may stay in flight
+        if ((e & 1) == 0) {
+          if (e + 1 < eh) wait_vmcnt<6>(); else wait_vmcnt<0>();          // in flight at most: row e+1
         } else {
-          if (i + 2 < nr) wait_vmcnt<12>(); else if (i + 1 < nr) wait_vmcnt<6>(); else wait_vmcnt<0>();   // rows i+1, i+2
+          if (e + 2 < eh) wait_vmcnt<12>(); else if (e + 1 < eh) wait_vmcnt<6>(); else wait_vmcnt<0>();   // rows e+1, e+2
         }
       }
       if (HAS_RENDER && !ORTHO) fence_row_invariants(q);
@@ -546,52 +464,15 @@ __device__ __forceinline__ void sg_bwd_pk_group(const Args& a, float* tile, cons
           gy[k] = pfma(ssa, Td, gy[k]);
         }
       }
-      if (HAS_GENV && (i & 1) == 0) {
-        // row i is consumed: its buffer and the one of row i-1 are free -> request rows i+2 and i+3 back to back
-        if (i + 2 < nr) tile32_dma_issue<SGR_PK_BWD_AUX>(tile + ((i + 2) % 3) * kT32Floats, gimg, x.p0, RC, a.J, (e + 2) * EW, lane);
-        if (i + 3 < nr) tile32_dma_issue<SGR_PK_BWD_AUX>(tile + ((i + 3) % 3) * kT32Floats, gimg, x.p0, RC, a.J, (e + 3) * EW, lane);
+      if (HAS_GENV && (e & 1) == 0) {
+        // row e is consumed: its buffer and the one of row e-1 are free -> request rows e+2 and e+3 back to back
+        if (e + 2 < eh) tile32_dma_issue<SGR_PK_BWD_AUX>(tile + ((e + 2) % 3) * kT32Floats, gimg, x.p0, RC, a.J, (e + 2) * EW, lane);
+        if (e + 3 < eh) tile32_dma_issue<SGR_PK_BWD_AUX>(tile + ((e + 3) % 3) * kT32Floats, gimg, x.p0, RC, a.J, (e + 3) * EW, lane);
       }
     }
   };
   if (ortho) row_loop(std::true_type{}); else row_loop(std::false_type{});
 
-  // the lane's 42 results (7 per lobe), chain rule of the pre-map included; every one is linear in the accumulators
-  float o[KPW][7];
-#pragma unroll
-  for (int k = 0; k < KPW; ++k) {
-    const float lpk = (k & 1) ? P.lpp[k / 2].y : P.lpp[k / 2].x;
-    const float w0 = P.w01[k].x, w1 = P.w01[k].y, w2 = (k & 1) ? P.w2p[k / 2].y : P.w2p[k / 2].x;
-    const float lam = lpk * kLn2;
-    o[k][0] = lam * (gx[k].x + gx[k].y);
-    o[k][1] = lam * (gy[k].x + gy[k].y);
-    o[k][2] = lam * (gz[k].x + gz[k].y);
-    float glk = gl[k].x + gl[k].y, q0 = gw0[k].x + gw0[k].y, q1 = gw1[k].x + gw1[k].y, q2 = gw2[k].x + gw2[k].y;
-    if (a.premap) {
-      glk *= premap_grad(lam);
-      q0 *= premap_grad(w0); q1 *= premap_grad(w1); q2 *= premap_grad(w2);
-    }
-    o[k][3] = glk; o[k][4] = q0; o[k][5] = q1; o[k][6] = q2;
-  }
-  if (SPLIT && r0 > 0) {
-    // the group's last rows: hand the partial gradients to the wave that owns row 0
-    float* part = a.split_part + (size_t)slot * (7 * KPW * kWave) + lane;
-#pragma unroll
-    for (int k = 0; k < KPW; ++k)
-#pragma unroll
-      for (int i = 0; i < 7; ++i) split_store(part + (k * 7 + i) * kWave, o[k][i]);
-    split_publish(a.split_flags, slot);
-    return;
-  }
-  if (SPLIT && r1 < a.eh) {
-    // the group's first rows: add what the other wave (lower workgroup id, dispatched earlier) publishes
-    split_acquire(a.split_flags, slot);
-    const float* part = a.split_part + (size_t)slot * (7 * KPW * kWave) + lane;
-#pragma unroll
-    for (int k = 0; k < KPW; ++k)
-#pragma unroll
-      for (int i = 0; i < 7; ++i) o[k][i] += split_load(part + (k * 7 + i) * kWave);
-    split_release(a.split_flags, slot);
-  }
   if (x.active) {
     float* g_axis_b = a.g_axis + (size_t)b * K * 3 * RC;
     float* g_lamb_b = a.g_lamb + (size_t)b * K * RC;
@@ -601,116 +482,25 @@ __device__ __forceinline__ void sg_bwd_pk_group(const Args& a, float* tile, cons
       const int kk = half * KPW + k;
       if (kk < K) {
         const unsigned o3 = (unsigned)(kk * 3 * RC + p), o1 = (unsigned)(kk * RC + p);
-        g_axis_b[o3] = o[k][0];
-        g_axis_b[o3 + RC] = o[k][1];
-        g_axis_b[o3 + 2 * RC] = o[k][2];
-        g_lamb_b[o1] = o[k][3];
-        g_weight_b[o3] = o[k][4];
-        g_weight_b[o3 + RC] = o[k][5];
-        g_weight_b[o3 + 2 * RC] = o[k][6];
+        const float lpk = (k & 1) ? P.lpp[k / 2].y : P.lpp[k / 2].x;
+        const float w0 = P.w01[k].x, w1 = P.w01[k].y, w2 = (k & 1) ? P.w2p[k / 2].y : P.w2p[k / 2].x;
+        const float lam = lpk * kLn2;
+        g_axis_b[o3] = lam * (gx[k].x + gx[k].y);
+        g_axis_b[o3 + RC] = lam * (gy[k].x + gy[k].y);
+        g_axis_b[o3 + 2 * RC] = lam * (gz[k].x + gz[k].y);
+        float glk = gl[k].x + gl[k].y, q0 = gw0[k].x + gw0[k].y, q1 = gw1[k].x + gw1[k].y, q2 = gw2[k].x + gw2[k].y;
+        if (a.premap) {
+          glk *= premap_grad(lam);
+          q0 *= premap_grad(w0); q1 *= premap_grad(w1); q2 *= premap_grad(w2);
+        }
+        g_lamb_b[o1] = glk;
+        g_weight_b[o3] = q0;
+        g_weight_b[o3 + RC] = q1;
+        g_weight_b[o3 + 2 * RC] = q2;
       }
     }
   }
-}
-
-// one 32-pixel group per single-wave workgroup
-template <int POOL, bool HAS_GENV, bool HAS_RENDER>
-__global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
-  __shared__ __attribute__((aligned(16))) float tile[HAS_GENV ? 3 * kT32Floats : 4];
-  SGR_TRACE_BEGIN
-  sg_bwd_pk_group<POOL, HAS_GENV, HAS_RENDER, false>(a, tile, (int)blockIdx.x, 0, a.eh, 0);
   SGR_TRACE_END
 }
-
-// tail-split launch (see fwd_pk_split_kernel)
-template <int POOL, bool HAS_GENV, bool HAS_RENDER>
-__global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_split_kernel(const Args a) {
-  __shared__ __attribute__((aligned(16))) float tile[HAS_GENV ? 3 * kT32Floats : 4];
-  SGR_TRACE_BEGIN
-  const int G = a.bn * ((a.R * a.C + kPx - 1) / kPx), whole = G - a.split_groups, id = (int)blockIdx.x;
-  if (id < whole) {
-    sg_bwd_pk_group<POOL, HAS_GENV, HAS_RENDER, false>(a, tile, id, 0, a.eh, 0);
-  } else {
-    const int j = id - whole, s = j >> 1, mid = a.eh >> 1;
-    if ((j & 1) == 0) sg_bwd_pk_group<POOL, HAS_GENV, HAS_RENDER, true>(a, tile, whole + s, mid, a.eh, s);
-    else sg_bwd_pk_group<POOL, HAS_GENV, HAS_RENDER, true>(a, tile, whole + s, 0, mid, s);
-  }
-  SGR_TRACE_END
-}
-
-// ---- host side of the tail-split launches ---------------------------------------------------------------------
-// Workspace = [16 KB of flags][slots x 42 x 64 floats of partial results]; slots = CUs x 4 SIMDs x 2 resident waves (these
-// kernels need more than 170 VGPRs, so exactly two fit a SIMD); at most `slots` groups are ever split.
-constexpr size_t kSplitFlagBytes = 16384;
-constexpr int kSplitPartFloats = 42 * kWave;
-static inline int wave_slots() {
-  static int cus[64] = {0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-  if (cus[dev] == 0) {
-    int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 0;
-    cus[dev] = n;
-  }
-  return cus[dev] * 8;
-}
-static inline size_t split_workspace_bytes() { return kSplitFlagBytes + (size_t)wave_slots() * kSplitPartFloats * sizeof(float); }
-static inline int split_env() {      // SGR_SPLIT=0: never split (A/B knob); SGR_SPLIT=n > 0: split exactly min(n, groups, slots) groups
-  static const int v = [] { const char* e = getenv("SGR_SPLIT"); return e ? atoi(e) : -1; }();
-  return v;
-}
-// How many of the last groups to run as two half-row-range workgroups: list scheduling of the work items on `slots`
-// identical wave slots in dispatch order (whole groups first, then the halves).  Cost of an item = its table rows +
-// kSplitPrologueRows row-equivalents for the prologue every item pays (lobe loads, tan pre-map, shading frame).  After
-// the whole groups the slots stand at two levels (one round apart); the halves are poured on the lower level first.  The
-// candidate with the smallest makespan wins, ties go to fewer splits.  A few hundred flops of host arithmetic per launch.
-constexpr double kSplitPrologueRows = 2.0;
-static inline double split_makespan(int groups, int S, int slots, int eh) {
-  const double whole = eh + kSplitPrologueRows, half = 0.5 * eh + kSplitPrologueRows;
-  const int n = groups - S, full = n / slots, rem = n % slots;
-  double lv[2] = {full * whole, (full + 1) * whole};
-  const long long cnt[2] = {slots - rem, rem};
-  double worst = rem ? lv[1] : lv[0];
-  long long items = 2LL * S;
-  while (items > 0) {
-    const int c = (cnt[1] == 0 || lv[0] <= lv[1]) ? 0 : 1;
-    if (items < cnt[c]) {
-      worst = lv[c] + half > worst ? lv[c] + half : worst;
-      items = 0;
-    } else {
-      lv[c] += half;
-      worst = lv[c] > worst ? lv[c] : worst;
-      items -= cnt[c];
-    }
-  }
-  return worst;
-}
-static inline int choose_split(int groups, int slots, int eh) {
-  if (slots <= 0 || groups <= 0 || eh < 2) return 0;
-  const int forced = split_env();
-  const int cap = groups < slots ? groups : slots;
-  if (forced == 0) return 0;
-  if (forced > 0) return forced < cap ? forced : cap;
-  int best = 0;
-  double best_t = split_makespan(groups, 0, slots, eh);
-  auto consider = [&](int S) {
-    if (S <= 0 || S > cap) return;
-    const double t = split_makespan(groups, S, slots, eh);
-    if (t < best_t - 1e-9 || (t < best_t + 1e-9 && S < best)) { best_t = t; best = S; }
-  };
-  consider(groups % slots);                      // the whole groups then fill complete rounds
-  for (int S = 64; S <= cap; S += 64) consider(S);
-  consider(cap);
-  return best;
-}
-static inline void split_setup(Args& a, void* ws, size_t ws_bytes) {
-  const int slots = wave_slots();
-  if (!ws || slots <= 0 || (size_t)slots * sizeof(unsigned) > kSplitFlagBytes || ws_bytes < split_workspace_bytes()) return;
-  a.split_flags = reinterpret_cast<unsigned*>(ws);
-  a.split_part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + kSplitFlagBytes);
-  a.split_slots = slots;
-}
-// number of groups to split for this launch (0: plain launch)
-static inline int split_count(const Args& a, int groups) { return a.split_flags ? choose_split(groups, a.split_slots, a.eh) : 0; }
 
 }  // namespace sgr

@@ -13,9 +13,9 @@ kwargs, argument meaning and return values):
 plus the additive fused entry ``render_from_sg`` and ``nn.Module`` aliases
 ``renderLayer`` / ``output_radiance`` (the names BASELINE.json uses).
 
-Everything here is plumbing: shape checks, output allocation with torch, the current HIP
-stream, and ``torch.autograd.Function`` wrappers whose forward/backward are single calls
-into the C ABI.  There is no CPU path: CPU tensors raise.
+Everything here is plumbing: shape checks and calls of the operators registered in ``ops.py``
+(``torch.ops.sgrender.*``: schema + fake-tensor shape function + autograd formula, each a single call into the C ABI
+on the current HIP stream).  There is no CPU path: CPU tensors raise.
 """
 from __future__ import annotations
 

@@ -9,7 +9,7 @@ hand-written kernel) and composes with other autograd code.  The C ABI stays the
   operator (forward)                      reference call it stands for                       C entry point
   sgrender::sg_to_env                     output2env.output2env / fromSGtoIm, models.py:371-404    sgr_sg_to_env_fwd
   sgrender::render_env                    renderingLayer.forwardEnv, models.py:461-522             sgr_render_env_fwd
-  sgrender::fused_render                  both back to back, wrapperBRDFLight.py:177+194           sgr_fused_fwd_ws
+  sgrender::fused_render                  both back to back, wrapperBRDFLight.py:177+194           sgr_fused_fwd
   (backward)  sg_to_env_bwd, render_env_bwd_env, render_bwd_brdf, fused_render_bwd_sg              sgr_*_bwd*
 
 There is no CPU implementation: CPU tensors raise.
@@ -89,38 +89,6 @@ def _dirs(dev, eh: int, ew: int) -> Tensor:
 def _view(dev, R: int, C: int, fov: float, cam: Sequence[float]) -> Tensor:
     cam = tuple(float(c) for c in cam)
     return _TABLES.get(("view", R, C, float(fov), cam), dev, lambda: tables.view_vectors(C, R, fov, cam))
-
-
-class _SplitWorkspaces:
-    """Workspace of the tail-split launches (include/sgrender.h: sgr_fused_fwd_ws / sgr_fused_bwd_sg_ws): one zero-filled
-    buffer per (device, stream), created on first use and reused -- every call leaves it as it found it.  Inside a
-    HIP-graph capture nothing may be cached (the memory belongs to the graph's pool), so a fresh buffer is made per call
-    and only its flag words are cleared."""
-
-    FLAG_BYTES = 16384
-
-    def __init__(self):
-        self._cache: Dict[Tuple, Tensor] = {}
-
-    def get(self, dev: torch.device) -> Tuple[Optional[Tensor], int]:
-        nbytes = int(_lib.load().sgr_split_workspace_bytes())
-        if nbytes <= self.FLAG_BYTES:
-            return None, 0
-        if torch.cuda.is_current_stream_capturing():
-            ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
-            ws[:self.FLAG_BYTES].zero_()
-            return ws, nbytes
-        key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
-        ws = self._cache.get(key)
-        if ws is None or ws.numel() < nbytes:
-            if len(self._cache) >= 16:
-                self._cache.pop(next(iter(self._cache)))
-            ws = torch.zeros(nbytes, device=dev, dtype=torch.uint8)
-            self._cache[key] = ws
-        return ws, nbytes
-
-
-_SPLIT_WS = _SplitWorkspaces()
 
 
 def _check_sg(axis, lamb, weight, K: Optional[int]):
@@ -362,10 +330,9 @@ def fused_render(albedo: Tensor, normal: Tensor, rough: Tensor, axis: Tensor, la
     spec = torch.empty_like(diffuse)
     d, v = _dirs(dev, eh, ew), _view(dev, R, C, fov, cam)
     with torch.cuda.device(dev):
-        ws, ws_bytes = _SPLIT_WS.get(dev)
-        _lib.call("sgr_fused_fwd_ws", _ptr(albedo_c), _ptr(normal_c), _ptr(rough_c), _ptr(axis_c), _ptr(lamb_c),
+        _lib.call("sgr_fused_fwd", _ptr(albedo_c), _ptr(normal_c), _ptr(rough_c), _ptr(axis_c), _ptr(lamb_c),
                   _ptr(weight_c), _ptr(d), _ptr(v), _ptr(env) if need_env else None, _ptr(diffuse), _ptr(spec),
-                  bn, K, R, C, eh, ew, h, w, float(F0), int(premap), _ptr(ws), ws_bytes, _stream(dev))
+                  bn, K, R, C, eh, ew, h, w, float(F0), int(premap), _stream(dev))
     return env, diffuse, spec
 
 
@@ -392,11 +359,10 @@ def fused_render_bwd_sg(g_env: Optional[Tensor], g_diffuse: Tensor, g_spec: Tens
     g_axis, g_lamb, g_weight = torch.empty_like(axis), torch.empty_like(lamb), torch.empty_like(weight)
     d, v = _dirs(dev, eh, ew), _view(dev, R, C, fov, cam)
     with torch.cuda.device(dev):
-        ws, ws_bytes = _SPLIT_WS.get(dev)
-        _lib.call("sgr_fused_bwd_sg_ws", _ptr(g_env), _ptr(g_diffuse), _ptr(g_spec), _ptr(albedo), _ptr(normal),
+        _lib.call("sgr_fused_bwd_sg", _ptr(g_env), _ptr(g_diffuse), _ptr(g_spec), _ptr(albedo), _ptr(normal),
                   _ptr(rough), _ptr(axis), _ptr(lamb), _ptr(weight), _ptr(d), _ptr(v),
                   _ptr(g_axis), _ptr(g_lamb), _ptr(g_weight),
-                  bn, K, R, C, eh, ew, h, w, float(F0), int(premap), _ptr(ws), ws_bytes, _stream(dev))
+                  bn, K, R, C, eh, ew, h, w, float(F0), int(premap), _stream(dev))
     return g_axis, g_lamb, g_weight
 
 

@@ -45,7 +45,6 @@ int main(int argc, char** argv) {
   SYM(sgr_fill_direction_table) SYM(sgr_fill_view_vectors) SYM(sgr_dirs_floats)
   SYM(sgr_sg_to_env_fwd) SYM(sgr_render_env_fwd) SYM(sgr_fused_fwd) SYM(sgr_sg_to_env_bwd) SYM(sgr_fused_bwd_sg)
   SYM(sgr_render_env_bwd_env) SYM(sgr_render_bwd_brdf) SYM(sgr_render_loss_fwd) SYM(sgr_render_loss_bwd) SYM(sgr_loss_workspace_floats)
-  SYM(sgr_fused_fwd_ws) SYM(sgr_fused_bwd_sg_ws) SYM(sgr_split_workspace_bytes)
   SYM(sgr_fused_fwd_recon) SYM(sgr_fused_bwd_recon) SYM(sgr_fused_recon_workspace_floats) SYM(sgr_recon_loss_fwd) SYM(sgr_recon_loss_bwd) SYM(sgr_recon_workspace_floats)
   const int K = argc > 4 ? atoi(argv[4]) : 12;
   const int imH = 240, imW = 320, R = 120, C = 160, eh = 8, ew = 16, J = eh * ew, q = 4;
@@ -108,21 +107,6 @@ int main(int argc, char** argv) {
            bytes_per_px * P / us * 1e-3, bytes_per_px * P / us * 1e-3 / 80.0, P / us);
   };
   printf("# %s  bn=%d  K=%d  P=%zu shaded px  reps=%d  SGR_GENERIC=%s  %s\n", libpath, bn, K, P, reps, getenv("SGR_GENERIC") ? "1" : "0", cold ? "COLD (1 GB memset between launches)" : "warm (same buffers relaunched)");
-  // tail-split launches (workspace given): the headline pair
-  const size_t span_bytes = sgr_split_workspace_bytes_p();
-  void* span_ws; CHECK(hipMalloc(&span_ws, span_bytes)); CHECK(hipMemset(span_ws, 0, span_bytes));
-  const bool only_pair = getenv("KBENCH_PAIR") && atoi(getenv("KBENCH_PAIR")) != 0;
-  bench("sgr_fused_fwd_ws (env written)", Bbrdf + Bsg + Benv + Bout, [&] { return sgr_fused_fwd_ws_p(albedo, normal, rough, axis, lamb, weight, dirs, view, env, diffuse, spec, bn, K, R, C, eh, ew, imH, imW, F0d, 1, span_ws, span_bytes, st); });
-  bench("sgr_fused_fwd_ws (render only)", Bbrdf + Bsg + Bout, [&] { return sgr_fused_fwd_ws_p(albedo, normal, rough, axis, lamb, weight, dirs, view, (float*)nullptr, diffuse, spec, bn, K, R, C, eh, ew, imH, imW, F0d, 1, span_ws, span_bytes, st); });
-  bench("sgr_fused_bwd_sg_ws (g_env+gD,gS)", Bbrdf + Bsg + Bout + Benv + Bsg, [&] { return sgr_fused_bwd_sg_ws_p(g_env, g_d, g_s, albedo, normal, rough, axis, lamb, weight, dirs, view, g_axis, g_lamb, g_weight, bn, K, R, C, eh, ew, imH, imW, F0d, 1, span_ws, span_bytes, st); });
-  bench("sgr_fused_bwd_sg_ws (gD,gS only)", Bbrdf + Bsg + Bout + Bsg, [&] { return sgr_fused_bwd_sg_ws_p((float*)nullptr, g_d, g_s, albedo, normal, rough, axis, lamb, weight, dirs, view, g_axis, g_lamb, g_weight, bn, K, R, C, eh, ew, imH, imW, F0d, 1, span_ws, span_bytes, st); });
-  bench("fwd_ws + bwd_ws back to back", 2 * (Bbrdf + Bsg + Bout) + 2 * Benv + Bsg, [&] {
-    int rc = sgr_fused_fwd_ws_p(albedo, normal, rough, axis, lamb, weight, dirs, view, env, diffuse, spec, bn, K, R, C, eh, ew, imH, imW, F0d, 1, span_ws, span_bytes, st);
-    return rc ? rc : sgr_fused_bwd_sg_ws_p(g_env, g_d, g_s, albedo, normal, rough, axis, lamb, weight, dirs, view, g_axis, g_lamb, g_weight, bn, K, R, C, eh, ew, imH, imW, F0d, 1, span_ws, span_bytes, st); });
-  bench("fwd + bwd back to back (no ws)", 2 * (Bbrdf + Bsg + Bout) + 2 * Benv + Bsg, [&] {
-    int rc = sgr_fused_fwd_p(albedo, normal, rough, axis, lamb, weight, dirs, view, env, diffuse, spec, bn, K, R, C, eh, ew, imH, imW, F0d, 1, st);
-    return rc ? rc : sgr_fused_bwd_sg_p(g_env, g_d, g_s, albedo, normal, rough, axis, lamb, weight, dirs, view, g_axis, g_lamb, g_weight, bn, K, R, C, eh, ew, imH, imW, F0d, 1, st); });
-  if (only_pair) return 0;
   bench("sgr_fused_fwd (env written)", Bbrdf + Bsg + Benv + Bout, [&] { return sgr_fused_fwd_p(albedo, normal, rough, axis, lamb, weight, dirs, view, env, diffuse, spec, bn, K, R, C, eh, ew, imH, imW, F0d, 1, st); });
   bench("sgr_fused_fwd (render only)", Bbrdf + Bsg + Bout, [&] { return sgr_fused_fwd_p(albedo, normal, rough, axis, lamb, weight, dirs, view, (float*)nullptr, diffuse, spec, bn, K, R, C, eh, ew, imH, imW, F0d, 1, st); });
   bench("sgr_sg_to_env_fwd (+tan outputs)", Bsg + Benv + Bsg * 4.0 / 7.0, [&] { return sgr_sg_to_env_fwd_p(axis, lamb, weight, dirs, env, lam_t, w_t, bn, K, R, C, eh, ew, 1, st); });

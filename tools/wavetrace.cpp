@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
   void* lib = dlopen(libpath, RTLD_NOW);
   if (!lib) { fprintf(stderr, "dlopen failed: %s\n", dlerror()); return 1; }
 #define SYM(name) auto name##_p = (decltype(&name))dlsym(lib, #name); if (!name##_p) { fprintf(stderr, "missing %s\n", #name); return 1; }
-  SYM(sgr_fill_direction_table) SYM(sgr_fill_view_vectors) SYM(sgr_dirs_floats) SYM(sgr_fused_fwd) SYM(sgr_fused_bwd_sg) SYM(sgr_fused_fwd_ws) SYM(sgr_fused_bwd_sg_ws) SYM(sgr_split_workspace_bytes)
+  SYM(sgr_fill_direction_table) SYM(sgr_fill_view_vectors) SYM(sgr_dirs_floats) SYM(sgr_fused_fwd) SYM(sgr_fused_bwd_sg)
   typedef int (*set_t)(void*);
   set_t set_fwd = (set_t)dlsym(lib, "sgr_debug_trace_fwd"), set_bwd = (set_t)dlsym(lib, "sgr_debug_trace_bwd");
   if (!set_fwd || !set_bwd) { fprintf(stderr, "library was not built with -DSGR_TRACE\n"); return 1; }
@@ -49,7 +49,7 @@ int main(int argc, char** argv) {
   float* diffuse = dev_empty(P * 3); float* spec = dev_empty(P * 3);
   float* g_d = dev_rand(P * 3, -1, 1, 10); float* g_s = dev_rand(P * 3, -1, 1, 11);
   float* g_axis = dev_empty(P * K * 3); float* g_lamb = dev_empty(P * K); float* g_weight = dev_empty(P * K * 3);
-  const size_t max_waves = (size_t)bn * ((RC + 31) / 32) + 4096;   // + split halves
+  const size_t max_waves = (size_t)bn * ((RC + 31) / 32);
   TraceRec* trace; CHECK(hipMalloc(&trace, sizeof(TraceRec) * max_waves));
   std::vector<TraceRec> h(max_waves);
   hipStream_t st; CHECK(hipStreamCreate(&st));
@@ -65,19 +65,13 @@ int main(int argc, char** argv) {
     unsigned long long tmin = ~0ull; for (size_t i = 0; i < waves; ++i) if (h[i].t0 && h[i].t0 < tmin) tmin = h[i].t0;
     printf("# %s waves=%zu event_us=%.1f\n", name, waves, ms * 1e3);
     for (size_t i = 0; i < waves; ++i)
-      if (h[i].t0) printf("%s %zu %llu %llu %u %u %u %u %u %llu\n", name, i, h[i].t0 - tmin, h[i].t1 - tmin, h[i].xcc & 0xf, (h[i].hw >> 13) & 7, (h[i].hw >> 12) & 1,
+      printf("%s %zu %llu %llu %u %u %u %u %u %llu\n", name, i, h[i].t0 - tmin, h[i].t1 - tmin, h[i].xcc & 0xf, (h[i].hw >> 13) & 7, (h[i].hw >> 12) & 1,
              (h[i].hw >> 8) & 15, (h[i].hw >> 4) & 3, h[i].tp - h[i].t0);
   };
   const size_t w64 = (size_t)bn * ((RC + 63) / 64), w32 = (size_t)bn * ((RC + 31) / 32);
   run("fwd_env", w64, [&] { return sgr_fused_fwd_p(albedo, normal, rough, axis, lamb, weight, dirs, view, env, diffuse, spec, bn, K, R, C, eh, ew, imH, imW, 0.05f, 1, st); });
   run("fwd_noenv", w64, [&] { return sgr_fused_fwd_p(albedo, normal, rough, axis, lamb, weight, dirs, view, (float*)nullptr, diffuse, spec, bn, K, R, C, eh, ew, imH, imW, 0.05f, 1, st); });
   run("bwd_genv", w32, [&] { return sgr_fused_bwd_sg_p(g_env, g_d, g_s, albedo, normal, rough, axis, lamb, weight, dirs, view, g_axis, g_lamb, g_weight, bn, K, R, C, eh, ew, imH, imW, 0.05f, 1, st); });
-  // tail-split launches (workspace given): up to `slots` extra workgroups
-  const size_t span_bytes = sgr_split_workspace_bytes_p(), slots = (span_bytes - 16384) / (42 * 64 * 4);
-  void* span_ws; CHECK(hipMalloc(&span_ws, span_bytes)); CHECK(hipMemset(span_ws, 0, span_bytes));
-  run("fwd_env_split", w64 + slots, [&] { return sgr_fused_fwd_ws_p(albedo, normal, rough, axis, lamb, weight, dirs, view, env, diffuse, spec, bn, K, R, C, eh, ew, imH, imW, 0.05f, 1, span_ws, span_bytes, st); });
-  run("bwd_genv_split", w32 + slots, [&] { return sgr_fused_bwd_sg_ws_p(g_env, g_d, g_s, albedo, normal, rough, axis, lamb, weight, dirs, view, g_axis, g_lamb, g_weight, bn, K, R, C, eh, ew, imH, imW, 0.05f, 1, span_ws, span_bytes, st); });
-  if (getenv("WAVETRACE_SPLIT_ONLY")) return 0;
   // inter-kernel gap: forward and backward back to back (separate trace buffers, absolute timestamps)
   TraceRec* trace2; CHECK(hipMalloc(&trace2, sizeof(TraceRec) * max_waves));
   set_fwd(trace); set_bwd(trace2);
