@@ -122,6 +122,15 @@ class _RenderLossParts(torch.autograd.Function):
         return g_d, g_s, None, None, None, None
 
 
+def ddp_loss_scale(group=None) -> float:
+    """Factor that makes DistributedDataParallel's gradient AVERAGING reproduce the single-process gradient of the
+    batch-global losses of this module (see :func:`combine_loss_parts`): the world size of ``group``; 1.0 when
+    torch.distributed is not initialised."""
+    if dist.is_available() and dist.is_initialized():
+        return float(dist.get_world_size(group))
+    return 1.0
+
+
 def combine_loss_parts(num: torch.Tensor, den_raw: torch.Tensor, group=None, divisor: float = 3.0) -> torch.Tensor:
     """``loss = sum_ranks(num) / max(sum_ranks(den), 1e-5) / divisor`` with the gradient
     ``d loss / d num_local = 1 / (divisor * den_global)``.
@@ -129,7 +138,13 @@ def combine_loss_parts(num: torch.Tensor, den_raw: torch.Tensor, group=None, div
     The reference's losses are ratios of two batch-global sums (wrapperBRDFLight.py:192,205-207), not
     means of per-image losses, so under batch sharding the pair is summed across ranks first: one
     all-reduce of two floats (RCCL over xGMI on the GPU path; pure torch + torch.distributed, so the
-    same code runs under gloo in the CPU tests)."""
+    same code runs under gloo in the CPU tests).
+
+    Gradient convention under sharding: every rank receives the gradient of the GLOBAL loss with respect to ITS
+    shard's inputs -- summed over ranks that is the single-process (reference: nn.DataParallel) gradient.
+    ``DistributedDataParallel`` AVERAGES parameter gradients over ranks, which would leave 1/world_size of it:
+    multiply the loss by :func:`ddp_loss_scale` (= world size) before ``backward()``, or build DDP with a SUM
+    communication hook (tests/test_sharded_loss_gloo.py::test_ddp_gradients_match_single_process)."""
     if group is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
         pair = torch.stack([num.detach(), den_raw.detach().to(num.dtype)])
         dist.all_reduce(pair, op=dist.ReduceOp.SUM, group=group)

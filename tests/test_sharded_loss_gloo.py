@@ -71,6 +71,47 @@ def test_sharded_render_loss_matches_full_batch():
         assert torch.allclose(gs_r, s_f.grad[r * per:(r + 1) * per], rtol=1e-10, atol=1e-14)
 
 
+def _tiny_net():
+    torch.manual_seed(5)
+    return torch.nn.Conv2d(3, 3, 3, padding=1, bias=True).double()
+
+
+def _ddp_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from inverserenderingofindoorscene_amd.losses import combine_loss_parts, ddp_loss_scale
+    inp, d, s = _full_batch()
+    per = BN // world
+    sl = slice(rank * per, (rank + 1) * per)
+    net = torch.nn.parallel.DistributedDataParallel(_tiny_net())
+    d_l, s_l = net(d[sl]), net(s[sl])              # a trainable stage in front of the loss (stands in for the light decoders)
+    _, _, num, den = O.render_loss(d_l, s_l, inp["im"][sl], inp["seg"][sl], R, C)
+    loss = combine_loss_parts(num, den, group=None)
+    (loss * ddp_loss_scale()).backward()           # DDP averages the parameter gradients over the ranks
+    out[rank] = (loss.item(), [p.grad.clone() for p in net.module.parameters()])
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_ddp_gradients_match_single_process():
+    """The light decoders under DistributedDataParallel: with the loss scaled by ddp_loss_scale() the averaged
+    parameter gradients equal the single-process full-batch gradients (what nn.DataParallel gives the reference)."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_ddp_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    inp, d, s = _full_batch()
+    net = _tiny_net()
+    err, _, _, _ = O.render_loss(net(d), net(s), inp["im"], inp["seg"], R, C)
+    err.backward()
+    for r in range(world):
+        loss_r, grads_r = out[r]
+        assert abs(loss_r - err.item()) < 1e-12 * max(1.0, abs(err.item()))
+        for g, p in zip(grads_r, net.parameters()):
+            assert torch.allclose(g, p.grad, rtol=1e-9, atol=1e-13)
+
+
 def test_global_pair_single_process_is_identity():
     from inverserenderingofindoorscene_amd.losses import _global_pair
     a, b, sharded = _global_pair(torch.tensor(2.0), torch.tensor(5.0), None)
