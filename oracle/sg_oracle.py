@@ -174,12 +174,17 @@ def _unit(x: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
 
 
 def render_env(albedo, normal, rough, env, fov_deg: float = 57.0, F0: float = 0.05,
-               camera_pos: Sequence[float] = (0.0, 0.0, 0.0)):
+               camera_pos: Sequence[float] = (0.0, 0.0, 0.0), window=None):
     """Diffuse and specular images from BRDF maps and a per-pixel env image.
 
     models.py:461-522.  ``env [bn,3,R,C,eh,ew]``; the constructor's
     ``imHeight,imWidth`` are the env grid ``R,C`` (trainLight.py:111-113).
     Returns ``(colorDiffuse[bn,3,R,C], colorSpec[bn,3,R,C])``.
+
+    ``window = (R_full, C_full, r0, c0)``: the tensors are the crop ``[r0:r0+R, c0:c0+C]`` of an ``R_full x C_full``
+    env grid (BRDF maps cropped to the matching image pixels).  Every operation of the path is per env cell, so the
+    result is the same crop of the full-grid result; only the view vectors depend on where the cell sits.  (Full-size
+    GPU tests check windows of every image instead of paying the fp64 evaluation of whole batches.)
     """
     bn, _, R, C, eh, ew = env.shape
     dt = env.dtype
@@ -187,7 +192,12 @@ def render_env(albedo, normal, rough, env, fov_deg: float = 57.0, F0: float = 0.
     dev = env.device
     ls = torch.from_numpy(ls_np).to(device=dev, dtype=dt)   # [J,3]
     om = torch.from_numpy(om_np).to(device=dev, dtype=dt)   # [J]
-    v = torch.from_numpy(view_vectors(C, R, fov_deg, camera_pos)).to(device=dev, dtype=dt)[None]   # [1,3,R,C]
+    if window is None:
+        v_np = view_vectors(C, R, fov_deg, camera_pos)
+    else:
+        R_full, C_full, r0, c0 = window
+        v_np = view_vectors(C_full, R_full, fov_deg, camera_pos)[:, r0:r0 + R, c0:c0 + C]
+    v = torch.from_numpy(np.ascontiguousarray(v_np)).to(device=dev, dtype=dt)[None]   # [1,3,R,C]
     J = eh * ew
 
     A, N, rho = pool_brdf(albedo, normal, rough, R, C)
@@ -226,10 +236,10 @@ def render_env(albedo, normal, rough, env, fov_deg: float = 57.0, F0: float = 0.
 
 def render_from_sg(albedo, normal, rough, axis_orig, lamb_orig, weight_orig,
                    env_height: int = 8, env_width: int = 16, fov_deg: float = 57.0, F0: float = 0.05,
-                   camera_pos: Sequence[float] = (0.0, 0.0, 0.0)):
-    """output2env followed by forwardEnv: ``(env, diffuse, spec)``."""
+                   camera_pos: Sequence[float] = (0.0, 0.0, 0.0), window=None):
+    """output2env followed by forwardEnv: ``(env, diffuse, spec)``; ``window``: see :func:`render_env`."""
     env, _, _, _ = output2env(axis_orig, lamb_orig, weight_orig, env_height, env_width)
-    d, s = render_env(albedo, normal, rough, env, fov_deg, F0, camera_pos)
+    d, s = render_env(albedo, normal, rough, env, fov_deg, F0, camera_pos, window)
     return env, d, s
 
 
