@@ -170,43 +170,6 @@ def main() -> None:
     headline_dts = plain_dts if world == 1 else loss_dts
     dt = median(headline_dts)
 
-    # informational: the same step with the batch processed as two half-batches on two HIP streams (forward + backward of
-    # each half on its own stream), so that one half's kernel tails (a 16-image launch covers the chip's wave slots only
-    # ~3 times) are filled by the other half's kernels.  Same work, same results; per-kernel timing is meaningless under
-    # overlap, so the contract line stays the single-stream loop.
-    two_stream_ms = None
-    try:
-        if bn % 2 == 0 and need_env and not args.layer_only:
-            hb = bn // 2
-            xs = [{k: (v[i * hb:(i + 1) * hb].detach().requires_grad_(k in ("axis", "lamb", "weight"))) for k, v in x.items()
-                   if k in ("albedo", "normal", "rough", "axis", "lamb", "weight")} for i in range(2)]
-            cts2 = [[ct_env[i * hb:(i + 1) * hb], ct_d[i * hb:(i + 1) * hb], ct_s[i * hb:(i + 1) * hb]] for i in range(2)]
-            streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
-
-            def step2():
-                cur = torch.cuda.current_stream(dev)
-                for i in range(2):
-                    streams[i].wait_stream(cur)
-                    with torch.cuda.stream(streams[i]):
-                        xi = xs[i]
-                        env, d, s = layer.forwardSG(xi["albedo"], xi["normal"], xi["rough"], xi["axis"], xi["lamb"], xi["weight"], need_env=True)
-                        torch.autograd.grad([env, d, s], [xi["axis"], xi["lamb"], xi["weight"]], grad_outputs=cts2[i])
-                for i in range(2):
-                    cur.wait_stream(streams[i])
-
-            for _ in range(3):
-                step2()
-            barrier()
-            t4 = time.perf_counter()
-            for _ in range(args.steps):
-                step2()
-            barrier()
-            two_stream_ms = (time.perf_counter() - t4) / args.steps * 1e3
-    except Exception as exc:       # informational leg: never fail the bench over it
-        two_stream_ms = None
-        if rank == 0:
-            print(f"# two-stream leg skipped: {str(exc)[:160]}", file=sys.stderr)
-
     # informational: the same two-kernel step captured once in a HIP graph and replayed (no per-launch host work, no
     # event markers between the kernels); per-kernel timing is not possible inside a graph, so the contract line above
     # stays the eager loop
@@ -349,7 +312,6 @@ def main() -> None:
                        "ms_per_step_layer_only": round(plain_ms, 4), "Mpix_per_s_layer_only": mpix(plain_ms),
                        "ms_per_step_with_render_loss": round(loss_step_ms, 4), "Mpix_per_s_with_render_loss": mpix(loss_step_ms),
                        "ms_per_step_hipgraph_replay": None if graph_ms is None else round(graph_ms, 4),
-                       "ms_per_step_two_half_batches_two_streams": None if two_stream_ms is None else round(two_stream_ms, 4),
                        "ms_per_step_light_objective_fused": None if obj_ms is None else round(obj_ms, 4),
                        "ms_per_step_light_objective_unfused": None if obj_unfused_ms is None else round(obj_unfused_ms, 4),
                        "ms_per_step_light_objective_fused_hipgraph_replay": None if obj_graph_ms is None else round(obj_graph_ms, 4),

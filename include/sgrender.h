@@ -148,6 +148,15 @@ int sgr_render_loss_bwd(const float* g_num, const float* diffuse, const float* s
                         const float* im_small, const float* seg_small, const float* coef,
                         float* g_diffuse, float* g_spec, int bn, int R, int C, void* stream);
 
+/* The two steps around the all-reduce of `parts` under batch sharding, kept on the device:
+ *   sgr_loss_finalize:  out[0] = parts[0] / max(parts[1], 1e-5) / divisor  (renderErr, wrapperBRDFLight.py:192,205-207:
+ *                       divisor 3; reconstErr, :179-188: divisor 3 * envHeight * envWidth),  out[1] = d out[0] / d parts[0];
+ *   sgr_render_loss_bwd_scaled:  sgr_render_loss_bwd with *g_num = *g_loss * *g_scale (g_scale = &out[1]; NULL = 1). */
+int sgr_loss_finalize(const float* parts /* [2], rank-summed */, float* out /* [2] */, float divisor, void* stream);
+int sgr_render_loss_bwd_scaled(const float* g_loss, const float* g_scale /* nullable */, const float* diffuse, const float* spec,
+                               const float* im_small, const float* seg_small, const float* coef,
+                               float* g_diffuse, float* g_spec, int bn, int R, int C, void* stream);
+
 /* models.LSregress (models.py:7-21): coef[b] = clamp(<pred_b,gt_b> / max(<pred_b,pred_b>,1e-5), 1e-3, 1e3);
  * n elements per image. */
 int sgr_lsregress_coef(const float* pred, const float* gt, float* coef, float* workspace,

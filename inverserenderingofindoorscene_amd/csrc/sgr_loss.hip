@@ -186,17 +186,26 @@ __global__ __launch_bounds__(kLossThreads) void loss_stage_d(const float* __rest
   }
 }
 
+// ---- loss value and gradient scale from the (rank-summed) totals: wrapperBRDFLight.py:192,205-207 --------
+//   out[0] = num / max(den, 1e-5) / divisor,   out[1] = d out[0] / d num
+__global__ void loss_finalize(const float* __restrict__ parts, float* __restrict__ out, float divisor) {
+  const float den = fmaxf(parts[1], 1e-5f);
+  out[0] = parts[0] / den / divisor;
+  out[1] = 1.0f / den / divisor;
+}
+
 // ---- backward: d(num)/d{diffuse, spec} * g_num ------------------------------------------------
 // num = sum (clamp(kd D + ks S, 0, 1) - imS)^2 seg ; kd, ks are constants HERE because the images that define them arrive
 // detached (wrapperBRDFLight.py:197-201; coefIm and the det indicator are detached by the reference itself, models.py:54,76).
 // The reference does not detach coefDiffuse / coefSpecular: call sites that pass live images differentiate through them,
 // a mode this implementation refuses (losses.py: _no_coef_grad).
 __global__ __launch_bounds__(kLossThreads) void loss_bwd(const float* __restrict__ g_num /* device scalar */,
+                                                          const float* __restrict__ g_scale /* device scalar or NULL */,
                                                           const float* __restrict__ diffuse, const float* __restrict__ spec,
                                                           const float* __restrict__ im_s, const float* __restrict__ seg_s,
                                                           const float* __restrict__ coef, float* __restrict__ g_diffuse,
                                                           float* __restrict__ g_spec, int RC, size_t total) {
-  const float gn = g_num[0];
+  const float gn = g_scale ? g_num[0] * g_scale[0] : g_num[0];
   const int n = 3 * RC;
   for (size_t o = (size_t)blockIdx.x * kLossThreads + threadIdx.x; o < total; o += (size_t)gridDim.x * kLossThreads) {
     const int b = (int)(o / n);
@@ -299,16 +308,28 @@ extern "C" int sgr_render_loss_fwd(const float* diffuse, const float* spec, cons
   return sgr_check((int)hipGetLastError(), "sgr_render_loss_fwd");
 }
 
-extern "C" int sgr_render_loss_bwd(const float* g_num, const float* diffuse, const float* spec, const float* im_small,
-                                   const float* seg_small, const float* coef, float* g_diffuse, float* g_spec, int bn,
-                                   int R, int C, void* stream) {
-  SGR_REQUIRE(g_num && diffuse && spec && im_small && seg_small && coef && g_diffuse && g_spec, "sgr_render_loss_bwd: NULL tensor");
+extern "C" int sgr_render_loss_bwd_scaled(const float* g_loss, const float* g_scale, const float* diffuse, const float* spec,
+                                          const float* im_small, const float* seg_small, const float* coef, float* g_diffuse,
+                                          float* g_spec, int bn, int R, int C, void* stream) {
+  SGR_REQUIRE(g_loss && diffuse && spec && im_small && seg_small && coef && g_diffuse && g_spec, "sgr_render_loss_bwd: NULL tensor");
   SGR_REQUIRE(bn > 0 && R > 0 && C > 0, "sgr_render_loss_bwd: non-positive size");
   const size_t total = (size_t)bn * 3 * R * C;
   const int blocks = (int)((total + kLossThreads * 4 - 1) / (kLossThreads * 4));
-  hipLaunchKernelGGL(loss_bwd, dim3(blocks > 2048 ? 2048 : blocks), dim3(kLossThreads), 0, (hipStream_t)stream, g_num, diffuse,
-                     spec, im_small, seg_small, coef, g_diffuse, g_spec, R * C, total);
+  hipLaunchKernelGGL(loss_bwd, dim3(blocks > 2048 ? 2048 : blocks), dim3(kLossThreads), 0, (hipStream_t)stream, g_loss, g_scale,
+                     diffuse, spec, im_small, seg_small, coef, g_diffuse, g_spec, R * C, total);
   return sgr_check((int)hipGetLastError(), "sgr_render_loss_bwd");
+}
+
+extern "C" int sgr_render_loss_bwd(const float* g_num, const float* diffuse, const float* spec, const float* im_small,
+                                   const float* seg_small, const float* coef, float* g_diffuse, float* g_spec, int bn,
+                                   int R, int C, void* stream) {
+  return sgr_render_loss_bwd_scaled(g_num, nullptr, diffuse, spec, im_small, seg_small, coef, g_diffuse, g_spec, bn, R, C, stream);
+}
+
+extern "C" int sgr_loss_finalize(const float* parts, float* out, float divisor, void* stream) {
+  SGR_REQUIRE(parts && out && divisor > 0.0f, "sgr_loss_finalize: bad argument");
+  hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(1), 0, (hipStream_t)stream, parts, out, divisor);
+  return sgr_check((int)hipGetLastError(), "sgr_loss_finalize");
 }
 
 extern "C" int sgr_lsregress_coef(const float* pred, const float* gt, float* coef, float* workspace, int bn, long long n,

@@ -81,11 +81,17 @@ def LSregressDiffSpec(diff, spec, imOrig, diffOrig, specOrig):
     return kd * diffOrig, ks * specOrig
 
 
-class _RenderLossParts(torch.autograd.Function):
-    """sgr_render_loss_fwd / sgr_render_loss_bwd: ``(num, den_raw, rendered)`` of this rank's shard."""
+def _sharded(group) -> bool:
+    return group is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
+
+class _RenderLoss(torch.autograd.Function):
+    """``(renderErr, rendered)``: sgr_render_loss_fwd -> [all-reduce of the two totals] -> sgr_loss_finalize, and
+    sgr_render_loss_bwd_scaled.  Six small launches per step and no elementwise torch glue: this sits between the two heavy
+    kernels of every training step, where a dozen 5-us launches are worth a tenth of the step."""
 
     @staticmethod
-    def forward(ctx, diffuse, spec, im, seg, R: int, C: int):
+    def forward(ctx, diffuse, spec, im, seg, R: int, C: int, group):
         dev = _require_hip(diffuse, spec, im, seg)
         d, s, im_c, seg_c = diffuse.contiguous(), spec.contiguous(), im.contiguous(), seg.contiguous()
         bn = d.shape[0]
@@ -99,27 +105,29 @@ class _RenderLossParts(torch.autograd.Function):
         rendered = torch.empty_like(im_s)
         coef = torch.empty((bn, 2), device=dev, dtype=torch.float32)
         parts = torch.empty(2, device=dev, dtype=torch.float32)
+        out = torch.empty(2, device=dev, dtype=torch.float32)
         ws = _workspace(bn, dev)
         with torch.cuda.device(dev):
             _lib.call("sgr_render_loss_fwd", _ptr(d), _ptr(s), _ptr(im_c), _ptr(seg_c), _ptr(im_s), _ptr(seg_s),
                       _ptr(rendered), _ptr(coef), _ptr(parts), _ptr(ws), bn, R, C, imH, imW, _stream(dev))
-        ctx.save_for_backward(d, s, im_s, seg_s, coef)
+            if _sharded(group):
+                dist.all_reduce(parts, op=dist.ReduceOp.SUM, group=group)      # [num, den] of the global batch (RCCL over xGMI)
+            _lib.call("sgr_loss_finalize", _ptr(parts), _ptr(out), 3.0, _stream(dev))
+        ctx.save_for_backward(d, s, im_s, seg_s, coef, out)
         ctx.mark_non_differentiable(rendered)
-        num, den = parts[0], parts[1]
-        ctx.mark_non_differentiable(den)
-        return num, den, rendered
+        return out[0], rendered
 
     @staticmethod
-    def backward(ctx, g_num, _g_den, _g_ren):
-        d, s, im_s, seg_s, coef = ctx.saved_tensors
+    def backward(ctx, g_loss, _g_ren):
+        d, s, im_s, seg_s, coef, out = ctx.saved_tensors
         dev = d.device
         bn, _, R, C = d.shape
-        g_num = g_num.contiguous().reshape(1).to(torch.float32)
+        g_loss = g_loss.contiguous().reshape(1).to(torch.float32)
         g_d, g_s = torch.empty_like(d), torch.empty_like(s)
         with torch.cuda.device(dev):
-            _lib.call("sgr_render_loss_bwd", _ptr(g_num), _ptr(d), _ptr(s), _ptr(im_s), _ptr(seg_s), _ptr(coef),
+            _lib.call("sgr_render_loss_bwd_scaled", _ptr(g_loss), _ptr(out[1:]), _ptr(d), _ptr(s), _ptr(im_s), _ptr(seg_s), _ptr(coef),
                       _ptr(g_d), _ptr(g_s), bn, R, C, _stream(dev))
-        return g_d, g_s, None, None, None, None
+        return g_d, g_s, None, None, None, None, None
 
 
 def ddp_loss_scale(group=None) -> float:
@@ -145,7 +153,7 @@ def combine_loss_parts(num: torch.Tensor, den_raw: torch.Tensor, group=None, div
     ``DistributedDataParallel`` AVERAGES parameter gradients over ranks, which would leave 1/world_size of it:
     multiply the loss by :func:`ddp_loss_scale` (= world size) before ``backward()``, or build DDP with a SUM
     communication hook (tests/test_sharded_loss_gloo.py::test_ddp_gradients_match_single_process)."""
-    if group is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+    if _sharded(group):
         pair = torch.stack([num.detach(), den_raw.detach().to(num.dtype)])
         dist.all_reduce(pair, op=dist.ReduceOp.SUM, group=group)
         num_g, den_g = pair[0], pair[1]
@@ -165,8 +173,7 @@ def render_loss(diffuse, spec, im, seg, envRow: int, envCol: int, group=None) ->
     if (h, w) != (envRow, envCol) and (h, w) != (2 * envRow, 2 * envCol):
         im = F.adaptive_avg_pool2d(im, (envRow, envCol))
         seg = F.adaptive_avg_pool2d(seg, (envRow, envCol))
-    num, den, rendered = _RenderLossParts.apply(diffuse, spec, im, seg, envRow, envCol)
-    return combine_loss_parts(num, den, group), rendered
+    return _RenderLoss.apply(diffuse, spec, im, seg, envRow, envCol, group)
 
 
 class _ReconLossParts(torch.autograd.Function):
