@@ -54,8 +54,8 @@ def algorithmic_bytes_per_shaded_px(K: int, J: int, q: int) -> dict:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=300, help="untimed steps first (0.15 s at config 2: the GPU's clocks ramp up over the first ~100 ms of load)")
     ap.add_argument("--batch", type=int, default=16, help="images per GPU")
     ap.add_argument("--reps", type=int, default=5, help="repetitions of the K-step timed loop; the median is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")

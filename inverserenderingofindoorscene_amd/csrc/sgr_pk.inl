@@ -191,7 +191,9 @@ __global__ __launch_bounds__(kWave, 2) void fwd_pk_kernel(const Args a) {
   const int RC = a.R * a.C;
 
   LobesPk<KP> P;
-  load_lobes_pk<KP, true>(a, b, (unsigned)p, x.active, 0, P, true);
+  // the post-tan copies are an output of sgr_sg_to_env_fwd only (no render): a compile-time `false` elsewhere keeps the
+  // scalar branches of the conditional stores out of the pre-map code, whose four chains per lobe then interleave freely
+  load_lobes_pk<KP, true>(a, b, (unsigned)p, x.active, 0, P, !DO_RENDER);
 
   PixLocal q;
   OrthoPix oq;
