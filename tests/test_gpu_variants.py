@@ -3,6 +3,7 @@ knobs (read once per process, hence the subprocesses), must pass the same golden
 
   SGR_BWD_MODE=split              two-wave lobe-split backward (sg_bwd_split_kernel)
   SGR_FWD_MODE/SGR_BWD_MODE=half2 half-wave forward for every forward variant, half-wave backward built for 2 waves/SIMD
+  SGR_FWD_MODE/SGR_BWD_MODE=half3 the same built for 3 waves/SIMD (round 1's defaults; the packed-fp32 kernels are round 2's)
   SGR_FWD_MODE=full               one-pixel-per-lane forward also for the SG -> env call
   SGR_GENERIC=1                   generic kernels (table-driven, any direction grid) on the reference's grid
   SGR_F1_MODE=half                half-wave statistics kernel in the fused objective's forward (objective tests)
@@ -22,6 +23,7 @@ SUBSET = "golden or trainlight"
 @pytest.mark.parametrize("env", [
     {"SGR_BWD_MODE": "split"},
     {"SGR_FWD_MODE": "half2", "SGR_BWD_MODE": "half2"},
+    {"SGR_FWD_MODE": "half3", "SGR_BWD_MODE": "half3"},
     {"SGR_FWD_MODE": "full"},
     {"SGR_GENERIC": "1"},
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
