@@ -277,6 +277,207 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_kernel(const Args a) {
   }
 }
 
+// ---- the same pass with the arithmetic in azimuth pairs (sgr_pk.inl): v_pk_fma_f32 over the directions (e, a), (e, a+1) ----
+// Per azimuth pair and lobe: 8 packed instructions + 4 v_exp for the exponentials and the partial radiance, 23 packed for the
+// gradient accumulation (the exponentials are kept, u / t are re-formed: registers); per pair 6 swaps + 3 packed adds for the
+// radiance, 6 v_rcp + 6 v_log for loss and cotangent, 6 swaps to hand the cotangents round.
+template <int POOL>
+__global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a) {
+  constexpr int EW = 16, HALF = 8, NP = 4, KPW = 6;
+  __shared__ __attribute__((aligned(16))) float tile[2 * kT32Floats];          // ground-truth rows, double-buffered
+
+  const int lane = threadIdx.x, half = lane >> 5, pl = lane & 31;
+  const int own = 1 - half;                         // the half row (sign) this half-wave evaluates the cotangent of
+  const int RC = a.R * a.C, K = a.K;
+  const Pix x = locate_group32(a, (int)blockIdx.x);
+  const int b = x.b, p = x.p;
+
+  __amdgpu_buffer_rsrc_t gimg = env_rsrc(a.env_gt + (size_t)b * 3 * RC * a.J, RC, a.J);
+  tile32_dma_issue(tile, gimg, x.p0, RC, a.J, 0, lane);
+
+  float alb[3];
+  const Frame f = load_frame<POOL>(a, x, alb);
+  PixLocal q = make_local(f, a.F0);
+  OrthoPix oq = make_ortho_pix(q);
+  const bool ortho = __all(frame_is_orthonormal(q));
+  f32x2 gds[3];                                     // (gD_c A_c / pi, gS_c)
+  {
+    const size_t o = (size_t)b * 3 * RC;
+    const unsigned up = (unsigned)p;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      gds[c] = f32x2{(a.g_diffuse + o + (size_t)c * RC)[up] * (alb[c] * kInvPi), (a.g_spec + o + (size_t)c * RC)[up]};
+  }
+  // reconstruction side: x = cf p + off;  dnum/dp = 2 m (ln x - ln(gt + off)) cf / x        (coef is a constant)
+  const float cf = a.coef[b], off = a.offset;
+  const float m = x.active ? (a.mask_in + (size_t)b * RC)[(unsigned)p] : 0.0f;
+  float den;
+  if (a.den_global) {
+    den = a.den_global[0];
+  } else {
+    double sden = 0.0;
+    for (int i = 0; i < a.bn; ++i) sden += (double)a.den_img[i];
+    den = (float)sden;
+  }
+  const float rec_scale = a.rec_w3j / fmaxf(den, 1e-5f);
+  f32x2 grec = splat2(2.0f * m * rec_scale * cf * kLn2);     // times dl (in log2 units) / x
+  f32x2 lossp = splat2(0.0f);
+
+  LobesPk<KPW> P;      // unit axes, lp = lam * log2e, post-tan weights
+  load_lobes_pk<KPW, false>(a, b, (unsigned)p, x.active, half * KPW, P, false);
+  f32x2 gw0[KPW], gw1[KPW], gw2[KPW], gl[KPW], gz[KPW], gx[KPW], gy[KPW];
+#pragma unroll
+  for (int k = 0; k < KPW; ++k) gw0[k] = gw1[k] = gw2[k] = gl[k] = gz[k] = gx[k] = gy[k] = splat2(0.f);
+
+  const SepTable rows = as_sep_table(a.rows);
+  const PairTable cpt = as_pair_table(a.cols, EW);
+  const XTable xt = (XTable)(a.cols + EW);
+  const int eh = a.eh;
+
+  auto row_loop = [&](auto ortho_c) {
+    constexpr bool ORTHO = decltype(ortho_c)::value;
+    for (int e = 0; e < eh; ++e) {
+      const float* cur = tile + (e & 1) * kT32Floats;
+      if (e + 1 < eh) {
+        tile32_dma_issue(tile + ((e + 1) & 1) * kT32Floats, gimg, x.p0, RC, a.J, (e + 1) * EW, lane);
+        wait_vmcnt<6>();        // row e has landed; row e+1 stays in flight
+      } else {
+        wait_vmcnt<0>();
+      }
+      if (!ORTHO) fence_row_invariants(q);
+      const f32x8 row = rows[e];
+      const float sr = row[0], cr = row[1];
+      f32x2 czr[KPW / 2];
+#pragma unroll
+      for (int mm = 0; mm < KPW / 2; ++mm) czr[mm] = pfma(P.azp[mm], splat2(cr), splat2(-1.0f));
+      const RowCtx rc = make_row_ctx(q, row, true);
+      OrthoRow orow = make_ortho_row(rc.ro);
+
+#pragma unroll 1
+      for (int ap = 0; ap < NP; ++ap) {
+        fence_lobes<KPW>(P);
+#pragma unroll
+        for (int mm = 0; mm < KPW / 2; ++mm) { SGR_FENCE2(czr[mm]); SGR_FENCE2(P.lpp[mm]); }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) SGR_FENCE2(gds[c]);
+        SGR_FENCE2(grec);
+        if (ORTHO) { SGR_FENCE2(oq.vB); SGR_FENCE2(oq.ff); SGR_FENCE2(oq.vvk); SGR_FENCE2(orow.nwc); SGR_FENCE2(orow.cvc); }
+        const f32x4 cs = cpt[ap];
+        const f32x2 ca = {cs[0], cs[1]}, sa = {cs[2], cs[3]};
+        const f32x2 srv = splat2(sr);
+        // ---- 1. this half's lobes: exponentials and partial radiance of the 4 directions -----------------
+        f32x2 ep[KPW], em[KPW];
+        f32x2 v[2][3];        // [half row][colour], the azimuth pair
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) v[sg][c] = splat2(0.f);
+#pragma unroll
+        for (int k = 0; k < KPW; ++k) {
+          const f32x2 cz = half_of(czr[k / 2], k & 1), lpk = half_of(P.lpp[k / 2], k & 1), w2 = half_of(P.w2p[k / 2], k & 1);
+          const f32x2 u = pfma(SGR_HI(P.axy[k]), sa, SGR_LO(P.axy[k]) * ca);
+          const f32x2 xp = lpk * pfma(srv, u, cz), xm = lpk * pfma(-srv, u, cz);
+          ep[k] = f32x2{fexp2(xp.x), fexp2(xp.y)};
+          em[k] = f32x2{fexp2(xm.x), fexp2(xm.y)};
+          v[0][0] = pfma(SGR_LO(P.w01[k]), ep[k], v[0][0]); v[0][1] = pfma(SGR_HI(P.w01[k]), ep[k], v[0][1]); v[0][2] = pfma(w2, ep[k], v[0][2]);
+          v[1][0] = pfma(SGR_LO(P.w01[k]), em[k], v[1][0]); v[1][1] = pfma(SGR_HI(P.w01[k]), em[k], v[1][1]); v[1][2] = pfma(w2, em[k], v[1][2]);
+        }
+        // ---- 2. full radiance of the half row this half-wave owns (lanes 0..31: half row 1, 32..63: half row 0)
+        f32x2 tot[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float dx = v[1][c].x, sx = v[0][c].x, dy = v[1][c].y, sy = v[0][c].y;
+          swap32(dx, sx);
+          swap32(dy, sy);
+          tot[c] = f32x2{dx + sx, dy + sy};
+        }
+        // ---- 3. its cotangent: reconstruction term (and loss) + render term --------------------------------
+        float gt[3][2];
+        tile32_read_pair(cur, pl, own * HALF + ap * 2, gt);
+        const f32x2 Pv = pfma(SGR_HI(oq.vB), sa, SGR_LO(oq.vB) * ca);
+        f32x2 wt, sp;
+        shade_pair<ORTHO>(q, oq, rc, orow, own, ca, sa, Pv, xt, ap * 2, wt, sp);
+        f32x2 go[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const f32x2 xx = pfma(splat2(cf), tot[c], splat2(off));
+          const f32x2 r = {__builtin_amdgcn_rcpf(xx.x), __builtin_amdgcn_rcpf(xx.y)};
+          const f32x2 ar = (f32x2{gt[c][0], gt[c][1]} + splat2(off)) * r;
+          const f32x2 dl = {-__builtin_amdgcn_logf(ar.x), -__builtin_amdgcn_logf(ar.y)};   // log2(x / (gt + off))
+          lossp = pfma(dl, dl, lossp);
+          const f32x2 gr = pfma(SGR_HI(gds[c]), sp, SGR_LO(gds[c]));
+          go[c] = pfma(grec * dl, r, wt * gr);
+        }
+        // ---- 4. both half rows' cotangents to all lanes --------------------------------------------------------
+        f32x2 g[2][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float dx = go[c].x, sx = go[c].x, dy = go[c].y, sy = go[c].y;
+          swap32(dx, sx);
+          swap32(dy, sy);
+          g[1][c] = f32x2{dx, dy};     // from lanes 0..31
+          g[0][c] = f32x2{sx, sy};     // from lanes 32..63
+        }
+        // ---- 5. this half's lobes: gradient accumulation (sg_bwd_pk_kernel's inner loop with the kept exponentials)
+        const f32x2 sca = srv * ca, ssa = srv * sa;
+#pragma unroll
+        for (int k = 0; k < KPW; ++k) {
+          const f32x2 cz = half_of(czr[k / 2], k & 1), w2 = half_of(P.w2p[k / 2], k & 1);
+          const f32x2 u = pfma(SGR_HI(P.axy[k]), sa, SGR_LO(P.axy[k]) * ca);
+          const f32x2 tp = pfma(srv, u, cz), tm = pfma(-srv, u, cz);
+          gw0[k] = pfma(g[0][0], ep[k], gw0[k]); gw1[k] = pfma(g[0][1], ep[k], gw1[k]); gw2[k] = pfma(g[0][2], ep[k], gw2[k]);
+          gw0[k] = pfma(g[1][0], em[k], gw0[k]); gw1[k] = pfma(g[1][1], em[k], gw1[k]); gw2[k] = pfma(g[1][2], em[k], gw2[k]);
+          const f32x2 Tp = pfma(g[0][2], w2, pfma(g[0][1], SGR_HI(P.w01[k]), g[0][0] * SGR_LO(P.w01[k]))) * ep[k];
+          const f32x2 Tm = pfma(g[1][2], w2, pfma(g[1][1], SGR_HI(P.w01[k]), g[1][0] * SGR_LO(P.w01[k]))) * em[k];
+          gl[k] = pfma(Tp, tp, gl[k]);
+          gl[k] = pfma(Tm, tm, gl[k]);
+          const f32x2 Ts = Tp + Tm, Td = Tp - Tm;
+          gz[k] = pfma(splat2(cr), Ts, gz[k]);
+          gx[k] = pfma(sca, Td, gx[k]);
+          gy[k] = pfma(ssa, Td, gy[k]);
+        }
+      }
+    }
+  };
+  if (ortho) row_loop(std::true_type{}); else row_loop(std::false_type{});
+
+  // loss partial of the tile: sum_p m_p sum_{c,j} (ln x - ln(gt+off))^2   (each half holds its half rows' share)
+  {
+    float r0 = m * (lossp.x + lossp.y) * (kLn2 * kLn2);
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) r0 += __shfl_xor(r0, s, 64);
+    if (lane == 0) a.ws[blockIdx.x] = r0;
+  }
+
+  if (x.active) {
+    float* g_axis_b = a.g_axis + (size_t)b * K * 3 * RC;
+    float* g_lamb_b = a.g_lamb + (size_t)b * K * RC;
+    float* g_weight_b = a.g_weight + (size_t)b * K * 3 * RC;
+#pragma unroll
+    for (int k = 0; k < KPW; ++k) {
+      const int kk = half * KPW + k;
+      if (kk < K) {
+        const unsigned o3 = (unsigned)(kk * 3 * RC + p), o1 = (unsigned)(kk * RC + p);
+        const float lpk = (k & 1) ? P.lpp[k / 2].y : P.lpp[k / 2].x;
+        const float w0 = P.w01[k].x, w1 = P.w01[k].y, w2 = (k & 1) ? P.w2p[k / 2].y : P.w2p[k / 2].x;
+        const float lam = lpk * kLn2;
+        g_axis_b[o3] = lam * (gx[k].x + gx[k].y);
+        g_axis_b[o3 + RC] = lam * (gy[k].x + gy[k].y);
+        g_axis_b[o3 + 2 * RC] = lam * (gz[k].x + gz[k].y);
+        float glk = gl[k].x + gl[k].y, q0 = gw0[k].x + gw0[k].y, q1 = gw1[k].x + gw1[k].y, q2 = gw2[k].x + gw2[k].y;
+        if (a.premap) {
+          glk *= premap_grad(lam);
+          q0 *= premap_grad(w0); q1 *= premap_grad(w1); q2 *= premap_grad(w2);
+        }
+        g_lamb_b[o1] = glk;
+        g_weight_b[o3] = q0;
+        g_weight_b[o3 + RC] = q1;
+        g_weight_b[o3 + 2 * RC] = q2;
+      }
+    }
+  }
+}
+
 // x *= s / applied, skipped entirely when the two are equal (the usual cotangent of a scalar objective is 1)
 struct RescaleArgs { float* x[4]; long long n[4]; };
 __global__ __launch_bounds__(256) void rescale_kernel(RescaleArgs r, const float* __restrict__ s, const float* __restrict__ applied) {
@@ -331,9 +532,9 @@ extern "C" int sgr_fused_fwd_recon(const float* albedo, const float* normal, con
   a.env_gt = env_gt; a.seg_small = seg_small; a.env_ind = env_ind; a.mask = mask;
   set_dims(a, bn, K, R, C, eh, ew, imH, imW);
   a.F0 = F0; a.premap = premap;
-  // SGR_F1_MODE=half: half-wave statistics kernel (32-pixel work units); default one pixel per lane
-  static const bool f1_half_env = [] { const char* e = getenv("SGR_F1_MODE"); return e && !strcmp(e, "half"); }();
-  const bool f1_half = f1_half_env && K > 6;
+  // SGR_F1_MODE=half: half-wave statistics kernel (32-pixel work units); scalar: round 1's one pixel per lane; default: packed fp32
+  static const int f1_mode = [] { const char* e = getenv("SGR_F1_MODE"); return !e ? 0 : (!strcmp(e, "half") ? 1 : (!strcmp(e, "scalar") ? 2 : 0)); }();
+  const bool f1_half = f1_mode == 1 && K > 6;
   const int tiles = f1_half ? recon_tiles32(R * C) : recon_tiles(R * C);
   float* den_img = workspace;
   float* ws0 = workspace + bn + 4;
@@ -346,7 +547,13 @@ extern "C" int sgr_fused_fwd_recon(const float* albedo, const float* normal, con
     else hipLaunchKernelGGL((fwd_half_kernel<2, false, true, 2, true>), grid, block, 0, st, a);
   } else {
     const dim3 grid = wave_grid(bn, R, C), block(kWave);
-    if (K <= 6) {
+    if (f1_mode == 0 && K <= 6) {
+      if (p1) hipLaunchKernelGGL((fwd_pk_kernel<6, 1, false, true, true>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((fwd_pk_kernel<6, 2, false, true, true>), grid, block, 0, st, a);
+    } else if (f1_mode == 0) {
+      if (p1) hipLaunchKernelGGL((fwd_pk_kernel<12, 1, false, true, true>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((fwd_pk_kernel<12, 2, false, true, true>), grid, block, 0, st, a);
+    } else if (K <= 6) {
       if (p1) hipLaunchKernelGGL((fwd_fast_kernel<6, 1, 16, 16, false, true, true>), grid, block, 0, st, a);
       else hipLaunchKernelGGL((fwd_fast_kernel<6, 2, 16, 16, false, true, true>), grid, block, 0, st, a);
     } else {
@@ -384,8 +591,16 @@ extern "C" int sgr_fused_bwd_recon(const float* albedo, const float* normal, con
   a.ws = ws1; a.den_img = den_img; a.den_global = den_global; a.rec_w3j = rec_weight / (3.0f * (float)(eh * ew));
   const hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)(bn * tiles32)), block(kWave);
-  if (imH == R && imW == C) hipLaunchKernelGGL((sg_bwd_recon_kernel<1>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((sg_bwd_recon_kernel<2>), grid, block, 0, st, a);
+  // SGR_B1_MODE=scalar: round 1's kernel; default: the same pass in packed fp32
+  static const bool b1_scalar = [] { const char* e = getenv("SGR_B1_MODE"); return e && !strcmp(e, "scalar"); }();
+  const bool p1 = (imH == R && imW == C);
+  if (b1_scalar) {
+    if (p1) hipLaunchKernelGGL((sg_bwd_recon_kernel<1>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((sg_bwd_recon_kernel<2>), grid, block, 0, st, a);
+  } else {
+    if (p1) hipLaunchKernelGGL((sg_bwd_recon_pk_kernel<1>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((sg_bwd_recon_pk_kernel<2>), grid, block, 0, st, a);
+  }
   hipLaunchKernelGGL(recon_fold1, dim3(1), dim3(kRThreads), 0, st, ws1, den_img, parts, bn, tiles32);     // parts = (loss numerator, local sum of the env mask)
   return sgr_check((int)hipGetLastError(), "sgr_fused_bwd_recon");
 }

@@ -52,6 +52,18 @@ __device__ __forceinline__ f32x2 half_of(f32x2 p, int i) { return i ? SGR_HI(p) 
 typedef const f32x4 __attribute__((address_space(4))) * PairTable;   // per azimuth pair: (ca_a, ca_a+1, sa_a, sa_a+1)
 __device__ __forceinline__ PairTable as_pair_table(const float* cols, int ew) { return (PairTable)(cols + 4 * ew); }
 
+// the 32-pixel group `g` of a half-wave kernel's grid (lanes l and l + 32 own the same pixel)
+__device__ __forceinline__ Pix locate_group32(const Args& a, int g) {
+  Pix x;
+  x.lane = threadIdx.x;
+  const int RC = a.R * a.C, tiles = (RC + kPx - 1) / kPx, pl = x.lane & 31;
+  x.b = g / tiles;
+  x.p0 = (g - x.b * tiles) * kPx;
+  x.active = (x.p0 + pl) < RC;
+  x.p = x.active ? (x.p0 + pl) : (RC - 1);
+  return x;
+}
+
 // SG parameters of the lane's pixel in register pairs (KP even; lobes past K carry zero weights).
 // FOLD: axis pre-multiplied by lp = lam * log2e (forward); unit axes otherwise (backward).
 template <int KP>
@@ -180,10 +192,17 @@ __device__ __forceinline__ void shade_pair(const PixLocal& q, const OrthoPix& oq
 #ifndef SGR_PK_TJ
 #define SGR_PK_TJ 16      // directions per flushed env tile row: 16 = one table row (64-byte segments), 32 = two rows (128-byte)
 #endif
-template <int KP, int POOL, bool WRITE_ENV, bool DO_RENDER>
+// HAS_GT (fused objective, no env image; see fwd_fast_kernel): the ground-truth env rows stream in by LDS-DMA, one whole
+// table row per 12 KB tile requested the moment the previous row's last pairs are in registers, and every lane accumulates
+// <pred, gt>, <pred, pred> and sum(gt) of its pixel as azimuth pairs -- the statistics behind the env mask and the
+// LSregress scale (wrapperBRDFLight.py:172-176, models.py:7-21).  Per-wave partials land in a.ws[blockIdx.x * 3 + {0,1,2}].
+template <int KP, int POOL, bool WRITE_ENV, bool DO_RENDER, bool HAS_GT = false>
 __global__ __launch_bounds__(kWave, 2) void fwd_pk_kernel(const Args a) {
+  static_assert(!(HAS_GT && WRITE_ENV), "the statistics variant does not write the env image");
   constexpr int EW = 16, TJ = SGR_PK_TJ, HALF = 8, NQ = 2, RPT = TJ / EW;
   __shared__ __attribute__((aligned(16))) float tile[WRITE_ENV ? Tile<TJ>::kFloats : 4];
+  using GD = DmaTile<16>;
+  __shared__ __attribute__((aligned(16))) float gtile[HAS_GT ? GD::kFloats : 4];
   SGR_TRACE_BEGIN
 
   const Pix x = locate(a);
@@ -211,6 +230,9 @@ __global__ __launch_bounds__(kWave, 2) void fwd_pk_kernel(const Args a) {
   const size_t img = (size_t)b * 3 * RC * a.J;
   const int eh = a.eh;
   f32x2 dacc[3] = {splat2(0.f), splat2(0.f), splat2(0.f)}, sacc[3] = {splat2(0.f), splat2(0.f), splat2(0.f)};
+  f32x2 s_pg = splat2(0.f), s_pp = splat2(0.f), s_g = splat2(0.f);
+  __amdgpu_buffer_rsrc_t gimg = env_rsrc(HAS_GT ? a.env_gt + img : a.view, RC, a.J);
+  if (HAS_GT) tile_dma_issue<16>(gtile, gimg, x.p0, RC, a.J, 0, lane);
   SGR_TRACE_MARK
 
   auto row_loop = [&](auto ortho_c) {
@@ -272,6 +294,24 @@ __global__ __launch_bounds__(kWave, 2) void fwd_pk_kernel(const Args a) {
             }
           }
         }
+        if (HAS_GT) {
+          if (aq == 0) wait_vmcnt<0>();      // this row's tile (requested a quad of arithmetic ago) has landed
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            float g[2][3][2];
+            tile_dma_read_pairs<16>(gtile, lane, aq * 4 + 2 * h, HALF + aq * 4 + 2 * h, g);
+            if (h == 1 && aq == NQ - 1 && e + 1 < eh) tile_dma_issue<16>(gtile, gimg, x.p0, RC, a.J, (e + 1) * EW, lane);
+#pragma unroll
+            for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                const f32x2 gv = {g[sg][c][0], g[sg][c][1]};
+                s_pg = pfma(acc[sg][c][h], gv, s_pg);
+                s_pp = pfma(acc[sg][c][h], acc[sg][c][h], s_pp);
+                s_g += gv;
+              }
+          }
+        }
         if (WRITE_ENV) {
 #pragma unroll
           for (int sg = 0; sg < 2; ++sg) {
@@ -295,6 +335,21 @@ __global__ __launch_bounds__(kWave, 2) void fwd_pk_kernel(const Args a) {
   };
   if (ortho) row_loop(std::true_type{}); else row_loop(std::false_type{});
 
+  if (HAS_GT) {
+    // env mask of the pixel (wrapperBRDFLight.py:172-174) and the wave's share of the per-image sums
+    const float not_dark = ((s_g.x + s_g.y) / (3.0f * (float)a.J)) > 0.001f ? 1.0f : 0.0f;
+    const float m = x.active ? (a.seg_small + (size_t)b * RC)[(unsigned)p] * a.env_ind[b] * not_dark : 0.0f;
+    if (x.active) (a.mask + (size_t)b * RC)[(unsigned)p] = m;
+    float r0 = m * m * (s_pg.x + s_pg.y), r1 = m * m * (s_pp.x + s_pp.y), r2 = m;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      r0 += __shfl_xor(r0, off, 64); r1 += __shfl_xor(r1, off, 64); r2 += __shfl_xor(r2, off, 64);
+    }
+    if (lane == 0) {
+      float* w = a.ws + (size_t)blockIdx.x * 3;
+      w[0] = r0; w[1] = r1; w[2] = r2;
+    }
+  }
   if (DO_RENDER && x.active) {
     const size_t o = (size_t)b * 3 * RC;
     const unsigned up = (unsigned)p;

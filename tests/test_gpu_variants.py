@@ -7,6 +7,7 @@ knobs (read once per process, hence the subprocesses), must pass the same golden
   SGR_FWD_MODE=full               one-pixel-per-lane forward also for the SG -> env call
   SGR_GENERIC=1                   generic kernels (table-driven, any direction grid) on the reference's grid
   SGR_F1_MODE=half                half-wave statistics kernel in the fused objective's forward (objective tests)
+  SGR_F1_MODE/SGR_B1_MODE=scalar  round 1's scalar objective kernels (the packed-fp32 ones are the default)
 """
 import os
 import subprocess
@@ -38,10 +39,12 @@ def test_alternative_kernels_pass_golden_parity(env):
     assert " passed" in r.stdout and "failed" not in r.stdout, tail
 
 
+@pytest.mark.parametrize("env", [{"SGR_F1_MODE": "half"}, {"SGR_F1_MODE": "scalar", "SGR_B1_MODE": "scalar"}],
+                         ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 @pytest.mark.timeout(600)
-def test_half_wave_objective_forward_passes_objective_tests():
+def test_alternative_objective_kernels_pass_objective_tests(env):
     e = dict(os.environ)
-    e["SGR_F1_MODE"] = "half"
+    e.update(env)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_objective.py"), "-q", "-m", "gpu", "-x",
                         "-k", "golden or oracle", "-p", "no:cacheprovider"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=580)
     tail = (r.stdout or "")[-1500:] + (r.stderr or "")[-500:]
