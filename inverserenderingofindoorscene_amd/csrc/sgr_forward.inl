@@ -184,10 +184,23 @@ static int fwd_pk_launch(const Args& a, hipStream_t st) {
     hipLaunchKernelGGL((fwd_pk_kernel<KP, 2, WRITE_ENV, DO_RENDER>), grid, block, 0, st, a);
   return (int)hipGetLastError();
 }
-static inline int fwd_mode() {     // 4 packed (default), 0 scalar one pixel per lane, 2 / 3 scalar half-wave kernel, -1 round-1 default
+// packed half-wave forward (envWidth 16, 6 < SGNum <= 12), OCC resident waves per SIMD
+template <bool WRITE_ENV, bool DO_RENDER, int OCC>
+static int fwd_pk_half_launch(const Args& a, hipStream_t st) {
+  const dim3 grid((unsigned)(a.bn * ((a.R * a.C + kPx - 1) / kPx))), block(kWave);
+  if (!DO_RENDER || (a.imH == a.R && a.imW == a.C))
+    hipLaunchKernelGGL((fwd_pk_half_kernel<1, WRITE_ENV, DO_RENDER, OCC>), grid, block, 0, st, a);
+  else
+    hipLaunchKernelGGL((fwd_pk_half_kernel<2, WRITE_ENV, DO_RENDER, OCC>), grid, block, 0, st, a);
+  return (int)hipGetLastError();
+}
+static inline int fwd_mode() {     // 4 packed (default; 7: one pixel per lane always, 5 / 6: half-wave always), 0 scalar one pixel per lane, 2 / 3 scalar half-wave kernel, -1 round-1 default
   static const int mode = [] {
     const char* e = getenv("SGR_FWD_MODE");
-    if (!e || !strcmp(e, "pk")) return 4;
+    if (!e) return 4;
+    if (!strcmp(e, "pk")) return 7;      // packed, one pixel per lane for every forward variant
+    if (e && !strcmp(e, "pkhalf2")) return 5;
+    if (e && !strcmp(e, "pkhalf3")) return 6;
     if (e && !strcmp(e, "scalar")) return -1;
     if (e && !strcmp(e, "full")) return 0;
     if (e && !strcmp(e, "half2")) return 2;
@@ -201,9 +214,14 @@ static int fwd_fast_launch(const Args& a, hipStream_t st) {
   // measured at config 2, one pixel per lane / half-wave: in the bench loop (working set cycling through HBM) env + render
   // 239 / 206 us, render only 163 / 172 us; relaunched on the same buffers (tools/kbench, inputs partly cache-resident)
   // env + render 214-223 / 209-219 us, env only 178 / 149 us  ->  half-wave whenever the env image is written
-  if (fwd_mode() == 4 && a.ew == 16 && a.K <= 12)
+  // packed kernels, measured at config 2 (kbench / bench loop): env + render: one pixel per lane 166-180 / 152 us, half-wave at 3
+  // waves per SIMD 177 / 147 us (and the backward behind it 5 us slower: a wash) -> one pixel per lane; env only
+  // (output2env.output2env alone): 172 vs 154 us -> half-wave; render only: 142 vs 150 us -> one pixel per lane
+  if (a.ew == 16 && a.K > 6 && a.K <= 12 && (fwd_mode() >= 5 || (fwd_mode() == 4 && WRITE_ENV && !DO_RENDER)))
+    return fwd_mode() == 5 ? fwd_pk_half_launch<WRITE_ENV, DO_RENDER, 2>(a, st) : fwd_pk_half_launch<WRITE_ENV, DO_RENDER, 3>(a, st);
+  if (fwd_mode() >= 4 && a.ew == 16 && a.K <= 12)
     return a.K <= 6 ? fwd_pk_launch<6, WRITE_ENV, DO_RENDER>(a, st) : fwd_pk_launch<12, WRITE_ENV, DO_RENDER>(a, st);
-  const int mode = (fwd_mode() >= 0 && fwd_mode() != 4) ? fwd_mode() : (WRITE_ENV ? 2 : 0);
+  const int mode = (fwd_mode() >= 0 && fwd_mode() < 4) ? fwd_mode() : (WRITE_ENV ? 2 : 0);
   if (a.ew == 16 && a.K > 6 && a.K <= 12 && mode != 0)
     return mode == 3 ? fwd_half_launch<WRITE_ENV, DO_RENDER, 3>(a, st) : fwd_half_launch<WRITE_ENV, DO_RENDER, 2>(a, st);
   if (a.ew == 16) {

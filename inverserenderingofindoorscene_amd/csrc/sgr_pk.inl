@@ -364,6 +364,153 @@ __global__ __launch_bounds__(kWave, 2) void fwd_pk_kernel(const Args a) {
 }
 
 
+// ============================== forward, half-wave lobe split, packed ==============================================
+// fwd_half_kernel's decomposition (sgr_fast.inl: one wave = 32 pixels x 2 groups of 6 lobes; swap(D = share of half row 1,
+// S = share of half row 0); D + S leaves lanes 0..31 with the radiance of half row 1 and lanes 32..63 with that of half
+// row 0, which each half then shades and stores) with the arithmetic in azimuth pairs.  Against fwd_pk_kernel: half as long
+// work units (9600 instead of 4800 at config 2: a shorter last round), half the lobes per lane (fewer registers: OCC = 3
+// resident waves per SIMD), no duplicated prologue work (each half pre-maps its own six lobes, the frame is evaluated
+// per lane as before) -- for 12 swaps + 6 packed adds per azimuth quad.
+template <int POOL, bool WRITE_ENV, bool DO_RENDER, int OCC>
+__global__ __launch_bounds__(kWave, OCC) void fwd_pk_half_kernel(const Args a) {
+  constexpr int EW = 16, HALF = 8, NQ = 2, KPW = 6, TD = 16;
+  __shared__ __attribute__((aligned(16))) float tile[WRITE_ENV ? T32Out<TD>::kFloats : 4];
+  SGR_TRACE_BEGIN
+
+  const int lane = threadIdx.x, half = lane >> 5, pl = lane & 31;
+  const int own = 1 - half;                         // the half row (sign) whose totals this half-wave ends up holding
+  const int RC = a.R * a.C;
+  const Pix x = locate_group32(a, (int)blockIdx.x);
+  const int b = x.b, p = x.p;
+
+  LobesPk<KPW> P;      // this half's lobes, folded (axis pre-multiplied by lam * log2e)
+  load_lobes_pk<KPW, true>(a, b, (unsigned)p, x.active, half * KPW, P, !DO_RENDER);
+
+  PixLocal q;
+  OrthoPix oq;
+  float alb[3] = {0.f, 0.f, 0.f};
+  bool ortho = true;
+  if (DO_RENDER) {
+    const Frame f = load_frame<POOL>(a, x, alb);
+    q = make_local(f, a.F0);
+    oq = make_ortho_pix(q);
+    ortho = __all(frame_is_orthonormal(q));
+  }
+  const SepTable rows = as_sep_table(a.rows);
+  const PairTable cpt = as_pair_table(a.cols, EW);
+  const XTable xt = (XTable)(a.cols + EW);
+  const size_t img = (size_t)b * 3 * RC * a.J;
+  const int eh = a.eh;
+  f32x2 dacc[3] = {splat2(0.f), splat2(0.f), splat2(0.f)}, sacc[3] = {splat2(0.f), splat2(0.f), splat2(0.f)};
+  SGR_TRACE_MARK
+
+  auto row_loop = [&](auto ortho_c) {
+    constexpr bool ORTHO = decltype(ortho_c)::value;
+    for (int e = 0; e < eh; ++e) {
+      if (DO_RENDER && !ORTHO) fence_row_invariants(q);
+      const f32x8 row = rows[e];
+      const float sr = row[0];
+      f32x2 Ck[KPW / 2];
+#pragma unroll
+      for (int m = 0; m < KPW / 2; ++m) Ck[m] = pfma(P.azp[m], splat2(row[1]), -P.lpp[m]);
+      const RowCtx rc = make_row_ctx(q, row, DO_RENDER);
+      OrthoRow orow = make_ortho_row(rc.ro);
+#pragma unroll 1
+      for (int aq = 0; aq < NQ; ++aq) {
+        fence_lobes<KPW>(P);
+#pragma unroll
+        for (int m = 0; m < KPW / 2; ++m) SGR_FENCE2(Ck[m]);
+        if (DO_RENDER && ORTHO) { SGR_FENCE2(oq.vB); SGR_FENCE2(oq.ff); SGR_FENCE2(oq.vvk); SGR_FENCE2(orow.nwc); SGR_FENCE2(orow.cvc); }
+        const f32x4 t0 = cpt[2 * aq], t1 = cpt[2 * aq + 1];
+        const f32x2 ca[2] = {f32x2{t0[0], t0[1]}, f32x2{t1[0], t1[1]}}, sa[2] = {f32x2{t0[2], t0[3]}, f32x2{t1[2], t1[3]}};
+        f32x2 acc[2][3][2];   // [sign][colour][azimuth pair of the quad]: this half's six lobes' share
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) acc[sg][c][0] = acc[sg][c][1] = splat2(0.f);
+#pragma unroll
+        for (int k = 0; k < KPW; ++k) {
+          const f32x2 ck = half_of(Ck[k / 2], k & 1), w2 = half_of(P.w2p[k / 2], k & 1);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const f32x2 U = pfma(SGR_HI(P.axy[k]), sa[h], SGR_LO(P.axy[k]) * ca[h]);
+            const f32x2 tp = pfma(splat2(sr), U, ck);
+            const f32x2 tm = pfma(splat2(-sr), U, ck);
+            const f32x2 ep = {fexp2(tp.x), fexp2(tp.y)};
+            const f32x2 em = {fexp2(tm.x), fexp2(tm.y)};
+            acc[0][0][h] = pfma(SGR_LO(P.w01[k]), ep, acc[0][0][h]);
+            acc[0][1][h] = pfma(SGR_HI(P.w01[k]), ep, acc[0][1][h]);
+            acc[0][2][h] = pfma(w2, ep, acc[0][2][h]);
+            acc[1][0][h] = pfma(SGR_LO(P.w01[k]), em, acc[1][0][h]);
+            acc[1][1][h] = pfma(SGR_HI(P.w01[k]), em, acc[1][1][h]);
+            acc[1][2][h] = pfma(w2, em, acc[1][2][h]);
+          }
+        }
+        // radiance of the half row this half-wave owns
+        f32x2 tot[3][2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            float dx = acc[1][c][h].x, sx = acc[0][c][h].x, dy = acc[1][c][h].y, sy = acc[0][c][h].y;
+            swap32(dx, sx);
+            swap32(dy, sy);
+            tot[c][h] = f32x2{dx + sx, dy + sy};
+          }
+        if (DO_RENDER) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const f32x2 Pv = pfma(SGR_HI(oq.vB), sa[h], SGR_LO(oq.vB) * ca[h]);
+            f32x2 wt, sp;
+            shade_pair<ORTHO>(q, oq, rc, orow, own, ca[h], sa[h], Pv, xt, aq * 4 + 2 * h, wt, sp);
+            const f32x2 sw = sp * wt;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              dacc[c] = pfma(wt, tot[c][h], dacc[c]);
+              sacc[c] = pfma(sw, tot[c][h], sacc[c]);
+            }
+          }
+        }
+        if (WRITE_ENV) {
+          const float e0[4] = {tot[0][0].x, tot[0][0].y, tot[0][1].x, tot[0][1].y};
+          const float e1[4] = {tot[1][0].x, tot[1][0].y, tot[1][1].x, tot[1][1].y};
+          const float e2[4] = {tot[2][0].x, tot[2][0].y, tot[2][1].x, tot[2][1].y};
+          tile32_write4<TD>(tile, pl, own * HALF + aq * 4, e0, e1, e2);
+        }
+      }
+      if (WRITE_ENV) {
+        __syncthreads();
+        tile32_store_global<TD>(tile, a.env_out + img, x.p0, RC, a.J, e * EW, EW, lane);
+        __syncthreads();
+      }
+    }
+  };
+  if (ortho) row_loop(std::true_type{}); else row_loop(std::false_type{});
+
+  if (DO_RENDER) {
+    // each half integrated one half row: add the two
+    float v[6] = {dacc[0].x + dacc[0].y, dacc[1].x + dacc[1].y, dacc[2].x + dacc[2].y, sacc[0].x + sacc[0].y, sacc[1].x + sacc[1].y, sacc[2].x + sacc[2].y};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      float d_ = v[i], s_ = v[i];
+      swap32(d_, s_);
+      v[i] = d_ + s_;
+    }
+    if (x.active && half == 0) {
+      const size_t o = (size_t)b * 3 * RC;
+      const unsigned up = (unsigned)p;
+      (a.diffuse + o)[up] = (alb[0] * kInvPi) * v[0];
+      (a.diffuse + o + RC)[up] = (alb[1] * kInvPi) * v[1];
+      (a.diffuse + o + 2 * (size_t)RC)[up] = (alb[2] * kInvPi) * v[2];
+      (a.spec + o)[up] = v[3];
+      (a.spec + o + RC)[up] = v[4];
+      (a.spec + o + 2 * (size_t)RC)[up] = v[5];
+    }
+  }
+  SGR_TRACE_END
+}
+
+
 // ============================== backward w.r.t. the SG parameters, half-wave, packed ===============
 // sg_bwd_half_kernel's decomposition (one wave = 32 pixels x 2 groups of 6 lobes; the env cotangent arrives one table
 // row at a time by double-buffered LDS-DMA; each half evaluates the microfacet terms of one half row and the halves

@@ -5,6 +5,7 @@ knobs (read once per process, hence the subprocesses), must pass the same golden
   SGR_FWD_MODE/SGR_BWD_MODE=half2 half-wave forward for every forward variant, half-wave backward built for 2 waves/SIMD
   SGR_FWD_MODE/SGR_BWD_MODE=half3 the same built for 3 waves/SIMD (round 1's defaults; the packed-fp32 kernels are round 2's)
   SGR_FWD_MODE=full               one-pixel-per-lane forward also for the SG -> env call
+  SGR_FWD_MODE=pk|pkhalf2|pkhalf3 packed fp32 forward: one pixel per lane / half-wave for every forward variant (the default mixes them)
   SGR_GENERIC=1                   generic kernels (table-driven, any direction grid) on the reference's grid
   SGR_F1_MODE=half                half-wave statistics kernel in the fused objective's forward (objective tests)
   SGR_F1_MODE/SGR_B1_MODE=scalar  round 1's scalar objective kernels (the packed-fp32 ones are the default)
@@ -26,6 +27,9 @@ SUBSET = "golden or trainlight"
     {"SGR_FWD_MODE": "half2", "SGR_BWD_MODE": "half2"},
     {"SGR_FWD_MODE": "half3", "SGR_BWD_MODE": "half3"},
     {"SGR_FWD_MODE": "full"},
+    {"SGR_FWD_MODE": "pk"},
+    {"SGR_FWD_MODE": "pkhalf2"},
+    {"SGR_FWD_MODE": "pkhalf3"},
     {"SGR_GENERIC": "1"},
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 @pytest.mark.timeout(600)
