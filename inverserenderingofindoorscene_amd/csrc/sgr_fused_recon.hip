@@ -323,8 +323,8 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
   f32x2 grec = splat2(2.0f * m * rec_scale * cf * kLn2);     // times dl (in log2 units) / x
   f32x2 lossp = splat2(0.0f);
 
-  LobesPk<KPW> P;      // unit axes, lp = lam * log2e, post-tan weights
-  load_lobes_pk<KPW, false>(a, b, (unsigned)p, x.active, half * KPW, P, false);
+  LobesPk<KPW> P;      // axes pre-multiplied by lp = lam * log2e (floored), as in sg_bwd_pk_kernel
+  load_lobes_pk<KPW, true>(a, b, (unsigned)p, x.active, half * KPW, P, false);
   f32x2 gw0[KPW], gw1[KPW], gw2[KPW], gl[KPW], gz[KPW], gx[KPW], gy[KPW];
 #pragma unroll
   for (int k = 0; k < KPW; ++k) gw0[k] = gw1[k] = gw2[k] = gl[k] = gz[k] = gx[k] = gy[k] = splat2(0.f);
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
       const float sr = row[0], cr = row[1];
       f32x2 czr[KPW / 2];
 #pragma unroll
-      for (int mm = 0; mm < KPW / 2; ++mm) czr[mm] = pfma(P.azp[mm], splat2(cr), splat2(-1.0f));
+      for (int mm = 0; mm < KPW / 2; ++mm) czr[mm] = pfma(P.azp[mm], splat2(cr), -P.lpp[mm]);      // lp (az c_e - 1)
       const RowCtx rc = make_row_ctx(q, row, true);
       OrthoRow orow = make_ortho_row(rc.ro);
 
@@ -374,9 +374,9 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
           for (int c = 0; c < 3; ++c) v[sg][c] = splat2(0.f);
 #pragma unroll
         for (int k = 0; k < KPW; ++k) {
-          const f32x2 cz = half_of(czr[k / 2], k & 1), lpk = half_of(P.lpp[k / 2], k & 1), w2 = half_of(P.w2p[k / 2], k & 1);
+          const f32x2 cz = half_of(czr[k / 2], k & 1), w2 = half_of(P.w2p[k / 2], k & 1);
           const f32x2 u = pfma(SGR_HI(P.axy[k]), sa, SGR_LO(P.axy[k]) * ca);
-          const f32x2 xp = lpk * pfma(srv, u, cz), xm = lpk * pfma(-srv, u, cz);
+          const f32x2 xp = pfma(srv, u, cz), xm = pfma(-srv, u, cz);      // lp t
           ep[k] = f32x2{fexp2(xp.x), fexp2(xp.y)};
           em[k] = f32x2{fexp2(xm.x), fexp2(xm.y)};
           v[0][0] = pfma(SGR_LO(P.w01[k]), ep[k], v[0][0]); v[0][1] = pfma(SGR_HI(P.w01[k]), ep[k], v[0][1]); v[0][2] = pfma(w2, ep[k], v[0][2]);
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
         for (int k = 0; k < KPW; ++k) {
           const f32x2 cz = half_of(czr[k / 2], k & 1), w2 = half_of(P.w2p[k / 2], k & 1);
           const f32x2 u = pfma(SGR_HI(P.axy[k]), sa, SGR_LO(P.axy[k]) * ca);
-          const f32x2 tp = pfma(srv, u, cz), tm = pfma(-srv, u, cz);
+          const f32x2 tp = pfma(srv, u, cz), tm = pfma(-srv, u, cz);      // lp t: gl accumulates lp sum T t
           gw0[k] = pfma(g[0][0], ep[k], gw0[k]); gw1[k] = pfma(g[0][1], ep[k], gw1[k]); gw2[k] = pfma(g[0][2], ep[k], gw2[k]);
           gw0[k] = pfma(g[1][0], em[k], gw0[k]); gw1[k] = pfma(g[1][1], em[k], gw1[k]); gw2[k] = pfma(g[1][2], em[k], gw2[k]);
           const f32x2 Tp = pfma(g[0][2], w2, pfma(g[0][1], SGR_HI(P.w01[k]), g[0][0] * SGR_LO(P.w01[k]))) * ep[k];
@@ -460,11 +460,11 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
         const unsigned o3 = (unsigned)(kk * 3 * RC + p), o1 = (unsigned)(kk * RC + p);
         const float lpk = (k & 1) ? P.lpp[k / 2].y : P.lpp[k / 2].x;
         const float w0 = P.w01[k].x, w1 = P.w01[k].y, w2 = (k & 1) ? P.w2p[k / 2].y : P.w2p[k / 2].x;
-        const float lam = lpk * kLn2;
+        const float lam = fabsf(lpk) <= 1e-30f ? 0.0f : lpk * kLn2;      // the floor stands for lam == 0
         g_axis_b[o3] = lam * (gx[k].x + gx[k].y);
         g_axis_b[o3 + RC] = lam * (gy[k].x + gy[k].y);
         g_axis_b[o3 + 2 * RC] = lam * (gz[k].x + gz[k].y);
-        float glk = gl[k].x + gl[k].y, q0 = gw0[k].x + gw0[k].y, q1 = gw1[k].x + gw1[k].y, q2 = gw2[k].x + gw2[k].y;
+        float glk = (gl[k].x + gl[k].y) * frcp(lpk), q0 = gw0[k].x + gw0[k].y, q1 = gw1[k].x + gw1[k].y, q2 = gw2[k].x + gw2[k].y;
         if (a.premap) {
           glk *= premap_grad(lam);
           q0 *= premap_grad(w0); q1 *= premap_grad(w1); q2 *= premap_grad(w2);

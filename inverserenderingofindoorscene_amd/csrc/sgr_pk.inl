@@ -65,7 +65,9 @@ __device__ __forceinline__ Pix locate_group32(const Args& a, int g) {
 }
 
 // SG parameters of the lane's pixel in register pairs (KP even; lobes past K carry zero weights).
-// FOLD: axis pre-multiplied by lp = lam * log2e (forward); unit axes otherwise (backward).
+// FOLD: axis pre-multiplied by lp = lam * log2e (forward and sg_bwd_pk_kernel); unit axes otherwise (objective backward).
+// The backward divides its sharpness gradient by lp again (see there), so a |lp| below 1e-30 -- lam == 0 is what the
+// decoders' clamp produces -- is replaced by 1e-30: exp2(1e-30 t) is exactly 1, like exp2(0 t).
 template <int KP>
 struct LobesPk {
   f32x2 axy[KP];        // (ax, ay)
@@ -110,7 +112,8 @@ __device__ __forceinline__ void load_lobes_pk(const Args& a, int b, unsigned up,
         }
       }
     }
-    const float lpk = l * kLog2e;
+    float lpk = l * kLog2e;
+    if (FOLD) lpk = fabsf(lpk) < 1e-30f ? 1e-30f : lpk;
     lp[k] = lpk;
     if (FOLD) { ax[k] *= lpk; ay[k] *= lpk; az[k] *= lpk; }
     w0[k] = live ? t0 : 0.0f; w1[k] = live ? t1 : 0.0f; w2[k] = live ? t2 : 0.0f;
@@ -579,8 +582,11 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
       gds[c] = f32x2{(a.g_diffuse + o + (size_t)c * RC)[up] * (alb[c] * kInvPi), (a.g_spec + o + (size_t)c * RC)[up]};
   }
 
-  LobesPk<KPW> P;      // unit axes, lp = lam * log2e, post-tan weights
-  load_lobes_pk<KPW, false>(a, b, (unsigned)p, x.active, half * KPW, P, false);
+  // axes pre-multiplied by lp = lam * log2e (floored, see load_lobes_pk): the exponents t' = lp t come straight out of the
+  // packed FMAs, and the sharpness gradient is accumulated as sum T t' = lp sum T t and divided by lp at the end -- two
+  // packed multiplies fewer per lobe and azimuth pair
+  LobesPk<KPW> P;
+  load_lobes_pk<KPW, true>(a, b, (unsigned)p, x.active, half * KPW, P, false);
 
   f32x2 gw0[KPW], gw1[KPW], gw2[KPW], gl[KPW], gz[KPW], gx[KPW], gy[KPW];
 #pragma unroll
@@ -609,7 +615,7 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
       const float sr = row[0], cr = row[1];
       f32x2 czr[KPW / 2];
 #pragma unroll
-      for (int m = 0; m < KPW / 2; ++m) czr[m] = pfma(P.azp[m], splat2(cr), splat2(-1.0f));
+      for (int m = 0; m < KPW / 2; ++m) czr[m] = pfma(P.azp[m], splat2(cr), -P.lpp[m]);      // lp (az c_e - 1)
       const RowCtx rc = make_row_ctx(q, row, HAS_RENDER);
       OrthoRow orow = make_ortho_row(rc.ro);
 
@@ -651,11 +657,10 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
         const f32x2 sca = srv * ca, ssa = srv * sa;
 #pragma unroll
         for (int k = 0; k < KPW; ++k) {
-          const f32x2 cz = half_of(czr[k / 2], k & 1), lpk = half_of(P.lpp[k / 2], k & 1), w2 = half_of(P.w2p[k / 2], k & 1);
+          const f32x2 cz = half_of(czr[k / 2], k & 1), w2 = half_of(P.w2p[k / 2], k & 1);
           const f32x2 u = pfma(SGR_HI(P.axy[k]), sa, SGR_LO(P.axy[k]) * ca);
-          const f32x2 tp = pfma(srv, u, cz), tm = pfma(-srv, u, cz);
-          const f32x2 xp = lpk * tp, xm = lpk * tm;
-          const f32x2 ep = {fexp2(xp.x), fexp2(xp.y)}, em = {fexp2(xm.x), fexp2(xm.y)};
+          const f32x2 tp = pfma(srv, u, cz), tm = pfma(-srv, u, cz);      // lp t
+          const f32x2 ep = {fexp2(tp.x), fexp2(tp.y)}, em = {fexp2(tm.x), fexp2(tm.y)};
           gw0[k] = pfma(g[0][0], ep, gw0[k]); gw1[k] = pfma(g[0][1], ep, gw1[k]); gw2[k] = pfma(g[0][2], ep, gw2[k]);
           gw0[k] = pfma(g[1][0], em, gw0[k]); gw1[k] = pfma(g[1][1], em, gw1[k]); gw2[k] = pfma(g[1][2], em, gw2[k]);
           const f32x2 Tp = pfma(g[0][2], w2, pfma(g[0][1], SGR_HI(P.w01[k]), g[0][0] * SGR_LO(P.w01[k]))) * ep;
@@ -688,11 +693,11 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
         const unsigned o3 = (unsigned)(kk * 3 * RC + p), o1 = (unsigned)(kk * RC + p);
         const float lpk = (k & 1) ? P.lpp[k / 2].y : P.lpp[k / 2].x;
         const float w0 = P.w01[k].x, w1 = P.w01[k].y, w2 = (k & 1) ? P.w2p[k / 2].y : P.w2p[k / 2].x;
-        const float lam = lpk * kLn2;
+        const float lam = fabsf(lpk) <= 1e-30f ? 0.0f : lpk * kLn2;      // the floor stands for lam == 0
         g_axis_b[o3] = lam * (gx[k].x + gx[k].y);
         g_axis_b[o3 + RC] = lam * (gy[k].x + gy[k].y);
         g_axis_b[o3 + 2 * RC] = lam * (gz[k].x + gz[k].y);
-        float glk = gl[k].x + gl[k].y, q0 = gw0[k].x + gw0[k].y, q1 = gw1[k].x + gw1[k].y, q2 = gw2[k].x + gw2[k].y;
+        float glk = (gl[k].x + gl[k].y) * frcp(lpk), q0 = gw0[k].x + gw0[k].y, q1 = gw1[k].x + gw1[k].y, q2 = gw2[k].x + gw2[k].y;
         if (a.premap) {
           glk *= premap_grad(lam);
           q0 *= premap_grad(w0); q1 *= premap_grad(w1); q2 *= premap_grad(w2);

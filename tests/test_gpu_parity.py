@@ -289,3 +289,48 @@ def test_error_behaviour(sgr):
         o2e.output2env(a.cuda().double(), torch.zeros(1, 12, 12, 16).cuda().double(), torch.zeros(1, 36, 12, 16).cuda().double())
 
 
+
+
+def test_zero_sharpness_lobes(sgr):
+    """lamb == 0 exactly is what the decoder's clamp produces (models.py:338-340): exp(0 * t) = 1 in every direction.  The
+    packed backward folds lam into the axes and divides the sharpness gradient by it again, with a 1e-30 floor standing in for
+    zero -- values and gradients of such lobes (and of weight == 0, lamb == 1 lobes) against the fp64 oracle, fused layer and
+    fused objective."""
+    from oracle import sg_oracle as O
+    bn, imH, imW, R, C, K, eh, ew = 2, 16, 24, 8, 12, 12, 8, 16
+    inp = O.synthetic_inputs(bn, imH, imW, R, C, K, eh, ew, seed=77)
+    inp["lamb"][:, 0] = 0.0
+    inp["lamb"][:, 7] = 0.0
+    inp["lamb"][:, 3, ::2] = 0.0
+    inp["lamb"][:, 5] = 1.0
+    inp["weight"][:, 6:9] = 0.0
+    x = {k: v.cuda() for k, v in inp.items()}
+    xo = {k: v.double() for k, v in inp.items()}
+    for k in ("axis", "lamb", "weight"):
+        x[k].requires_grad_(True)
+        xo[k].requires_grad_(True)
+    layer = sgr.renderingLayer(imWidth=C, imHeight=R, envWidth=ew, envHeight=eh)
+    env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=True)
+    eo, do, so = O.render_from_sg(xo["albedo"], xo["normal"], xo["rough"], xo["axis"], xo["lamb"], xo["weight"], eh, ew)
+    g = torch.Generator().manual_seed(3)
+    ct = [torch.randn(t.shape, generator=g) for t in (env, d, s)]
+    gr = torch.autograd.grad([env, d, s], [x[k] for k in ("axis", "lamb", "weight")], grad_outputs=[t.cuda() for t in ct])
+    go = torch.autograd.grad([eo, do, so], [xo[k] for k in ("axis", "lamb", "weight")], grad_outputs=[t.double() for t in ct], retain_graph=True)
+    assert rel_l2(env.detach().cpu(), eo.detach()) < TOL_L2 and rel_l2(d.detach().cpu(), do.detach()) < TOL_L2
+    for k, a, b in zip(("axis", "lamb", "weight"), gr, go):
+        assert torch.isfinite(a).all(), k
+        assert rel_l2(a.cpu(), b) < 3e-4, (k, rel_l2(a.cpu(), b))
+    # the zero-sharpness lobes on their own: axis gradient exactly zero, sharpness gradient that of the oracle
+    assert float(gr[0][:, 0].abs().max()) == 0.0 and float(gr[0][:, 7].abs().max()) == 0.0
+    assert rel_l2(gr[1][:, [0, 7]].cpu(), go[1][:, [0, 7]]) < 3e-4
+    ind = torch.ones(bn, 1, 1, 1)
+    obj = sgr.light_objective(layer, x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], x["im"], x["seg"],
+                              x["env_gt"], ind.cuda(), 1.0, 10.0)
+    g2 = torch.autograd.grad(obj[0], [x[k] for k in ("axis", "lamb", "weight")])
+    ro, _, _, _ = O.render_loss(do, so, xo["im"], xo["seg"], R, C)
+    co, _, _, _ = O.recon_loss(eo, xo["env_gt"], xo["seg"], ind.double(), R, C)
+    g3 = torch.autograd.grad(ro + 10.0 * co, [xo[k] for k in ("axis", "lamb", "weight")])
+    for k, a, b in zip(("axis", "lamb", "weight"), g2, g3):
+        assert torch.isfinite(a).all(), k
+        assert rel_l2(a.cpu(), b) < 5e-4, (k, rel_l2(a.cpu(), b))
+    assert float(g2[0][:, 0].abs().max()) == 0.0
