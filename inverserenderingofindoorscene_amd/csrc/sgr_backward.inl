@@ -206,7 +206,10 @@ static int sgbwd_launch_k(const Args& a, hipStream_t st) {
 
 template <int EW, bool HAS_GENV, bool HAS_RENDER>
 static int sgbwd_fast_launch_pool(const Args& a, hipStream_t st) {
-  const dim3 grid = wave_grid(a.bn, a.R, a.C), block(kWave);
+  // one workgroup per (pixel group, register group of lobes), ids interleaved in chunks of 8 (see sg_bwd_fast_kernel)
+  const int kp = a.K <= 6 ? 6 : 12, ng = (a.K + kp - 1) / kp;
+  const unsigned tiles = wave_grid(a.bn, a.R, a.C).x;
+  const dim3 grid(((tiles + 7) / 8) * 8 * (unsigned)ng), block(kWave);
   const bool p1 = (!HAS_RENDER || (a.imH == a.R && a.imW == a.C));
   if (a.K <= 6) {   // fewer lobes in registers -> higher occupancy
     if (p1) hipLaunchKernelGGL((sg_bwd_fast_kernel<6, 1, EW, HAS_GENV, HAS_RENDER>), grid, block, 0, st, a);

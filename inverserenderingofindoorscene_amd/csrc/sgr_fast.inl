@@ -543,6 +543,11 @@ __global__ __launch_bounds__(kWave, OCC) void fwd_half_kernel(const Args a) {
 //   dL/dw_c = sum g_c E,   dL/dlam = sum T t,   dL/da = lam (ca A, sa A, sum T c_e),  A_a = sum_e (+-s_e) T
 // The env cotangent arrives one table row (EW directions) at a time by LDS-DMA, double-buffered for
 // EW = 16 (2 x 12 KB): the next row's 12 DMA instructions are in flight while this row is consumed.
+// More lobes than KP (config 5: 24): one workgroup per (pixel group, register group of KP lobes) instead of one workgroup
+// walking the groups one after the other -- half as long work units (-12 % at config 5), and the workgroups of a pixel
+// group sit 8 ids apart, i.e. are dispatched back to back to the SAME XCD, so that part of the second one's cotangent rows
+// comes out of that XCD's L2 instead of HBM (PMC at config 5: 3.47 GB fetched for 2.34 GB algorithmic; the sequential form
+// fetched 4.36 GB; two waves of ONE workgroup with a tile each measured worse: 2.88 vs 2.50 ms, 3.9 GB).
 template <int KP, int POOL, int EW, bool HAS_GENV, bool HAS_RENDER>
 __global__ __launch_bounds__(kWave, 2) void sg_bwd_fast_kernel(const Args a) {
   constexpr int TJ = EW;
@@ -552,9 +557,21 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_fast_kernel(const Args a) {
   using D = DmaTile<TJ>;
   __shared__ __attribute__((aligned(16))) float tile[HAS_GENV ? NBUF * D::kFloats : 4];
 
-  const Pix x = locate(a);
-  const int lane = x.lane, b = x.b, p = x.p;
   const int RC = a.R * a.C, K = a.K;
+  // workgroup id -> (pixel group t, lobe group): ids [16 m, 16 m + 8) are lobe group 0 of pixel groups 8 m .. 8 m + 7,
+  // ids [16 m + 8, 16 m + 16) lobe group 1 of the same pixel groups (for two groups; ng in general)
+  const int ng = (K + KP - 1) / KP;
+  const int chunk = (int)blockIdx.x / (8 * ng), within = (int)blockIdx.x - chunk * (8 * ng);
+  const int grp = within >> 3, t = chunk * 8 + (within & 7);
+  const int tiles = (RC + kWave - 1) / kWave;
+  if (t >= a.bn * tiles) return;
+  Pix x;
+  x.lane = threadIdx.x;
+  x.b = t / tiles;
+  x.p0 = (t - x.b * tiles) * kWave;
+  x.active = (x.p0 + x.lane) < RC;
+  x.p = x.active ? (x.p0 + x.lane) : (RC - 1);
+  const int lane = x.lane, b = x.b, p = x.p;
 
   PixLocal q;
   bool ortho = true;
@@ -579,7 +596,8 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_fast_kernel(const Args a) {
   __amdgpu_buffer_rsrc_t gimg = env_rsrc(HAS_GENV ? a.g_env + (size_t)b * 3 * RC * a.J : a.view, RC, a.J);
   const int eh = a.eh;
 
-  for (int kg = 0; kg < K; kg += KP) {
+  {
+    const int kg = grp * KP;
     Lobes<KP> L;
     load_lobes<KP, false>(a, x, kg, L, false);
     float gax[KP], gay[KP], gaz[KP], glam[KP], gw0[KP], gw1[KP], gw2[KP];
