@@ -585,7 +585,7 @@ extern "C" int sgr_fused_bwd_recon(const float* albedo, const float* normal, con
   a.env_gt = env_gt; a.mask_in = mask; a.coef = coef; a.offset = offset;
   set_dims(a, bn, K, R, C, eh, ew, imH, imW);
   a.F0 = F0; a.premap = premap;
-  const int tiles = recon_tiles(R * C), tiles32 = recon_tiles32(R * C);
+  const int tiles32 = recon_tiles32(R * C);
   float* den_img = workspace;
   float* ws1 = workspace + bn + 4 + (size_t)bn * tiles32 * 3;
   a.ws = ws1; a.den_img = den_img; a.den_global = den_global; a.rec_w3j = rec_weight / (3.0f * (float)(eh * ew));
