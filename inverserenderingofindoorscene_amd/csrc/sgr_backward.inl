@@ -241,15 +241,21 @@ static int sgbwd_half_launch(const Args& a, hipStream_t st) {
     hipLaunchKernelGGL((sg_bwd_half_kernel<2, HAS_GENV, HAS_RENDER, OCC>), grid, block, 0, st, a);
   return (int)hipGetLastError();
 }
-// packed-fp32 half-wave backward (envWidth 16, SGNum <= 12), sgr_pk.inl
+// packed-fp32 half-wave backward (envWidth 16 or 32; one workgroup per 32 pixels and group of 12 lobes), sgr_pk.inl
+template <bool HAS_GENV, bool HAS_RENDER, int EW>
+static int sgbwd_pk_launch_ew(const Args& a, hipStream_t st) {
+  const int ng = (a.K + 11) / 12;
+  const unsigned tiles = (unsigned)(a.bn * ((a.R * a.C + kPx - 1) / kPx));
+  const dim3 grid(ng == 1 ? tiles : ((tiles + 7) / 8) * 8 * (unsigned)ng), block(kWave);
+  if (!HAS_RENDER || (a.imH == a.R && a.imW == a.C))
+    hipLaunchKernelGGL((sg_bwd_pk_kernel<1, HAS_GENV, HAS_RENDER, EW>), grid, block, 0, st, a);
+  else
+    hipLaunchKernelGGL((sg_bwd_pk_kernel<2, HAS_GENV, HAS_RENDER, EW>), grid, block, 0, st, a);
+  return (int)hipGetLastError();
+}
 template <bool HAS_GENV, bool HAS_RENDER>
 static int sgbwd_pk_launch(const Args& a, hipStream_t st) {
-  const dim3 grid((unsigned)(a.bn * ((a.R * a.C + kPx - 1) / kPx))), block(kWave);
-  if (!HAS_RENDER || (a.imH == a.R && a.imW == a.C))
-    hipLaunchKernelGGL((sg_bwd_pk_kernel<1, HAS_GENV, HAS_RENDER>), grid, block, 0, st, a);
-  else
-    hipLaunchKernelGGL((sg_bwd_pk_kernel<2, HAS_GENV, HAS_RENDER>), grid, block, 0, st, a);
-  return (int)hipGetLastError();
+  return a.ew == 16 ? sgbwd_pk_launch_ew<HAS_GENV, HAS_RENDER, 16>(a, st) : sgbwd_pk_launch_ew<HAS_GENV, HAS_RENDER, 32>(a, st);
 }
 static inline int bwd_mode() {     // 4 packed half-wave (default), 0 split (two waves), 2 / 3 scalar half-wave kernel built for that many waves per SIMD
   static const int mode = [] {       // round 1, config 2 (g_env + gD,gS): split 350 us, half2 328 us, half3 320 us
@@ -268,7 +274,9 @@ static inline bool bwd_split_enabled() {
 
 template <bool HAS_GENV, bool HAS_RENDER>
 static int sgbwd_launch(const Args& a, hipStream_t st) {
-  if (fast_ok(a) && a.ew == 16 && a.K > 6 && a.K <= 12 && bwd_mode() == 4 && !sgr_generic_forced())
+  // packed: SGNum 7..12 on the 8x16 grid (the headline), and everything above 6 lobes on 16-wide and 32-wide grids
+  // (config 5: 24 lobes, 16x32: 2.50 ms with the scalar kernel)
+  if (fast_ok(a) && a.K > 6 && bwd_mode() == 4 && !sgr_generic_forced())
     return sgbwd_pk_launch<HAS_GENV, HAS_RENDER>(a, st);
   if (fast_ok(a) && a.ew == 16 && a.K > 6 && a.K <= 12 && bwd_mode() != 0 && !sgr_generic_forced())
     return bwd_mode() == 3 ? sgbwd_half_launch<HAS_GENV, HAS_RENDER, 3>(a, st) : sgbwd_half_launch<HAS_GENV, HAS_RENDER, 2>(a, st);

@@ -194,6 +194,16 @@ static int fwd_pk_half_launch(const Args& a, hipStream_t st) {
     hipLaunchKernelGGL((fwd_pk_half_kernel<2, WRITE_ENV, DO_RENDER, OCC>), grid, block, 0, st, a);
   return (int)hipGetLastError();
 }
+// packed half-wave forward with 12 lobes per half: 12 < SGNum <= 24, envWidth 16 or 32 (config 5)
+template <bool WRITE_ENV, bool DO_RENDER, int EW>
+static int fwd_pk_half24_launch(const Args& a, hipStream_t st) {
+  const dim3 grid((unsigned)(a.bn * ((a.R * a.C + kPx - 1) / kPx))), block(kWave);
+  if (!DO_RENDER || (a.imH == a.R && a.imW == a.C))
+    hipLaunchKernelGGL((fwd_pk_half_kernel<1, WRITE_ENV, DO_RENDER, 2, 12, EW>), grid, block, 0, st, a);
+  else
+    hipLaunchKernelGGL((fwd_pk_half_kernel<2, WRITE_ENV, DO_RENDER, 2, 12, EW>), grid, block, 0, st, a);
+  return (int)hipGetLastError();
+}
 static inline int fwd_mode() {     // 4 packed (default; 7: one pixel per lane always, 5 / 6: half-wave always), 0 scalar one pixel per lane, 2 / 3 scalar half-wave kernel, -1 round-1 default
   static const int mode = [] {
     const char* e = getenv("SGR_FWD_MODE");
@@ -214,6 +224,8 @@ static int fwd_fast_launch(const Args& a, hipStream_t st) {
   // measured at config 2, one pixel per lane / half-wave: in the bench loop (working set cycling through HBM) env + render
   // 239 / 206 us, render only 163 / 172 us; relaunched on the same buffers (tools/kbench, inputs partly cache-resident)
   // env + render 214-223 / 209-219 us, env only 178 / 149 us  ->  half-wave whenever the env image is written
+  if (fwd_mode() >= 4 && a.K > 12 && a.K <= 24)      // 24 lobes: 12 per half-wave, packed (config 5: 1.32 -> ms with the scalar 24-lobe kernel)
+    return a.ew == 16 ? fwd_pk_half24_launch<WRITE_ENV, DO_RENDER, 16>(a, st) : fwd_pk_half24_launch<WRITE_ENV, DO_RENDER, 32>(a, st);
   // packed kernels, measured at config 2 (kbench / bench loop): env + render: one pixel per lane 166-180 / 152 us, half-wave at 3
   // waves per SIMD 177 / 147 us (and the backward behind it 5 us slower: a wash) -> one pixel per lane; env only
   // (output2env.output2env alone): 172 vs 154 us -> half-wave; render only: 142 vs 150 us -> one pixel per lane

@@ -374,9 +374,11 @@ __global__ __launch_bounds__(kWave, 2) void fwd_pk_kernel(const Args a) {
 // work units (9600 instead of 4800 at config 2: a shorter last round), half the lobes per lane (fewer registers: OCC = 3
 // resident waves per SIMD), no duplicated prologue work (each half pre-maps its own six lobes, the frame is evaluated
 // per lane as before) -- for 12 swaps + 6 packed adds per azimuth quad.
-template <int POOL, bool WRITE_ENV, bool DO_RENDER, int OCC>
+// KPW = 12, EW = 32 (OCC 2): SGNum up to 24 on the 16x32 grid of BASELINE config 5 -- the one-pixel-per-lane kernels would
+// need 24 lobes per lane there and spill.
+template <int POOL, bool WRITE_ENV, bool DO_RENDER, int OCC, int KPW = 6, int EW = 16>
 __global__ __launch_bounds__(kWave, OCC) void fwd_pk_half_kernel(const Args a) {
-  constexpr int EW = 16, HALF = 8, NQ = 2, KPW = 6, TD = 16;
+  constexpr int HALF = EW / 2, NQ = HALF / 4, TD = EW;
   __shared__ __attribute__((aligned(16))) float tile[WRITE_ENV ? T32Out<TD>::kFloats : 4];
   SGR_TRACE_BEGIN
 
@@ -536,9 +538,37 @@ __device__ __forceinline__ void tile32_read_two_pairs2(const float* tile, int pl
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int POOL, bool HAS_GENV, bool HAS_RENDER>
+// EW = 32 (BASELINE config 5's 16 x 32 grid): a table row is walked as Q = 2 "virtual rows" of 8 + 8 directions -- the
+// azimuths [8 q, 8 q + 8) of both half rows -- whose cotangents are gathered into the SAME 16-float-per-pixel LDS tile
+// layout by giving the DMA lanes the matching source columns (two 32-byte pieces per pixel and colour), so the loop body is
+// the EW = 16 one with the azimuth tables indexed at 4 q + ap.  More than 12 lobes: one workgroup per (32-pixel group,
+// group of 12 lobes), the workgroups of a pixel group 8 ids apart (same XCD, shared L2; see sg_bwd_fast_kernel).
+template <int AUX, int EW>
+__device__ __forceinline__ void tile32_dma_issue_vrow(float* tile, __amdgpu_buffer_rsrc_t rsrc, int p0, int RC, int J, int vr, int lane) {
+  if (EW == 16) {
+    tile32_dma_issue<AUX>(tile, rsrc, p0, RC, J, vr * 16, lane);
+  } else {
+    const int e = vr >> 1, q = vr & 1;
+    const int lrow = lane >> 2, slot = lane & 3;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int row = it * 16 + lrow;
+      const int ls = slot ^ ((row >> 2) & 3);                              // logical 16-byte slot this lane fills
+      const int col = 4 * ls + 8 * q + (ls >= 2 ? 8 : 0);                  // slots 0,1: half row 0; slots 2,3: half row 1
+      const int voff = (row * J + col) * 4;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int soff = (int)((((size_t)c * RC + p0) * J + e * 32) * 4);
+        float* dst = tile + (c * kPx + it * 16) * 16;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)dst, 16, voff, soff, 0, AUX);
+      }
+    }
+  }
+}
+
+template <int POOL, bool HAS_GENV, bool HAS_RENDER, int EW = 16>
 __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
-  constexpr int EW = 16, HALF = 8, NP = 4, KPW = 6;
+  constexpr int HALF = 8, NP = 4, KPW = 6, Q = EW / 16;
   // env cotangent rows: a ring of three one-row LDS-DMA buffers (18 KB).  Rows are requested two at a time, back to back
   // (the two 64-byte halves of every 128-byte line of the image), one row ahead of their use; non-temporal, since the
   // cotangent is read exactly once and must not push the SG parameters out of the Infinity Cache
@@ -548,21 +578,20 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
   const int lane = threadIdx.x, half = lane >> 5, pl = lane & 31;
   const int own = 1 - half;                         // the half row (sign) whose BRDF terms this half-wave evaluates
   const int RC = a.R * a.C, K = a.K;
-  Pix x;
-  x.lane = lane;
-  {
-    const int tiles = (RC + kPx - 1) / kPx;
-    x.b = blockIdx.x / tiles;
-    x.p0 = (blockIdx.x - x.b * tiles) * kPx;
-    x.active = (x.p0 + pl) < RC;
-    x.p = x.active ? (x.p0 + pl) : (RC - 1);
-  }
+  // workgroup id -> (32-pixel group t, group of 12 lobes): ids [8 ng m, 8 ng m + 8) are lobe group 0 of pixel groups
+  // 8 m .. 8 m + 7, the next 8 ids lobe group 1 of the same pixel groups, ...  (ng = 1: id == t)
+  const int ng = (K + 2 * KPW - 1) / (2 * KPW);
+  const int chunk = (int)blockIdx.x / (8 * ng), within = (int)blockIdx.x - chunk * (8 * ng);
+  const int grp = within >> 3, t = chunk * 8 + (within & 7);
+  if (t >= a.bn * ((RC + kPx - 1) / kPx)) return;
+  const Pix x = locate_group32(a, t);
   const int b = x.b, p = x.p;
+  const int nvr = a.eh * Q;                         // virtual rows
 
   __amdgpu_buffer_rsrc_t gimg = env_rsrc(HAS_GENV ? a.g_env + (size_t)b * 3 * RC * a.J : a.view, RC, a.J);
   if (HAS_GENV) {
-    tile32_dma_issue<SGR_PK_BWD_AUX>(tile, gimg, x.p0, RC, a.J, 0, lane);
-    if (a.eh > 1) tile32_dma_issue<SGR_PK_BWD_AUX>(tile + kT32Floats, gimg, x.p0, RC, a.J, EW, lane);
+    tile32_dma_issue_vrow<SGR_PK_BWD_AUX, EW>(tile, gimg, x.p0, RC, a.J, 0, lane);
+    if (nvr > 1) tile32_dma_issue_vrow<SGR_PK_BWD_AUX, EW>(tile + kT32Floats, gimg, x.p0, RC, a.J, 1, lane);
   }
 
   PixLocal q;
@@ -586,7 +615,7 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
   // packed FMAs, and the sharpness gradient is accumulated as sum T t' = lp sum T t and divided by lp at the end -- two
   // packed multiplies fewer per lobe and azimuth pair
   LobesPk<KPW> P;
-  load_lobes_pk<KPW, true>(a, b, (unsigned)p, x.active, half * KPW, P, false);
+  load_lobes_pk<KPW, true>(a, b, (unsigned)p, x.active, grp * 2 * KPW + half * KPW, P, false);
 
   f32x2 gw0[KPW], gw1[KPW], gw2[KPW], gl[KPW], gz[KPW], gx[KPW], gy[KPW];
 #pragma unroll
@@ -595,19 +624,19 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
   const SepTable rows = as_sep_table(a.rows);
   const PairTable cpt = as_pair_table(a.cols, EW);
   const XTable xt = (XTable)(a.cols + EW);
-  const int eh = a.eh;
   SGR_TRACE_MARK
 
   auto row_loop = [&](auto ortho_c) {
     constexpr bool ORTHO = decltype(ortho_c)::value;
-    for (int e = 0; e < eh; ++e) {
-      const float* cur = tile + (HAS_GENV ? (e % 3) * kT32Floats : 0);
+    for (int vr = 0; vr < nvr; ++vr) {
+      const int e = Q == 1 ? vr : (vr >> 1), aoff = Q == 1 ? 0 : (vr & 1) * NP;      // table row; first azimuth pair of this virtual row
+      const float* cur = tile + (HAS_GENV ? (vr % 3) * kT32Floats : 0);
       if (HAS_GENV) {
-        // rows e+1, e+2 (e odd) were requested when row e-1 was done; up to two rows (12 instructions) may stay in flight
-        if ((e & 1) == 0) {
-          if (e + 1 < eh) wait_vmcnt<6>(); else wait_vmcnt<0>();          // in flight at most: row e+1
+        // rows vr+1, vr+2 (vr odd) were requested when row vr-1 was done; up to two rows (12 instructions) may stay in flight
+        if ((vr & 1) == 0) {
+          if (vr + 1 < nvr) wait_vmcnt<6>(); else wait_vmcnt<0>();          // in flight at most: row vr+1
         } else {
-          if (e + 2 < eh) wait_vmcnt<12>(); else if (e + 1 < eh) wait_vmcnt<6>(); else wait_vmcnt<0>();   // rows e+1, e+2
+          if (vr + 2 < nvr) wait_vmcnt<12>(); else if (vr + 1 < nvr) wait_vmcnt<6>(); else wait_vmcnt<0>();   // rows vr+1, vr+2
         }
       }
       if (HAS_RENDER && !ORTHO) fence_row_invariants(q);
@@ -629,9 +658,9 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
           for (int c = 0; c < 3; ++c) SGR_FENCE2(gds[c]);
           if (ORTHO) { SGR_FENCE2(oq.vB); SGR_FENCE2(oq.ff); SGR_FENCE2(oq.vvk); SGR_FENCE2(orow.nwc); SGR_FENCE2(orow.cvc); }
         }
-        const f32x4 cs = cpt[ap];
+        const f32x4 cs = cpt[aoff + ap];
         const f32x2 ca = {cs[0], cs[1]}, sa = {cs[2], cs[3]};
-        f32x2 g[2][3];            // [sign][colour], the azimuth pair (2 ap, 2 ap + 1)
+        f32x2 g[2][3];            // [sign][colour], the azimuth pair (2 ap, 2 ap + 1) of this virtual row
         if (HAS_GENV) {
           tile32_read_two_pairs2(cur, pl, ap * 2, HALF + ap * 2, g[0], g[1]);
         } else {
@@ -642,7 +671,7 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
           // the render term of the half row this half-wave owns, then both halves' terms to all lanes
           const f32x2 Pv = pfma(SGR_HI(oq.vB), sa, SGR_LO(oq.vB) * ca);
           f32x2 wt, sp;
-          shade_pair<ORTHO>(q, oq, rc, orow, own, ca, sa, Pv, xt, ap * 2, wt, sp);
+          shade_pair<ORTHO>(q, oq, rc, orow, own, ca, sa, Pv, xt, (aoff + ap) * 2, wt, sp);
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
             const f32x2 r_ = wt * pfma(SGR_HI(gds[c]), sp, SGR_LO(gds[c]));
@@ -673,10 +702,10 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
           gy[k] = pfma(ssa, Td, gy[k]);
         }
       }
-      if (HAS_GENV && (e & 1) == 0) {
-        // row e is consumed: its buffer and the one of row e-1 are free -> request rows e+2 and e+3 back to back
-        if (e + 2 < eh) tile32_dma_issue<SGR_PK_BWD_AUX>(tile + ((e + 2) % 3) * kT32Floats, gimg, x.p0, RC, a.J, (e + 2) * EW, lane);
-        if (e + 3 < eh) tile32_dma_issue<SGR_PK_BWD_AUX>(tile + ((e + 3) % 3) * kT32Floats, gimg, x.p0, RC, a.J, (e + 3) * EW, lane);
+      if (HAS_GENV && (vr & 1) == 0) {
+        // row vr is consumed: its buffer and the one of row vr-1 are free -> request rows vr+2 and vr+3 back to back
+        if (vr + 2 < nvr) tile32_dma_issue_vrow<SGR_PK_BWD_AUX, EW>(tile + ((vr + 2) % 3) * kT32Floats, gimg, x.p0, RC, a.J, vr + 2, lane);
+        if (vr + 3 < nvr) tile32_dma_issue_vrow<SGR_PK_BWD_AUX, EW>(tile + ((vr + 3) % 3) * kT32Floats, gimg, x.p0, RC, a.J, vr + 3, lane);
       }
     }
   };
@@ -688,7 +717,7 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
     float* g_weight_b = a.g_weight + (size_t)b * K * 3 * RC;
 #pragma unroll
     for (int k = 0; k < KPW; ++k) {
-      const int kk = half * KPW + k;
+      const int kk = grp * 2 * KPW + half * KPW + k;
       if (kk < K) {
         const unsigned o3 = (unsigned)(kk * 3 * RC + p), o1 = (unsigned)(kk * RC + p);
         const float lpk = (k & 1) ? P.lpp[k / 2].y : P.lpp[k / 2].x;

@@ -173,7 +173,9 @@ def test_sg_only_grads_like_trainlight(sgr, golden):
     dict(bn=1, imH=12, imW=16, R=6, C=8, K=5, eh=8, ew=16),      # K <= 6: 6-lobe register groups
     dict(bn=1, imH=12, imW=16, R=6, C=8, K=7, eh=7, ew=16),      # K padded to 12, odd envHeight
     dict(bn=1, imH=12, imW=16, R=6, C=8, K=24, eh=4, ew=16),     # forward 24 lobes in registers, backward 2 groups
-    dict(bn=1, imH=10, imW=12, R=5, C=6, K=12, eh=3, ew=32),     # envWidth 32, single-buffered DMA rows
+    dict(bn=1, imH=10, imW=12, R=5, C=6, K=12, eh=3, ew=32),     # envWidth 32: table rows walked as two virtual rows
+    dict(bn=2, imH=12, imW=16, R=6, C=8, K=32, eh=3, ew=16),     # three groups of 12 lobes (one workgroup each in the backward)
+    dict(bn=1, imH=14, imW=18, R=7, C=9, K=17, eh=5, ew=32),     # two lobe groups, the second partly empty, envWidth 32, ragged tiles
 ])
 def test_shapes_vs_oracle(sgr, shape):
     from oracle import sg_oracle as O
