@@ -1,0 +1,40 @@
+"""CPU: bench.py's bookkeeping -- the algorithmic bytes of SURVEY.md section 8d, and that the PMC traffic records
+(profiles/traffic.json, keyed by workload) name the kernels bench.py looks for, so `roofline.traffic` of the contract line is a
+measurement of THAT kernel on THAT workload or null, never a figure borrowed from another configuration."""
+import importlib.util
+import json
+import os
+import re
+
+from conftest import ROOT
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_algorithmic_bytes_match_survey_8d():
+    b = _bench()
+    cfg2 = b.algorithmic_bytes_per_shaded_px(K=12, J=128, q=4)
+    assert cfg2 == dict(fwd_env=2008, fwd_noenv=472, bwd_sg=2344)
+    assert cfg2["fwd_env"] + cfg2["bwd_sg"] == 4352                      # fwd+bwd, trainLight mode
+    cfg5 = b.algorithmic_bytes_per_shaded_px(K=24, J=512, q=4)
+    assert cfg5["fwd_env"] == 6952 and cfg5["fwd_noenv"] == 808
+    assert b.HBM_PEAK_GBPS == 8000.0
+
+
+def test_traffic_records_are_keyed_by_workload_and_name_the_dispatched_kernels():
+    recs = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    for key, fwd, bwd, alg_fwd, alg_bwd in (("config2_batch16_env", r"::fwd_pk_kernel<12, 2, true, true", r"::sg_bwd_pk_kernel<2, true, true", 616857600, 720076800),
+                                            ("config5_batch4_env", r"::fwd_pk_half_kernel<2, true, true, 2, 12, 32>", r"::sg_bwd_pk_kernel<2, true, true, 32>", 2135654400, 2342092800)):
+        assert key in recs, key
+        names = list(recs[key])
+        f = [n for n in names if re.search(fwd, n)]
+        g = [n for n in names if re.search(bwd, n)]
+        assert f and g, (key, names)
+        # measured HBM bytes: never below the algorithmic bytes (minus counter noise), and no gross re-reads
+        assert 0.98 * alg_fwd <= recs[key][f[0]]["hbm_bytes"] <= 1.10 * alg_fwd, (key, recs[key][f[0]])
+        assert 0.98 * alg_bwd <= recs[key][g[0]]["hbm_bytes"] <= 1.25 * alg_bwd, (key, recs[key][g[0]])
