@@ -185,13 +185,13 @@ static int fwd_pk_launch(const Args& a, hipStream_t st) {
   return (int)hipGetLastError();
 }
 // packed half-wave forward (envWidth 16, 6 < SGNum <= 12), OCC resident waves per SIMD
-template <bool WRITE_ENV, bool DO_RENDER, int OCC>
+template <bool WRITE_ENV, bool DO_RENDER, int OCC, int EW = 16>
 static int fwd_pk_half_launch(const Args& a, hipStream_t st) {
   const dim3 grid((unsigned)(a.bn * ((a.R * a.C + kPx - 1) / kPx))), block(kWave);
   if (!DO_RENDER || (a.imH == a.R && a.imW == a.C))
-    hipLaunchKernelGGL((fwd_pk_half_kernel<1, WRITE_ENV, DO_RENDER, OCC>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((fwd_pk_half_kernel<1, WRITE_ENV, DO_RENDER, OCC, 6, EW>), grid, block, 0, st, a);
   else
-    hipLaunchKernelGGL((fwd_pk_half_kernel<2, WRITE_ENV, DO_RENDER, OCC>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((fwd_pk_half_kernel<2, WRITE_ENV, DO_RENDER, OCC, 6, EW>), grid, block, 0, st, a);
   return (int)hipGetLastError();
 }
 // packed half-wave forward with 12 lobes per half: 12 < SGNum <= 24, envWidth 16 or 32 (config 5)
@@ -226,6 +226,8 @@ static int fwd_fast_launch(const Args& a, hipStream_t st) {
   // env + render 214-223 / 209-219 us, env only 178 / 149 us  ->  half-wave whenever the env image is written
   if (fwd_mode() >= 4 && a.K > 12 && a.K <= 24)      // 24 lobes: 12 per half-wave, packed (config 5: 1.32 -> ms with the scalar 24-lobe kernel)
     return a.ew == 16 ? fwd_pk_half24_launch<WRITE_ENV, DO_RENDER, 16>(a, st) : fwd_pk_half24_launch<WRITE_ENV, DO_RENDER, 32>(a, st);
+  if (fwd_mode() >= 4 && a.ew == 32 && a.K > 6 && a.K <= 12)      // 16x32 grid, up to 12 lobes: six per half-wave, packed
+    return fwd_pk_half_launch<WRITE_ENV, DO_RENDER, 3, 32>(a, st);
   // packed kernels, measured at config 2 (kbench / bench loop): env + render: one pixel per lane 166-180 / 152 us, half-wave at 3
   // waves per SIMD 177 / 147 us (and the backward behind it 5 us slower: a wash) -> one pixel per lane; env only
   // (output2env.output2env alone): 172 vs 154 us -> half-wave; render only: 142 vs 150 us -> one pixel per lane
