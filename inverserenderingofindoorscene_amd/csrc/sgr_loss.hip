@@ -197,8 +197,8 @@ __global__ void loss_finalize(const float* __restrict__ parts, float* __restrict
 // ---- backward: d(num)/d{diffuse, spec} * g_num ------------------------------------------------
 // num = sum (clamp(kd D + ks S, 0, 1) - imS)^2 seg ; kd, ks are constants HERE because the images that define them arrive
 // detached (wrapperBRDFLight.py:197-201; coefIm and the det indicator are detached by the reference itself, models.py:54,76).
-// The reference does not detach coefDiffuse / coefSpecular: call sites that pass live images differentiate through them,
-// a mode this implementation refuses (losses.py: _no_coef_grad).
+// The reference does not detach coefDiffuse / coefSpecular: call sites that pass live images differentiate through them;
+// that mode runs in torch on the host layer (losses.py: _lsregress_diffspec_live), not through this kernel.
 __global__ __launch_bounds__(kLossThreads) void loss_bwd(const float* __restrict__ g_num /* device scalar */,
                                                           const float* __restrict__ g_scale /* device scalar or NULL */,
                                                           const float* __restrict__ diffuse, const float* __restrict__ spec,

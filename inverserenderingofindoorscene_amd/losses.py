@@ -33,15 +33,34 @@ def _workspace(bn: int, dev) -> torch.Tensor:
     return torch.empty(_lib.load().sgr_loss_workspace_floats(bn), device=dev, dtype=torch.float32)
 
 
-def _no_coef_grad(*ts):
-    for t in ts:
-        if t.requires_grad:
-            raise NotImplementedError(
-                "sgrender: LSregressDiffSpec treats the regression coefficients as constants -- the trainLight / testReal "
-                "call pattern, which passes detached diffuse / specular images as the first two arguments "
-                "(wrapperBRDFLight.py:197-201).  The reference itself does NOT detach coefDiffuse / coefSpecular "
-                "(models.py:44-63), so call sites that pass live tensors there (trainFineTune*_cascade1.py) differentiate "
-                "through them; that mode is a deliberate restriction of this implementation: detach the first two arguments")
+def _lsregress_diffspec_live(diff, spec, imOrig, diffOrig, specOrig):
+    """models.py:23-84 for call sites that differentiate THROUGH the regression coefficients (the reference does not
+    detach ``coefDiffuse / coefSpecular``; ``trainFineTune*_cascade1.py`` pass live ``diffusePred / specularPred`` as the
+    first two arguments).  Off the trainLight hot path, so plain torch ops on the device tensors with autograd doing the
+    rest: the normal equations of the masked two-column least-squares problem per image (Gram matrix by one batched
+    matmul), Cramer's rule with the reference's floors, its one-column fallback where the determinant per element is
+    below 1e-2 (a constant indicator), the [0, 1000] clamp, and the second, detached one-unknown rescale of the clamped sum."""
+    nb, n = diff.shape[0], diff[0].numel()
+    keep = (imOrig < 0.9).to(diff.dtype)
+    cols = torch.stack([(diff * keep).reshape(nb, -1), (spec * keep).reshape(nb, -1)], dim=1)      # [nb, 2, n]
+    rhs = (imOrig * keep).reshape(nb, -1, 1)                                                      # [nb, n, 1]
+    gram = cols @ cols.transpose(1, 2)                                                            # [nb, 2, 2]
+    proj = (cols @ rhs).squeeze(-1)                                                               # [nb, 2]
+    g_dd, g_ss, g_ds = gram[:, 0, 0], gram[:, 1, 1], gram[:, 0, 1]
+    det = g_dd * g_ss - g_ds * g_ds
+    floor = torch.clamp(det, min=1e-2)
+    kd_two = (proj[:, 0] * g_ss - proj[:, 1] * g_ds) / floor
+    ks_two = (g_dd * proj[:, 1] - proj[:, 0] * g_ds) / floor
+    kd_one = torch.clamp(proj[:, 0] / torch.clamp(g_dd, min=1e-5), 0.001, 1000.0)
+    two = (det.detach() / n) > 1e-2
+    kd = torch.clamp(torch.where(two, kd_two, kd_one), 0.0, 1000.0).reshape(nb, 1, 1, 1)
+    ks = torch.clamp(torch.where(two, ks_two, torch.zeros_like(ks_two)), 0.0, 1000.0).reshape(nb, 1, 1, 1)
+    d_scaled, s_scaled = kd * diffOrig, ks * specOrig
+    with torch.no_grad():
+        ren = torch.clamp(d_scaled + s_scaled, 0.0, 1.0).reshape(nb, -1)
+        again = (ren * imOrig.reshape(nb, -1)).sum(1) / torch.clamp((ren * ren).sum(1), min=1e-5)
+        again = torch.clamp(again, 0.001, 1000.0).reshape(nb, 1, 1, 1)
+    return again * d_scaled, again * s_scaled
 
 
 def LSregress(pred, gt, origin):
@@ -64,9 +83,14 @@ def LSregressDiffSpec(diff, spec, imOrig, diffOrig, specOrig):
     """Two-unknown (diffuse, specular) scale regression, then the one-unknown rescale of the clamped
     sum (models.py:23-84).  Returns ``(diffScaled, specScaled)``.
 
-    Restriction: ``diff`` / ``spec`` must not require grad (see ``_no_coef_grad``); ``imOrig`` may."""
+    With detached ``diff`` / ``spec`` (the trainLight / testReal pattern, wrapperBRDFLight.py:197-201) the coefficients are
+    constants and come from the HIP reduction kernels; if either carries a gradient the reference differentiates through
+    the coefficients (it does not detach them, models.py:44-63) and so does :func:`_lsregress_diffspec_live`."""
     dev = _require_hip(diff, spec, imOrig, diffOrig, specOrig)
-    _no_coef_grad(diff, spec)
+    if diff.shape != spec.shape or diff.shape != imOrig.shape:
+        raise RuntimeError("sgrender: LSregressDiffSpec needs diff, spec and imOrig of one shape")
+    if torch.is_grad_enabled() and (diff.requires_grad or spec.requires_grad):
+        return _lsregress_diffspec_live(diff, spec, imOrig, diffOrig, specOrig)
     nb = diff.shape[0]
     d, s, im = diff.detach().contiguous(), spec.detach().contiguous(), imOrig.detach().contiguous()
     if d.shape != s.shape or d.shape != im.shape:

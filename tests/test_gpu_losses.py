@@ -50,9 +50,18 @@ def test_lsregress_functions_vs_golden(sgr, golden):
     pm, gm = (env * m).reshape(nb, -1).double(), (env_gt * m).reshape(nb, -1).double()
     coef = torch.clamp((pm * gm).sum(1) / torch.clamp((pm * pm).sum(1), min=1e-5), 0.001, 1000.0).reshape(nb, 1, 1, 1, 1, 1)
     assert rel_l2(g_origin.cpu(), (ct.double() * coef).cpu()) < 1e-5, name
-    # LSregressDiffSpec: the trainLight call pattern (detached first arguments) only -- a deliberate restriction
-    with pytest.raises(NotImplementedError):
-        sgr.LSregressDiffSpec(d.clone().requires_grad_(True), s, im_s, d, s)
+    # LSregressDiffSpec with live first arguments (trainFineTune*_cascade1.py): the reference differentiates through the
+    # coefficients; same values as the kernel path, and the gradient against the oracle's fp64 restatement
+    from oracle import sg_oracle as O
+    d_live, s_live = d.clone().requires_grad_(True), s.clone().requires_grad_(True)
+    ds2, ss2 = sgr.LSregressDiffSpec(d_live, s_live, im_s, d_live, s_live)
+    assert rel_l2(ds2.detach().cpu(), z["ref32_diff_scaled"]) < 1e-5, name
+    ct2 = torch.randn(ds2.shape, generator=torch.Generator().manual_seed(4)).cuda()
+    gl = torch.autograd.grad((ds2 * ct2).sum() + (ss2 * ct2).sum(), [d_live, s_live])
+    do_, so_ = d.double().cpu().requires_grad_(True), s.double().cpu().requires_grad_(True)
+    dso, sso = O.lsregress_diffspec(do_, so_, im_s.double().cpu(), do_, so_)
+    go = torch.autograd.grad((dso * ct2.double().cpu()).sum() + (sso * ct2.double().cpu()).sum(), [do_, so_])
+    assert rel_l2(gl[0].cpu(), go[0]) < 1e-4 and rel_l2(gl[1].cpu(), go[1]) < 1e-4, name
 
 
 def test_render_loss_vs_golden(sgr, golden):

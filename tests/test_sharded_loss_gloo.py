@@ -126,3 +126,31 @@ def test_combine_single_process_is_plain_ratio():
     assert abs(loss.item() / (3.0 / 1e-5 / 3.0) - 1) < 1e-5      # max(den, 1e-5), wrapperBRDFLight.py:192
     loss.backward()
     assert abs(num.grad.item() / (1.0 / 1e-5 / 3.0) - 1) < 1e-5
+
+
+def test_lsregress_diffspec_live_coefficients_match_the_oracle():
+    """LSregressDiffSpec with grad-carrying first arguments (trainFineTune*_cascade1.py): the host layer's differentiable
+    restatement against the oracle's (itself pinned to the reference), values and gradients, fp64, including an image whose
+    determinant falls under the two-unknown threshold and one with bright (masked) pixels."""
+    from inverserenderingofindoorscene_amd.losses import _lsregress_diffspec_live
+    g = torch.Generator().manual_seed(9)
+    nb, R_, C_ = 4, 6, 8
+    d = torch.rand(nb, 3, R_, C_, generator=g, dtype=torch.float64)
+    s = torch.rand(nb, 3, R_, C_, generator=g, dtype=torch.float64) * 0.5
+    im = torch.rand(nb, 3, R_, C_, generator=g, dtype=torch.float64) * 1.1        # some pixels >= 0.9: masked out
+    s[1] = d[1] * 0.3                                                             # collinear columns: determinant 0 -> one-unknown fallback
+    d[2] *= 1e-2; s[2] *= 1e-2                                                    # tiny Gram matrix: floors active
+    args_a = [t.clone().requires_grad_(True) for t in (d, s)]
+    args_b = [t.clone().requires_grad_(True) for t in (d, s)]
+    orig_a = [t.clone().requires_grad_(True) for t in (d, s)]
+    orig_b = [t.clone().requires_grad_(True) for t in (d, s)]
+    oa = _lsregress_diffspec_live(args_a[0], args_a[1], im, orig_a[0], orig_a[1])
+    ob = O.lsregress_diffspec(args_b[0], args_b[1], im, orig_b[0], orig_b[1])
+    w = [torch.randn(nb, 3, R_, C_, generator=g, dtype=torch.float64) for _ in range(2)]
+    for x, y in zip(oa, ob):
+        assert torch.allclose(x, y, rtol=1e-10, atol=1e-12)
+    ga = torch.autograd.grad((oa[0] * w[0]).sum() + (oa[1] * w[1]).sum(), args_a + orig_a)
+    gb = torch.autograd.grad((ob[0] * w[0]).sum() + (ob[1] * w[1]).sum(), args_b + orig_b)
+    for x, y in zip(ga, gb):
+        assert torch.allclose(x, y, rtol=1e-8, atol=1e-10)
+    assert ga[0].abs().max() > 0 and ga[1].abs().max() > 0        # the coefficients do carry gradient
