@@ -224,18 +224,23 @@ def main() -> None:
             (err + 10.0 * rec).backward()
             clear()
 
-        res = []
-        for fn in (step_obj_fused, step_obj_unfused):
-            fn()
-            barrier()
-            t2 = time.perf_counter()
-            for _ in range(args.steps):
+        try:
+            res = []
+            for fn in (step_obj_fused, step_obj_unfused):
                 fn()
-            barrier()
-            res.append((time.perf_counter() - t2) / args.steps * 1e3)
-        obj_ms, obj_unfused_ms = res
+                barrier()
+                t2 = time.perf_counter()
+                for _ in range(args.steps):
+                    fn()
+                barrier()
+                res.append((time.perf_counter() - t2) / args.steps * 1e3)
+            obj_ms, obj_unfused_ms = res
+        except Exception as exc:       # informational legs: never fail the bench over them
+            obj_ms = obj_unfused_ms = None
+            if rank == 0:
+                print(f"# light-objective legs skipped: {str(exc)[:160]}", file=sys.stderr)
         # the fused objective (two heavy kernels + ~15 small ones) replayed from a HIP graph: no launch gaps
-        if world == 1:
+        if world == 1 and obj_ms is not None:
             try:
                 side = torch.cuda.Stream(device=dev)
                 side.wait_stream(torch.cuda.current_stream(dev))
