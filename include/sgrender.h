@@ -14,7 +14,12 @@
  *     only enqueues work on that stream: no allocation, no host synchronisation;
  *   - return value: 0 on success, otherwise a hipError_t (> 0) or one of the
  *     SGR_ERR_* codes (< 0); sgr_last_error() returns a thread-local description;
- *   - pointers marked "nullable" may be NULL to skip that output / input.
+ *   - pointers marked "nullable" may be NULL to skip that output / input;
+ *   - `premap`: 1 = `lamb` / `weight` are the light decoders' raw outputs and the entry point applies
+ *     tan(pi/2 * 0.999 x) first (output2env.output2env, models.py:396-400); 0 = they are post-tan already
+ *     (output2env.fromSGtoIm); 2 (backward entry points) = they are the post-tan values a forward call returned
+ *     (`lamb_tan` / `weight_tan`), and the gradients are still those w.r.t. the RAW inputs -- the backward then
+ *     applies the chain rule d tan = 0.999 pi/2 (1 + y^2) from y alone instead of re-evaluating 4K tangents per cell.
  *
  * Shapes:  bn images; K = SGNum lobes per cell (<= SGR_MAX_LOBES); env grid R x C
  *   (envRow x envCol == the renderingLayer ctor's imHeight x imWidth); J = eh*ew
@@ -28,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SGR_ABI_VERSION 1
+#define SGR_ABI_VERSION 2
 #define SGR_MAX_LOBES 32
 
 #define SGR_OK 0
@@ -81,11 +86,21 @@ int sgr_fused_fwd(const float* albedo, const float* normal, const float* rough,
                   int bn, int K, int R, int C, int eh, int ew, int imH, int imW, float F0,
                   int premap, void* stream);
 
+/* sgr_fused_fwd that also returns the post-tan sharpness / intensity (nullable; the values output2env.output2env
+ * returns next to the env image, models.py:396-404) for the backward entry points' premap = 2 mode. */
+int sgr_fused_fwd_tan(const float* albedo, const float* normal, const float* rough,
+                      const float* axis, const float* lamb, const float* weight,
+                      const float* dirs, const float* view,
+                      float* env /* nullable */, float* lamb_tan /* nullable */, float* weight_tan /* nullable */,
+                      float* diffuse, float* spec,
+                      int bn, int K, int R, int C, int eh, int ew, int imH, int imW, float F0,
+                      int premap, void* stream);
+
 /* Backward of output2env.output2env / fromSGtoIm (torch.autograd of models.py:371-404).
  *   g_env [bn,3,R,C,eh,ew] in;  g_axis [bn,K,3,R,C], g_lamb [bn,K,R,C], g_weight [bn,3K,R,C] out.
- *   With premap != 0 the inputs are the raw decoder outputs and the gradients are w.r.t.
- *   those (chain rule through tan applied); with premap == 0 they are w.r.t. the post-tan
- *   lamb / weight (fromSGtoIm). */
+ *   With premap == 1 the inputs are the raw decoder outputs and the gradients are w.r.t.
+ *   those (chain rule through tan applied); premap == 2: the same gradients from post-tan inputs;
+ *   with premap == 0 they are w.r.t. the post-tan lamb / weight (fromSGtoIm). */
 int sgr_sg_to_env_bwd(const float* g_env, const float* axis, const float* lamb, const float* weight,
                       const float* dirs, float* g_axis, float* g_lamb, float* g_weight,
                       int bn, int K, int R, int C, int eh, int ew, int premap, void* stream);
@@ -210,6 +225,15 @@ int sgr_fused_fwd_recon(const float* albedo, const float* normal, const float* r
                         float* diffuse, float* spec, float* mask, float* coef, float* parts, float* workspace,
                         int bn, int K, int R, int C, int eh, int ew, int imH, int imW, float F0, int premap,
                         void* stream);
+
+/* sgr_fused_fwd_recon that also returns the post-tan sharpness / intensity for sgr_fused_bwd_recon(premap = 2). */
+int sgr_fused_fwd_recon_tan(const float* albedo, const float* normal, const float* rough, const float* axis,
+                            const float* lamb, const float* weight, const float* dirs, const float* view,
+                            const float* env_gt, const float* seg_small, const float* env_ind,
+                            float* lamb_tan /* nullable */, float* weight_tan /* nullable */,
+                            float* diffuse, float* spec, float* mask, float* coef, float* parts, float* workspace,
+                            int bn, int K, int R, int C, int eh, int ew, int imH, int imW, float F0, int premap,
+                            void* stream);
 
 /* Backward of  objective = (render terms, through g_diffuse / g_spec) + rec_weight * reconstErr,
  *   reconstErr = num / max(den, 1e-5) / 3 / (eh*ew),  num = sum mask (log(coef env + offset) - log(env_gt + offset))^2,

@@ -16,7 +16,7 @@ from ctypes import c_char_p, c_float, c_int, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SGR_LIB", os.path.join(_HERE, "libsgrender.so"))
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class SgrenderUnavailable(RuntimeError):
@@ -43,6 +43,7 @@ SIGNATURES = {
     "sgr_sg_to_env_fwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], c_int),
     "sgr_render_env_fwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P], c_int),
     "sgr_fused_fwd": ([_P] * 11 + [_I] * 8 + [_F, _I, _P], c_int),
+    "sgr_fused_fwd_tan": ([_P] * 13 + [_I] * 8 + [_F, _I, _P], c_int),
     "sgr_sg_to_env_bwd": ([_P] * 8 + [_I] * 7 + [_P], c_int),
     "sgr_fused_bwd_sg": ([_P] * 14 + [_I] * 8 + [_F, _I, _P], c_int),
     "sgr_render_env_bwd_env": ([_P] * 8 + [_I] * 7 + [_F, _P], c_int),
@@ -61,6 +62,7 @@ SIGNATURES = {
     "sgr_fused_recon_supported": ([_I] * 5, c_int),
     "sgr_fused_recon_workspace_floats": ([_I, _I, _I], c_int),
     "sgr_fused_fwd_recon": ([_P] * 17 + [_I] * 8 + [_F, _I, _P], c_int),
+    "sgr_fused_fwd_recon_tan": ([_P] * 19 + [_I] * 8 + [_F, _I, _P], c_int),
     "sgr_light_heads_fwd": ([_P] * 7 + [_I] * 4 + [_P], c_int),
     "sgr_light_heads_bwd": ([_P] * 10 + [_I] * 4 + [_P], c_int),
     "sgr_rescale_inplace": ([_P, _P, _I, _P, _P, _P], c_int),

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kWave, 1) void sg_bwd_kernel(const Args a) {
         az[k] = (a.axis + ab + 2 * (size_t)RC)[up];
         float l = (a.lamb + (size_t)(b * K + kg + k) * RC)[up];
         float t0 = (a.weight + ab)[up], t1 = (a.weight + ab + RC)[up], t2 = (a.weight + ab + 2 * (size_t)RC)[up];
-        if (a.premap) {
+        if (a.premap == 1) {
           l = premap(l);
           t0 = premap(t0); t1 = premap(t1); t2 = premap(t2);
         }

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(kWave, 1) void brdf_bwd_kernel(const Args a) {
         az[k] = a.axis[ab + 2 * (size_t)RC];
         float l = a.lamb[(size_t)(b * K + k) * RC + p];
         float t0 = a.weight[ab], t1 = a.weight[ab + RC], t2 = a.weight[ab + 2 * (size_t)RC];
-        if (a.premap) {
+        if (a.premap == 1) {
           l = premap(l);
           t0 = premap(t0); t1 = premap(t1); t2 = premap(t2);
         }
@@ -227,7 +227,7 @@ extern "C" int sgr_render_bwd_brdf(const float* g_diffuse, const float* g_spec, 
   a.dirs = reinterpret_cast<const float4*>(dirs); a.view = view;
   a.g_albedo = g_albedo; a.g_normal = g_normal; a.g_rough = g_rough;
   a.bn = bn; a.K = env ? 0 : K; a.R = R; a.C = C; a.J = eh * ew; a.Jpad = sgr_dirs_padded(a.J); a.imH = imH; a.imW = imW;
-  a.F0 = F0; a.premap = premap; a.eh = eh; a.ew = ew;
+  a.F0 = F0; a.premap = premap == 1 ? 1 : 0; a.eh = eh; a.ew = ew;      // 2 = post-tan SG inputs: nothing to pre-map, no SG chain rule here
   const hipStream_t st = (hipStream_t)stream;
   return sgr_check(imH == R ? brdf_launch<1>(a, st) : brdf_launch<2>(a, st), "sgr_render_bwd_brdf");
 }

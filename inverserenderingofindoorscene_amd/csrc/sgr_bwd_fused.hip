@@ -11,6 +11,7 @@ extern "C" int sgr_fused_bwd_sg(const float* g_env, const float* g_diffuse, cons
   SGR_REQUIRE(g_diffuse && g_spec && albedo && normal && rough && axis && lamb && weight && dirs && view && g_axis &&
                   g_lamb && g_weight, "sgr_fused_bwd_sg: NULL tensor");
   SGR_REQUIRE(bn > 0 && K > 0 && R > 0 && C > 0 && eh > 0 && ew > 0, "sgr_fused_bwd_sg: non-positive size");
+  SGR_REQUIRE(premap >= 0 && premap <= 2, "sgr_fused_bwd_sg: premap must be 0, 1 or 2");
   if (int rc = check_pool_b(R, C, imH, imW, "sgr_fused_bwd_sg: BRDF-map / env-grid ratio must be 1 or 2 (pool first)")) return rc;
   Args a{};
   a.g_env = g_env; a.g_diffuse = g_diffuse; a.g_spec = g_spec;

@@ -54,7 +54,7 @@ __device__ __forceinline__ void load_lobes(const Args& a, const Pix& x, int kg, 
   for (int k = 0; k < KP; ++k) {
     const bool live = kg + k < K;
     float l = L.lp[k], t0 = L.w0[k], t1 = L.w1[k], t2 = L.w2[k];
-    if (a.premap) {
+    if (a.premap == 1) {
       l = premap(l);
       t0 = premap(t0); t1 = premap(t1); t2 = premap(t2);
       if (write_tan && live && x.active) {
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(kWave, OCC) void fwd_half_kernel(const Args a) {
       const int kk = half * KPW + k;
       const bool live = kk < K;
       float l = L.lp[k], t0 = L.w0[k], t1 = L.w1[k], t2 = L.w2[k];
-      if (a.premap) {
+      if (a.premap == 1) {
         l = premap(l); t0 = premap(t0); t1 = premap(t1); t2 = premap(t2);
         if (live && x.active) {
           const unsigned o3 = (unsigned)(kk * 3 * RC + p), o1 = (unsigned)(kk * RC + p);
@@ -952,7 +952,7 @@ __global__ __launch_bounds__(kWave, OCC) void sg_bwd_half_kernel(const Args a) {
     for (int k = 0; k < KPW; ++k) {
       const bool live = half * KPW + k < K;
       float l = L.lp[k], t0 = L.w0[k], t1 = L.w1[k], t2 = L.w2[k];
-      if (a.premap) { l = premap(l); t0 = premap(t0); t1 = premap(t1); t2 = premap(t2); }
+      if (a.premap == 1) { l = premap(l); t0 = premap(t0); t1 = premap(t1); t2 = premap(t2); }
       L.lp[k] = l * kLog2e;
       L.w0[k] = live ? t0 : 0.0f; L.w1[k] = live ? t1 : 0.0f; L.w2[k] = live ? t2 : 0.0f;
     }

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(kWave, 2) void fwd_kernel(const Args a) {
         az[k] = (a.axis + ab + 2 * (size_t)RC)[up];
         float l = (a.lamb + lb)[up];
         float t0 = (a.weight + ab)[up], t1 = (a.weight + ab + RC)[up], t2 = (a.weight + ab + 2 * (size_t)RC)[up];
-        if (a.premap) {
+        if (a.premap == 1) {
           l = premap(l);
           t0 = premap(t0); t1 = premap(t1); t2 = premap(t2);
           if (a.lamb_tan && x.active) (a.lamb_tan + lb)[up] = l;
@@ -204,6 +204,41 @@ static int fwd_pk_half24_launch(const Args& a, hipStream_t st) {
     hipLaunchKernelGGL((fwd_pk_half_kernel<2, WRITE_ENV, DO_RENDER, 2, 12, EW>), grid, block, 0, st, a);
   return (int)hipGetLastError();
 }
+// mixed grid (sgr_pk.inl, fwd_pk_mixed_kernel): whole rounds of 64-pixel units, the last partial round as 32-pixel half-wave units.
+// slots = resident one-pixel-per-lane waves on the device (2 per SIMD); SGR_FWD_SLOTS overrides, SGR_FWD_MIXED=0 disables.
+static inline int fwd_wave_slots() {
+  static const int forced = [] { const char* e = getenv("SGR_FWD_SLOTS"); return e ? atoi(e) : 0; }();
+  if (forced > 0) return forced;
+  static int per_device[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 2048;
+  if (per_device[dev] == 0) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    per_device[dev] = cus * 4 * 2;
+  }
+  return per_device[dev];
+}
+static inline bool fwd_mixed_enabled() {
+  static const bool on = [] { const char* e = getenv("SGR_FWD_MIXED"); return !(e && atoi(e) == 0); }();
+  return on;
+}
+// number of leading 64-pixel units that run one pixel per lane; the rest are split.  The tail is split only when it fills at
+// most half of the slots (twice as many half-length waves then still fit one round); a fuller last round is left alone.
+static inline int fwd_mixed_nfull(int units) {
+  const int slots = fwd_wave_slots();
+  const int tail = units % slots;
+  return (tail != 0 && 2 * tail <= slots) ? units - tail : units;
+}
+template <int UNUSED = 0>      // a template so that only translation units that launch it instantiate the kernels
+static int fwd_pk_mixed_launch(const Args& a, hipStream_t st, int nfull) {
+  const int units = (int)wave_grid(a.bn, a.R, a.C).x;
+  const dim3 grid((unsigned)(nfull + 2 * (units - nfull))), block(kWave);
+  if (a.imH == a.R && a.imW == a.C) hipLaunchKernelGGL((fwd_pk_mixed_kernel<1>), grid, block, 0, st, a, nfull);
+  else hipLaunchKernelGGL((fwd_pk_mixed_kernel<2>), grid, block, 0, st, a, nfull);
+  return (int)hipGetLastError();
+}
+
 static inline int fwd_mode() {     // 4 packed (default; 7: one pixel per lane always, 5 / 6: half-wave always), 0 scalar one pixel per lane, 2 / 3 scalar half-wave kernel, -1 round-1 default
   static const int mode = [] {
     const char* e = getenv("SGR_FWD_MODE");
@@ -233,6 +268,12 @@ static int fwd_fast_launch(const Args& a, hipStream_t st) {
   // (output2env.output2env alone): 172 vs 154 us -> half-wave; render only: 142 vs 150 us -> one pixel per lane
   if (a.ew == 16 && a.K > 6 && a.K <= 12 && (fwd_mode() >= 5 || (fwd_mode() == 4 && WRITE_ENV && !DO_RENDER)))
     return fwd_mode() == 5 ? fwd_pk_half_launch<WRITE_ENV, DO_RENDER, 2>(a, st) : fwd_pk_half_launch<WRITE_ENV, DO_RENDER, 3>(a, st);
+  if constexpr (WRITE_ENV && DO_RENDER) {
+    if (fwd_mode() == 4 && a.ew == 16 && a.K > 6 && a.K <= 12 && fwd_mixed_enabled()) {
+      const int units = (int)wave_grid(a.bn, a.R, a.C).x, nfull = fwd_mixed_nfull(units);
+      if (nfull < units) return fwd_pk_mixed_launch<>(a, st, nfull);
+    }
+  }
   if (fwd_mode() >= 4 && a.ew == 16 && a.K <= 12)
     return a.K <= 6 ? fwd_pk_launch<6, WRITE_ENV, DO_RENDER>(a, st) : fwd_pk_launch<12, WRITE_ENV, DO_RENDER>(a, st);
   const int mode = (fwd_mode() >= 0 && fwd_mode() < 4) ? fwd_mode() : (WRITE_ENV ? 2 : 0);

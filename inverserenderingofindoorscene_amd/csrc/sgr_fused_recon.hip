@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_kernel(const Args a) {
   for (int k = 0; k < KPW; ++k) {
     const bool live = half * KPW + k < K;
     float l = L.lp[k], t0 = L.w0[k], t1 = L.w1[k], t2 = L.w2[k];
-    if (a.premap) { l = premap(l); t0 = premap(t0); t1 = premap(t1); t2 = premap(t2); }
+    if (a.premap == 1) { l = premap(l); t0 = premap(t0); t1 = premap(t1); t2 = premap(t2); }
     L.lp[k] = l * kLog2e;
     L.w0[k] = live ? t0 : 0.0f; L.w1[k] = live ? t1 : 0.0f; L.w2[k] = live ? t2 : 0.0f;
   }
@@ -450,29 +450,32 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
   }
 
   if (x.active) {
-    float* g_axis_b = a.g_axis + (size_t)b * K * 3 * RC;
-    float* g_lamb_b = a.g_lamb + (size_t)b * K * RC;
-    float* g_weight_b = a.g_weight + (size_t)b * K * 3 * RC;
+    // wave-uniform plane base of lobe slot k + the lane's 32-bit byte offset (see load_lobes_pk)
+    const unsigned o3_own = ((unsigned)(half * KPW * 3 * RC) + (unsigned)p) * 4u, o1_own = ((unsigned)(half * KPW * RC) + (unsigned)p) * 4u;
+    char* g_axis_b = reinterpret_cast<char*>(a.g_axis + (size_t)b * K * 3 * RC);
+    char* g_lamb_b = reinterpret_cast<char*>(a.g_lamb + (size_t)b * K * RC);
+    char* g_weight_b = reinterpret_cast<char*>(a.g_weight + (size_t)b * K * 3 * RC);
 #pragma unroll
     for (int k = 0; k < KPW; ++k) {
       const int kk = half * KPW + k;
       if (kk < K) {
-        const unsigned o3 = (unsigned)(kk * 3 * RC + p), o1 = (unsigned)(kk * RC + p);
         const float lpk = (k & 1) ? P.lpp[k / 2].y : P.lpp[k / 2].x;
         const float w0 = P.w01[k].x, w1 = P.w01[k].y, w2 = (k & 1) ? P.w2p[k / 2].y : P.w2p[k / 2].x;
-        const float lam = fabsf(lpk) <= 1e-30f ? 0.0f : lpk * kLn2;      // the floor stands for lam == 0
-        g_axis_b[o3] = lam * (gx[k].x + gx[k].y);
-        g_axis_b[o3 + RC] = lam * (gy[k].x + gy[k].y);
-        g_axis_b[o3 + 2 * RC] = lam * (gz[k].x + gz[k].y);
+        const float lam = fabsf(lpk) <= kLpFloor ? 0.0f : lpk * kLn2;      // the floor stands for lam == 0
         float glk = (gl[k].x + gl[k].y) * frcp(lpk), q0 = gw0[k].x + gw0[k].y, q1 = gw1[k].x + gw1[k].y, q2 = gw2[k].x + gw2[k].y;
         if (a.premap) {
           glk *= premap_grad(lam);
           q0 *= premap_grad(w0); q1 *= premap_grad(w1); q2 *= premap_grad(w2);
         }
-        g_lamb_b[o1] = glk;
-        g_weight_b[o3] = q0;
-        g_weight_b[o3 + RC] = q1;
-        g_weight_b[o3 + 2 * RC] = q2;
+        char* pa = g_axis_b + (size_t)k * 3 * RC * 4;
+        char* pw = g_weight_b + (size_t)k * 3 * RC * 4;
+        *reinterpret_cast<float*>(pa + o3_own) = lam * (gx[k].x + gx[k].y);
+        *reinterpret_cast<float*>(pa + (size_t)RC * 4 + o3_own) = lam * (gy[k].x + gy[k].y);
+        *reinterpret_cast<float*>(pa + (size_t)RC * 8 + o3_own) = lam * (gz[k].x + gz[k].y);
+        *reinterpret_cast<float*>(g_lamb_b + (size_t)k * RC * 4 + o1_own) = glk;
+        *reinterpret_cast<float*>(pw + o3_own) = q0;
+        *reinterpret_cast<float*>(pw + (size_t)RC * 4 + o3_own) = q1;
+        *reinterpret_cast<float*>(pw + (size_t)RC * 8 + o3_own) = q2;
       }
     }
   }
@@ -515,11 +518,11 @@ extern "C" int sgr_fused_recon_workspace_floats(int bn, int R, int C) {
   return bn + 4 + bn * recon_tiles32(R * C) * 3 + bn * recon_tiles32(R * C);
 }
 
-extern "C" int sgr_fused_fwd_recon(const float* albedo, const float* normal, const float* rough, const float* axis, const float* lamb,
-                                   const float* weight, const float* dirs, const float* view, const float* env_gt,
-                                   const float* seg_small, const float* env_ind, float* diffuse, float* spec, float* mask,
-                                   float* coef, float* parts, float* workspace, int bn, int K, int R, int C, int eh, int ew, int imH,
-                                   int imW, float F0, int premap, void* stream) {
+static int fused_fwd_recon_impl(const float* albedo, const float* normal, const float* rough, const float* axis, const float* lamb,
+                               const float* weight, const float* dirs, const float* view, const float* env_gt,
+                               const float* seg_small, const float* env_ind, float* lamb_tan, float* weight_tan, float* diffuse,
+                               float* spec, float* mask, float* coef, float* parts, float* workspace, int bn, int K, int R, int C,
+                               int eh, int ew, int imH, int imW, float F0, int premap, void* stream) {
   SGR_REQUIRE(albedo && normal && rough && axis && lamb && weight && dirs && view && env_gt && seg_small && env_ind && diffuse &&
                   spec && mask && coef && parts && workspace,
               "sgr_fused_fwd_recon: NULL tensor");
@@ -530,8 +533,9 @@ extern "C" int sgr_fused_fwd_recon(const float* albedo, const float* normal, con
   a.albedo = albedo; a.normal = normal; a.rough = rough; a.axis = axis; a.lamb = lamb; a.weight = weight;
   a.dirs = reinterpret_cast<const float4*>(dirs); a.view = view; a.diffuse = diffuse; a.spec = spec;
   a.env_gt = env_gt; a.seg_small = seg_small; a.env_ind = env_ind; a.mask = mask;
+  a.lamb_tan = lamb_tan; a.weight_tan = weight_tan;
   set_dims(a, bn, K, R, C, eh, ew, imH, imW);
-  a.F0 = F0; a.premap = premap;
+  a.F0 = F0; a.premap = premap == 1 ? 1 : 0;
   // SGR_F1_MODE=half: half-wave statistics kernel (32-pixel work units); scalar: round 1's one pixel per lane; default: packed fp32
   static const int f1_mode = [] { const char* e = getenv("SGR_F1_MODE"); return !e ? 0 : (!strcmp(e, "half") ? 1 : (!strcmp(e, "scalar") ? 2 : 0)); }();
   const bool f1_half = f1_mode == 1 && K > 6;
@@ -566,6 +570,25 @@ extern "C" int sgr_fused_fwd_recon(const float* albedo, const float* normal, con
   return sgr_check((int)hipGetLastError(), "sgr_fused_fwd_recon");
 }
 
+extern "C" int sgr_fused_fwd_recon(const float* albedo, const float* normal, const float* rough, const float* axis, const float* lamb,
+                                   const float* weight, const float* dirs, const float* view, const float* env_gt,
+                                   const float* seg_small, const float* env_ind, float* diffuse, float* spec, float* mask,
+                                   float* coef, float* parts, float* workspace, int bn, int K, int R, int C, int eh, int ew, int imH,
+                                   int imW, float F0, int premap, void* stream) {
+  return fused_fwd_recon_impl(albedo, normal, rough, axis, lamb, weight, dirs, view, env_gt, seg_small, env_ind, nullptr, nullptr, diffuse,
+                              spec, mask, coef, parts, workspace, bn, K, R, C, eh, ew, imH, imW, F0, premap, stream);
+}
+// also returns the post-tan sharpness / intensity for sgr_fused_bwd_recon(premap = 2)
+extern "C" int sgr_fused_fwd_recon_tan(const float* albedo, const float* normal, const float* rough, const float* axis,
+                                       const float* lamb, const float* weight, const float* dirs, const float* view,
+                                       const float* env_gt, const float* seg_small, const float* env_ind, float* lamb_tan,
+                                       float* weight_tan, float* diffuse, float* spec, float* mask, float* coef, float* parts,
+                                       float* workspace, int bn, int K, int R, int C, int eh, int ew, int imH, int imW, float F0,
+                                       int premap, void* stream) {
+  return fused_fwd_recon_impl(albedo, normal, rough, axis, lamb, weight, dirs, view, env_gt, seg_small, env_ind, lamb_tan, weight_tan,
+                              diffuse, spec, mask, coef, parts, workspace, bn, K, R, C, eh, ew, imH, imW, F0, premap, stream);
+}
+
 extern "C" int sgr_fused_bwd_recon(const float* albedo, const float* normal, const float* rough, const float* axis, const float* lamb,
                                    const float* weight, const float* dirs, const float* view, const float* env_gt, const float* mask,
                                    const float* coef, const float* den_global, const float* g_diffuse, const float* g_spec,
@@ -576,6 +599,7 @@ extern "C" int sgr_fused_bwd_recon(const float* albedo, const float* normal, con
                   g_axis && g_lamb && g_weight && parts && workspace,
               "sgr_fused_bwd_recon: NULL tensor");
   SGR_REQUIRE(bn > 0 && K > 0 && R > 0 && C > 0 && eh > 0 && ew > 0, "sgr_fused_bwd_recon: non-positive size");
+  SGR_REQUIRE(premap >= 0 && premap <= 2, "sgr_fused_bwd_recon: premap must be 0, 1 or 2");
   SGR_SUPPORTED(fused_recon_ok(K, R, C, eh, ew), "sgr_fused_bwd_recon: needs envWidth 16, SGNum <= 12 (use the unfused calls)");
   if (int rc = check_pool(R, C, imH, imW, "sgr_fused_bwd_recon: BRDF-map / env-grid ratio must be 1 or 2 (pool first)")) return rc;
   Args a{};

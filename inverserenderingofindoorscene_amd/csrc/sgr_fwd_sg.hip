@@ -12,7 +12,7 @@ extern "C" int sgr_sg_to_env_fwd(const float* axis, const float* lamb, const flo
   a.axis = axis; a.lamb = lamb; a.weight = weight; a.dirs = reinterpret_cast<const float4*>(dirs);
   a.env_out = env; a.lamb_tan = lamb_tan; a.weight_tan = weight_tan;
   set_dims(a, bn, K, R, C, eh, ew, R, C);
-  a.premap = premap;
+  a.premap = premap == 1 ? 1 : 0;
   return sgr_check(fwd_launch<true, true, false>(a, (hipStream_t)stream), "sgr_sg_to_env_fwd");
 }
 
@@ -25,7 +25,7 @@ extern "C" int sgr_sg_shading(const float* axis, const float* lamb, const float*
   Args a{};
   a.axis = axis; a.lamb = lamb; a.weight = weight; a.dirs = reinterpret_cast<const float4*>(dirs); a.diffuse = shading;
   set_dims(a, bn, K, R, C, eh, ew, R, C);
-  a.premap = premap;
+  a.premap = premap == 1 ? 1 : 0;
   const dim3 grid = wave_grid(bn, R, C), block(kWave);
   const hipStream_t st = (hipStream_t)stream;
   if (ew == 16) {

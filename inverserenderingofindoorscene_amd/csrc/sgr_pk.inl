@@ -64,10 +64,33 @@ __device__ __forceinline__ Pix locate_group32(const Args& a, int g) {
   return x;
 }
 
+// the 64-pixel unit `u` of a one-pixel-per-lane launch (locate() with an explicit unit index)
+__device__ __forceinline__ Pix locate_unit(const Args& a, int u) {
+  Pix x;
+  x.lane = threadIdx.x;
+  const int RC = a.R * a.C, tiles = (RC + kWave - 1) / kWave;
+  x.b = u / tiles;
+  x.p0 = (u - x.b * tiles) * kWave;
+  x.active = (x.p0 + x.lane) < RC;
+  x.p = x.active ? (x.p0 + x.lane) : (RC - 1);
+  return x;
+}
+// half `h` (pixels 32 h .. 32 h + 31) of the 64-pixel unit `u`, as a half-wave kernel's 32-pixel group
+__device__ __forceinline__ Pix locate_half_of_unit(const Args& a, int u, int h) {
+  Pix x;
+  x.lane = threadIdx.x;
+  const int RC = a.R * a.C, tiles = (RC + kWave - 1) / kWave, pl = x.lane & 31;
+  x.b = u / tiles;
+  x.p0 = (u - x.b * tiles) * kWave + h * kPx;
+  x.active = (x.p0 + pl) < RC;
+  x.p = x.active ? (x.p0 + pl) : (RC - 1);
+  return x;
+}
+
 // SG parameters of the lane's pixel in register pairs (KP even; lobes past K carry zero weights).
 // FOLD: axis pre-multiplied by lp = lam * log2e (forward and sg_bwd_pk_kernel); unit axes otherwise (objective backward).
-// The backward divides its sharpness gradient by lp again (see there), so a |lp| below 1e-30 -- lam == 0 is what the
-// decoders' clamp produces -- is replaced by 1e-30: exp2(1e-30 t) is exactly 1, like exp2(0 t).
+// The backward divides its sharpness gradient by lp again (see there), so a |lp| below kLpFloor = 2^-40 -- lam == 0 is
+// what the decoders' clamp produces -- is replaced by the floor: exp2(2^-40 t) is exactly 1, like exp2(0 t).
 template <int KP>
 struct LobesPk {
   f32x2 axy[KP];        // (ax, ay)
@@ -76,10 +99,54 @@ struct LobesPk {
   f32x2 azp[KP / 2];    // (az, az)  likewise
   f32x2 lpp[KP / 2];    // (lp, lp)  likewise
 };
+// Two pre-maps at a time (round 3): tan(fl(fl(0.999 x) pi/2)) with the argument products, the Cody-Waite reduction and the
+// polynomial of sgr_math.h's tan_f32 issued as v_pk_mul / v_pk_fma_f32 over a register pair; only the parity select and
+// v_rcp_f32 stay per element.  n = rint(y 2/pi) comes out of the 1.5 * 2^23 magic-number add (one packed FMA + one packed
+// subtract instead of a multiply and two v_rndne), which also leaves the parity of n in the low mantissa bit of q -- no
+// v_cvt.  Valid for |y| < 2^22 pi/2 (the decoders produce y in [0, 1.5692]).  Against tan_f32 the quotient is rounded once
+// instead of twice, so n can differ at exact ties of y 2/pi (z = +-pi/4: both branches are equally accurate there).
+// 23 instructions per pair against 2 x 19: 48 pre-maps per pixel in the forward.
+// Written for two pairs in lockstep: a packed fp32 instruction needs one wait state before a dependent one (the compiler
+// pads a lone chain with an s_nop after every instruction), and the two independent chains fill each other's gaps.
+__device__ __forceinline__ void premap2x2(f32x2& u, f32x2& v) {
+  constexpr float kMagic = 12582912.0f;
+  const f32x2 yu = (u * splat2(kPremapScale)) * splat2(kHalfPiHi);      // two rounded products, like torch (no add to contract with)
+  const f32x2 yv = (v * splat2(kPremapScale)) * splat2(kHalfPiHi);
+  f32x2 qu = pfma(yu, splat2(kTwoOverPi), splat2(kMagic));
+  f32x2 qv = pfma(yv, splat2(kTwoOverPi), splat2(kMagic));
+  asm("" : "+v"(qu));                                                    // (y c + M) - M must not be simplified
+  asm("" : "+v"(qv));
+  const f32x2 nu = qu - splat2(kMagic), nv = qv - splat2(kMagic);
+  f32x2 zu = pfma(-nu, splat2(kPio2_1), yu), zv = pfma(-nv, splat2(kPio2_1), yv);
+  zu = pfma(-nu, splat2(kPio2_2), zu); zv = pfma(-nv, splat2(kPio2_2), zv);
+  zu = pfma(-nu, splat2(kPio2_3), zu); zv = pfma(-nv, splat2(kPio2_3), zv);
+  const f32x2 su = zu * zu, sv = zv * zv;
+  f32x2 pu = pfma(splat2(9.38540185543e-3f), su, splat2(3.11992232697e-3f)), pv = pfma(splat2(9.38540185543e-3f), sv, splat2(3.11992232697e-3f));
+  pu = pfma(pu, su, splat2(2.44301354525e-2f)); pv = pfma(pv, sv, splat2(2.44301354525e-2f));
+  pu = pfma(pu, su, splat2(5.34112807005e-2f)); pv = pfma(pv, sv, splat2(5.34112807005e-2f));
+  pu = pfma(pu, su, splat2(1.33387994085e-1f)); pv = pfma(pv, sv, splat2(1.33387994085e-1f));
+  pu = pfma(pu, su, splat2(3.33331568548e-1f)); pv = pfma(pv, sv, splat2(3.33331568548e-1f));
+  const f32x2 tu = pfma(pu * su, zu, zu), tv = pfma(pv * sv, zv, zv);
+  const bool u0 = (__float_as_uint(qu.x) & 1u) != 0, u1 = (__float_as_uint(qu.y) & 1u) != 0;
+  const bool v0 = (__float_as_uint(qv.x) & 1u) != 0, v1 = (__float_as_uint(qv.y) & 1u) != 0;
+  u = f32x2{u0 ? -frcp(tu.x) : tu.x, u1 ? -frcp(tu.y) : tu.y};
+  v = f32x2{v0 ? -frcp(tv.x) : tv.x, v1 ? -frcp(tv.y) : tv.y};
+}
+
+// |lp| below this floor stands for lam == 0 (see LobesPk): 2^-40 -- exp2(2^-40 t) is exactly 1 for the |t| <= 2 of the
+// layer, like exp2(0 t), and sums of T (lp t) stay twenty orders of magnitude above the denormal range even for the
+// 1e-9-sized cotangents of a normalised training loss (1e-30, the first choice, did not: ADVICE round 2)
+constexpr float kLpFloor = 9.094947017729282e-13f;
+
 // Loads (and pre-maps) the lobes straight into pairs; same two-pass structure as load_lobes (sgr_fast.inl): every load
 // of every lobe is in flight before the pre-map consumes any.  `kg` = first lobe (may differ between the two halves of
 // a wave, so the lobe planes are addressed by 32-bit per-lane offsets into the image's SG block); lobes past K re-read
 // lobe K-1 and get zero weights.
+// a.premap: 1 = lamb / weight are the decoders' raw outputs (pre-mapped here); 0 and 2 = they are post-tan already (2: the
+// backward still applies the pre-map's chain rule, see sg_bwd_pk_kernel).  The post-tan values go to a.lamb_tan /
+// a.weight_tan when those are given (an output of output2env.output2env, models.py:396-404, and what the backward
+// kernels read instead of re-evaluating 24 tangents per lane) -- in a loop of their own after the last pre-map, so that
+// the pre-map chains of all lobes interleave freely.
 template <int KP, bool FOLD>
 __device__ __forceinline__ void load_lobes_pk(const Args& a, int b, unsigned up, bool active, int kg, LobesPk<KP>& P, bool write_tan) {
   static_assert(KP % 2 == 0, "lobes are packed in pairs");
@@ -88,35 +155,60 @@ __device__ __forceinline__ void load_lobes_pk(const Args& a, int b, unsigned up,
   const float* lamb_b = a.lamb + (size_t)b * K * RC;
   const float* weight_b = a.weight + (size_t)b * K * 3 * RC;
   float ax[KP], ay[KP], az[KP], lp[KP], w0[KP], w1[KP], w2[KP];
+  // addresses: wave-uniform plane base (SGPR pair, scalar arithmetic) + one 32-bit per-lane BYTE offset -> the
+  // `global_load_dword v, v_off, s[base:base+1]` form with no per-load vector arithmetic (indexing a float* with a 32-bit
+  // element index costs a 64-bit shift + add per load: the scaled index may not fit 32 bits as far as the compiler knows).
+  // Lane offsets: first lobe kg of this lane's half; a lobe slot past K (second half of a wave, K < 2 KP) re-reads the
+  // slot's lobe of the first half instead (its weights are zeroed below).
+  const unsigned o3_own = ((unsigned)(kg * 3 * RC) + up) * 4u, o1_own = ((unsigned)(kg * RC) + up) * 4u, o_low = up * 4u;
 #pragma unroll
   for (int k = 0; k < KP; ++k) {
-    const int kk = min(kg + k, K - 1);
-    const unsigned o3 = (unsigned)(kk * 3 * RC) + up, o1 = (unsigned)(kk * RC) + up;
-    ax[k] = axis_b[o3]; ay[k] = axis_b[o3 + RC]; az[k] = axis_b[o3 + 2 * RC];
-    lp[k] = lamb_b[o1];
-    w0[k] = weight_b[o3]; w1[k] = weight_b[o3 + RC]; w2[k] = weight_b[o3 + 2 * RC];
+    const bool live = kg + k < K;
+    const int ku = min(k, K - 1);                                         // wave-uniform slot (K < KP: clamp)
+    const unsigned v3 = live ? o3_own : o_low, v1 = live ? o1_own : o_low;
+    const char* pa = reinterpret_cast<const char*>(axis_b + (size_t)ku * 3 * RC);
+    const char* pw = reinterpret_cast<const char*>(weight_b + (size_t)ku * 3 * RC);
+    const char* pl = reinterpret_cast<const char*>(lamb_b + (size_t)ku * RC);
+    ax[k] = *reinterpret_cast<const float*>(pa + v3);
+    ay[k] = *reinterpret_cast<const float*>(pa + (size_t)RC * 4 + v3);
+    az[k] = *reinterpret_cast<const float*>(pa + (size_t)RC * 8 + v3);
+    lp[k] = *reinterpret_cast<const float*>(pl + v1);
+    w0[k] = *reinterpret_cast<const float*>(pw + v3);
+    w1[k] = *reinterpret_cast<const float*>(pw + (size_t)RC * 4 + v3);
+    w2[k] = *reinterpret_cast<const float*>(pw + (size_t)RC * 8 + v3);
+  }
+  if (a.premap == 1) {
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+      f32x2 r0 = {lp[k], w0[k]}, r1 = {w1[k], w2[k]};
+      premap2x2(r0, r1);
+      lp[k] = r0.x; w0[k] = r0.y; w1[k] = r1.x; w2[k] = r1.y;
+    }
+    if (write_tan && (a.lamb_tan || a.weight_tan)) {
+      char* lt_b = a.lamb_tan ? reinterpret_cast<char*>(a.lamb_tan + (size_t)b * K * RC) : nullptr;
+      char* wt_b = a.weight_tan ? reinterpret_cast<char*>(a.weight_tan + (size_t)b * K * 3 * RC) : nullptr;
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        if (kg + k < K && active) {
+          if (lt_b) *reinterpret_cast<float*>(lt_b + (size_t)k * RC * 4 + o1_own) = lp[k];
+          if (wt_b) {
+            char* pw = wt_b + (size_t)k * 3 * RC * 4;
+            *reinterpret_cast<float*>(pw + o3_own) = w0[k];
+            *reinterpret_cast<float*>(pw + (size_t)RC * 4 + o3_own) = w1[k];
+            *reinterpret_cast<float*>(pw + (size_t)RC * 8 + o3_own) = w2[k];
+          }
+        }
+      }
+    }
   }
 #pragma unroll
   for (int k = 0; k < KP; ++k) {
     const bool live = kg + k < K;
-    float l = lp[k], t0 = w0[k], t1 = w1[k], t2 = w2[k];
-    if (a.premap) {
-      l = premap(l);
-      t0 = premap(t0); t1 = premap(t1); t2 = premap(t2);
-      if (write_tan && live && active) {
-        const unsigned o3 = (unsigned)((kg + k) * 3 * RC) + up, o1 = (unsigned)((kg + k) * RC) + up;
-        if (a.lamb_tan) (a.lamb_tan + (size_t)b * K * RC)[o1] = l;
-        if (a.weight_tan) {
-          float* wt_b = a.weight_tan + (size_t)b * K * 3 * RC;
-          wt_b[o3] = t0; wt_b[o3 + RC] = t1; wt_b[o3 + 2 * RC] = t2;
-        }
-      }
-    }
-    float lpk = l * kLog2e;
-    if (FOLD) lpk = fabsf(lpk) < 1e-30f ? 1e-30f : lpk;
+    float lpk = lp[k] * kLog2e;
+    if (FOLD) lpk = fabsf(lpk) < kLpFloor ? kLpFloor : lpk;
     lp[k] = lpk;
     if (FOLD) { ax[k] *= lpk; ay[k] *= lpk; az[k] *= lpk; }
-    w0[k] = live ? t0 : 0.0f; w1[k] = live ? t1 : 0.0f; w2[k] = live ? t2 : 0.0f;
+    if (!live) w0[k] = w1[k] = w2[k] = 0.0f;
   }
 #pragma unroll
   for (int k = 0; k < KP; ++k) {
@@ -199,23 +291,20 @@ __device__ __forceinline__ void shade_pair(const PixLocal& q, const OrthoPix& oq
 // table row per 12 KB tile requested the moment the previous row's last pairs are in registers, and every lane accumulates
 // <pred, gt>, <pred, pred> and sum(gt) of its pixel as azimuth pairs -- the statistics behind the env mask and the
 // LSregress scale (wrapperBRDFLight.py:172-176, models.py:7-21).  Per-wave partials land in a.ws[blockIdx.x * 3 + {0,1,2}].
-template <int KP, int POOL, bool WRITE_ENV, bool DO_RENDER, bool HAS_GT = false>
-__global__ __launch_bounds__(kWave, 2) void fwd_pk_kernel(const Args a) {
+// `unit` = index of the 64-pixel group in the launch's (image, tile) order; `tile` / `gtile` = the workgroup's LDS (env tile
+// of Tile<TJ>::kFloats floats when WRITE_ENV, ground-truth row tile of DmaTile<16>::kFloats floats when HAS_GT)
+template <int KP, int POOL, bool WRITE_ENV, bool DO_RENDER, bool HAS_GT>
+__device__ __forceinline__ void fwd_pk_body(const Args& a, int unit, float* tile, float* gtile) {
   static_assert(!(HAS_GT && WRITE_ENV), "the statistics variant does not write the env image");
   constexpr int EW = 16, TJ = SGR_PK_TJ, HALF = 8, NQ = 2, RPT = TJ / EW;
-  __shared__ __attribute__((aligned(16))) float tile[WRITE_ENV ? Tile<TJ>::kFloats : 4];
-  using GD = DmaTile<16>;
-  __shared__ __attribute__((aligned(16))) float gtile[HAS_GT ? GD::kFloats : 4];
   SGR_TRACE_BEGIN
 
-  const Pix x = locate(a);
+  const Pix x = locate_unit(a, unit);
   const int lane = x.lane, b = x.b, p = x.p;
   const int RC = a.R * a.C;
 
   LobesPk<KP> P;
-  // the post-tan copies are an output of sgr_sg_to_env_fwd only (no render): a compile-time `false` elsewhere keeps the
-  // scalar branches of the conditional stores out of the pre-map code, whose four chains per lobe then interleave freely
-  load_lobes_pk<KP, true>(a, b, (unsigned)p, x.active, 0, P, !DO_RENDER);
+  load_lobes_pk<KP, true>(a, b, (unsigned)p, x.active, 0, P, true);      // post-tan copies leave when a.lamb_tan / a.weight_tan are given
 
   PixLocal q;
   OrthoPix oq;
@@ -349,7 +438,7 @@ __global__ __launch_bounds__(kWave, 2) void fwd_pk_kernel(const Args a) {
       r0 += __shfl_xor(r0, off, 64); r1 += __shfl_xor(r1, off, 64); r2 += __shfl_xor(r2, off, 64);
     }
     if (lane == 0) {
-      float* w = a.ws + (size_t)blockIdx.x * 3;
+      float* w = a.ws + (size_t)unit * 3;
       w[0] = r0; w[1] = r1; w[2] = r2;
     }
   }
@@ -365,6 +454,12 @@ __global__ __launch_bounds__(kWave, 2) void fwd_pk_kernel(const Args a) {
   }
   SGR_TRACE_END
 }
+template <int KP, int POOL, bool WRITE_ENV, bool DO_RENDER, bool HAS_GT = false>
+__global__ __launch_bounds__(kWave, 2) void fwd_pk_kernel(const Args a) {
+  __shared__ __attribute__((aligned(16))) float tile[WRITE_ENV ? Tile<SGR_PK_TJ>::kFloats : 4];
+  __shared__ __attribute__((aligned(16))) float gtile[HAS_GT ? DmaTile<16>::kFloats : 4];
+  fwd_pk_body<KP, POOL, WRITE_ENV, DO_RENDER, HAS_GT>(a, (int)blockIdx.x, tile, gtile);
+}
 
 
 // ============================== forward, half-wave lobe split, packed ==============================================
@@ -376,20 +471,19 @@ __global__ __launch_bounds__(kWave, 2) void fwd_pk_kernel(const Args a) {
 // per lane as before) -- for 12 swaps + 6 packed adds per azimuth quad.
 // KPW = 12, EW = 32 (OCC 2): SGNum up to 24 on the 16x32 grid of BASELINE config 5 -- the one-pixel-per-lane kernels would
 // need 24 lobes per lane there and spill.
-template <int POOL, bool WRITE_ENV, bool DO_RENDER, int OCC, int KPW = 6, int EW = 16>
-__global__ __launch_bounds__(kWave, OCC) void fwd_pk_half_kernel(const Args a) {
+// `x` = the 32-pixel group of this wave (locate_group32 / locate_half_of_unit); `tile` = T32Out<EW>::kFloats floats of LDS when WRITE_ENV
+template <int POOL, bool WRITE_ENV, bool DO_RENDER, int KPW, int EW>
+__device__ __forceinline__ void fwd_pk_half_body(const Args& a, const Pix x, float* tile) {
   constexpr int HALF = EW / 2, NQ = HALF / 4, TD = EW;
-  __shared__ __attribute__((aligned(16))) float tile[WRITE_ENV ? T32Out<TD>::kFloats : 4];
   SGR_TRACE_BEGIN
 
   const int lane = threadIdx.x, half = lane >> 5, pl = lane & 31;
   const int own = 1 - half;                         // the half row (sign) whose totals this half-wave ends up holding
   const int RC = a.R * a.C;
-  const Pix x = locate_group32(a, (int)blockIdx.x);
   const int b = x.b, p = x.p;
 
   LobesPk<KPW> P;      // this half's lobes, folded (axis pre-multiplied by lam * log2e)
-  load_lobes_pk<KPW, true>(a, b, (unsigned)p, x.active, half * KPW, P, !DO_RENDER);
+  load_lobes_pk<KPW, true>(a, b, (unsigned)p, x.active, half * KPW, P, true);
 
   PixLocal q;
   OrthoPix oq;
@@ -513,6 +607,31 @@ __global__ __launch_bounds__(kWave, OCC) void fwd_pk_half_kernel(const Args a) {
     }
   }
   SGR_TRACE_END
+}
+template <int POOL, bool WRITE_ENV, bool DO_RENDER, int OCC, int KPW = 6, int EW = 16>
+__global__ __launch_bounds__(kWave, OCC) void fwd_pk_half_kernel(const Args a) {
+  __shared__ __attribute__((aligned(16))) float tile[WRITE_ENV ? T32Out<EW>::kFloats : 4];
+  fwd_pk_half_body<POOL, WRITE_ENV, DO_RENDER, KPW, EW>(a, locate_group32(a, (int)blockIdx.x), tile);
+}
+
+// ============================== forward, mixed grid: whole rounds one pixel per lane, the last partial round half-wave ==========
+// The one-pixel-per-lane kernel runs two waves per SIMD; a launch whose last round fills at most half of the slots leaves those
+// SIMDs with one wave each (which issues only ~55 % of the time on its own) for a whole unit's duration: 20 % of the kernel at
+// 16 images (4800 units on 2048 slots).  Here the first `nfull` 64-pixel units -- whole rounds -- run fwd_pk_body, and each of the
+// remaining units is launched as two 32-pixel half-wave units (fwd_pk_half_body: six lobes per lane, half the work per wave,
+// 12 % more instructions for the exchange), twice as many waves of about half the duration.  Workgroups are dispatched in
+// id order, so the short units are the last ones to start.  One LDS allocation serves both paths.
+template <int POOL>
+__global__ __launch_bounds__(kWave, 2) void fwd_pk_mixed_kernel(const Args a, const int nfull) {
+  __shared__ __attribute__((aligned(16))) float tile[Tile<SGR_PK_TJ>::kFloats];
+  static_assert(Tile<SGR_PK_TJ>::kFloats >= T32Out<16>::kFloats, "the half-wave tile lives in the same allocation");
+  const int id = (int)blockIdx.x;
+  if (id < nfull) {
+    fwd_pk_body<12, POOL, true, true, false>(a, id, tile, nullptr);
+  } else {
+    const int i = id - nfull;
+    fwd_pk_half_body<POOL, true, true, 6, 16>(a, locate_half_of_unit(a, nfull + (i >> 1), i & 1), tile);
+  }
 }
 
 
@@ -712,29 +831,32 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
   if (ortho) row_loop(std::true_type{}); else row_loop(std::false_type{});
 
   if (x.active) {
-    float* g_axis_b = a.g_axis + (size_t)b * K * 3 * RC;
-    float* g_lamb_b = a.g_lamb + (size_t)b * K * RC;
-    float* g_weight_b = a.g_weight + (size_t)b * K * 3 * RC;
+    // same addressing as the loads: wave-uniform plane base of lobe slot k of lobe group `grp` + the lane's byte offset
+    const unsigned o3_own = ((unsigned)(half * KPW * 3 * RC) + (unsigned)p) * 4u, o1_own = ((unsigned)(half * KPW * RC) + (unsigned)p) * 4u;
+    char* g_axis_b = reinterpret_cast<char*>(a.g_axis + (size_t)b * K * 3 * RC);
+    char* g_lamb_b = reinterpret_cast<char*>(a.g_lamb + (size_t)b * K * RC);
+    char* g_weight_b = reinterpret_cast<char*>(a.g_weight + (size_t)b * K * 3 * RC);
 #pragma unroll
     for (int k = 0; k < KPW; ++k) {
-      const int kk = grp * 2 * KPW + half * KPW + k;
+      const int ks = grp * 2 * KPW + k, kk = ks + half * KPW;      // ks: wave-uniform slot; kk: this lane's lobe
       if (kk < K) {
-        const unsigned o3 = (unsigned)(kk * 3 * RC + p), o1 = (unsigned)(kk * RC + p);
         const float lpk = (k & 1) ? P.lpp[k / 2].y : P.lpp[k / 2].x;
         const float w0 = P.w01[k].x, w1 = P.w01[k].y, w2 = (k & 1) ? P.w2p[k / 2].y : P.w2p[k / 2].x;
-        const float lam = fabsf(lpk) <= 1e-30f ? 0.0f : lpk * kLn2;      // the floor stands for lam == 0
-        g_axis_b[o3] = lam * (gx[k].x + gx[k].y);
-        g_axis_b[o3 + RC] = lam * (gy[k].x + gy[k].y);
-        g_axis_b[o3 + 2 * RC] = lam * (gz[k].x + gz[k].y);
+        const float lam = fabsf(lpk) <= kLpFloor ? 0.0f : lpk * kLn2;      // the floor stands for lam == 0
         float glk = (gl[k].x + gl[k].y) * frcp(lpk), q0 = gw0[k].x + gw0[k].y, q1 = gw1[k].x + gw1[k].y, q2 = gw2[k].x + gw2[k].y;
         if (a.premap) {
           glk *= premap_grad(lam);
           q0 *= premap_grad(w0); q1 *= premap_grad(w1); q2 *= premap_grad(w2);
         }
-        g_lamb_b[o1] = glk;
-        g_weight_b[o3] = q0;
-        g_weight_b[o3 + RC] = q1;
-        g_weight_b[o3 + 2 * RC] = q2;
+        char* pa = g_axis_b + (size_t)ks * 3 * RC * 4;
+        char* pw = g_weight_b + (size_t)ks * 3 * RC * 4;
+        *reinterpret_cast<float*>(pa + o3_own) = lam * (gx[k].x + gx[k].y);
+        *reinterpret_cast<float*>(pa + (size_t)RC * 4 + o3_own) = lam * (gy[k].x + gy[k].y);
+        *reinterpret_cast<float*>(pa + (size_t)RC * 8 + o3_own) = lam * (gz[k].x + gz[k].y);
+        *reinterpret_cast<float*>(g_lamb_b + (size_t)ks * RC * 4 + o1_own) = glk;
+        *reinterpret_cast<float*>(pw + o3_own) = q0;
+        *reinterpret_cast<float*>(pw + (size_t)RC * 4 + o3_own) = q1;
+        *reinterpret_cast<float*>(pw + (size_t)RC * 8 + o3_own) = q2;
       }
     }
   }

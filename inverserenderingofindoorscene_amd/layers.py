@@ -121,8 +121,10 @@ class renderingLayer:
         self._check_grid(R, C)
         _require_hip(diffusePred, normalPred, roughPred, axisOrig, lambOrig, weightOrig)
         a, n, r = _prepool(diffusePred, normalPred, roughPred, R, C)
-        env, d, s = torch.ops.sgrender.fused_render(a, n, r, axisOrig, lambOrig, weightOrig, self.envHeight, self.envWidth,
-                                                    self.fov_deg, float(self.F0), list(self._cam), bool(premap), bool(need_env))
+        # the post-tan sharpness / intensity leave the forward kernel only when a backward will read them
+        want_tan = bool(premap) and torch.is_grad_enabled() and (axisOrig.requires_grad or lambOrig.requires_grad or weightOrig.requires_grad)
+        env, d, s, _, _ = torch.ops.sgrender.fused_render(a, n, r, axisOrig, lambOrig, weightOrig, self.envHeight, self.envWidth,
+                                                          self.fov_deg, float(self.F0), list(self._cam), bool(premap), bool(need_env), want_tan)
         return (env if need_env else None), d, s
 
 

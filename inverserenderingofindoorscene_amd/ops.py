@@ -151,7 +151,9 @@ def _(axis, lamb, weight, eh, ew, premap, want_tan):
 
 
 @torch.library.custom_op("sgrender::sg_to_env_bwd", mutates_args=())
-def sg_to_env_bwd(g_env: Tensor, axis: Tensor, lamb: Tensor, weight: Tensor, eh: int, ew: int, premap: bool) -> Tuple[Tensor, Tensor, Tensor]:
+def sg_to_env_bwd(g_env: Tensor, axis: Tensor, lamb: Tensor, weight: Tensor, eh: int, ew: int, premap: int) -> Tuple[Tensor, Tensor, Tensor]:
+    """``premap``: 0 post-tan inputs (gradients w.r.t. them), 1 raw decoder outputs, 2 post-tan inputs saved by the forward with
+    the gradients still w.r.t. the raw ones (include/sgrender.h)."""
     dev = _require_hip(g_env, axis, lamb, weight)
     g_env, axis, lamb, weight = g_env.contiguous(), axis.contiguous(), lamb.contiguous(), weight.contiguous()
     bn, K, R, C = _check_sg(axis, lamb, weight, None)
@@ -170,9 +172,15 @@ def _(g_env, axis, lamb, weight, eh, ew, premap):
 
 
 def _sg_to_env_setup(ctx, inputs, output):
-    axis, lamb, weight, eh, ew, premap, _ = inputs
-    ctx.save_for_backward(axis, lamb, weight)
-    ctx.cfg = (eh, ew, premap)
+    axis, lamb, weight, eh, ew, premap, want_tan = inputs
+    if premap and want_tan:
+        # the post-tan tensors exist anyway (the reference returns them): the backward reads them instead of re-evaluating
+        # 4K tangents per cell (premap mode 2)
+        ctx.save_for_backward(axis, output[1], output[2])
+        ctx.cfg = (eh, ew, 2)
+    else:
+        ctx.save_for_backward(axis, lamb, weight)
+        ctx.cfg = (eh, ew, int(premap))
     ctx.set_materialize_grads(False)
 
 
@@ -183,15 +191,14 @@ def _sg_to_env_backward(ctx, g_env, g_lam_t, g_w_t):
     if g_env is not None:
         g_axis, g_lamb, g_weight = torch.ops.sgrender.sg_to_env_bwd(g_env, axis, lamb, weight, eh, ew, premap)
     # cotangents of the returned post-tan tensors (nobody in the reference differentiates through them,
-    # wrapperBRDFLight.py:177; handled for completeness with elementwise torch)
+    # wrapperBRDFLight.py:177; handled for completeness with elementwise torch).  Only produced in mode 2,
+    # where `lamb` / `weight` are the saved post-tan tensors themselves.
     scale = 0.999 * (np.pi / 2)
     if g_lam_t is not None and g_lam_t.numel():
-        y = torch.tan(np.pi / 2 * (0.999 * lamb))
-        extra = g_lam_t * scale * (1 + y * y)
+        extra = g_lam_t * scale * (1 + lamb * lamb)
         g_lamb = extra if g_lamb is None else g_lamb + extra
     if g_w_t is not None and g_w_t.numel():
-        y = torch.tan(np.pi / 2 * (0.999 * weight))
-        extra = g_w_t * scale * (1 + y * y)
+        extra = g_w_t * scale * (1 + weight * weight)
         g_weight = extra if g_weight is None else g_weight + extra
     return g_axis, g_lamb, g_weight, None, None, None, None
 
@@ -316,8 +323,9 @@ render_env.register_autograd(_render_env_backward, setup_context=_render_env_set
 # --------------------------------------------------------------------------- #
 @torch.library.custom_op("sgrender::fused_render", mutates_args=())
 def fused_render(albedo: Tensor, normal: Tensor, rough: Tensor, axis: Tensor, lamb: Tensor, weight: Tensor, eh: int, ew: int,
-                 fov: float, F0: float, cam: List[float], premap: bool, need_env: bool) -> Tuple[Tensor, Tensor, Tensor]:
-    """``(env, diffuse, spec)``; ``env`` is empty when ``need_env`` is false (the env image is then never materialised)."""
+                 fov: float, F0: float, cam: List[float], premap: bool, need_env: bool, want_tan: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
+    """``(env, diffuse, spec, lamb_tan, weight_tan)``; ``env`` is empty when ``need_env`` is false (the env image is then never
+    materialised); the post-tan tensors are empty unless ``premap and want_tan`` (they are what the backward reads)."""
     dev = _require_hip(albedo, normal, rough, axis, lamb, weight)
     albedo_c, normal_c, rough_c = albedo.contiguous(), normal.contiguous(), rough.contiguous()
     axis_c, lamb_c, weight_c = axis.contiguous(), lamb.contiguous(), weight.contiguous()
@@ -328,27 +336,36 @@ def fused_render(albedo: Tensor, normal: Tensor, rough: Tensor, axis: Tensor, la
     env = torch.empty((bn, 3, R, C, eh, ew), device=dev, dtype=torch.float32) if need_env else albedo_c.new_empty(0)
     diffuse = torch.empty((bn, 3, R, C), device=dev, dtype=torch.float32)
     spec = torch.empty_like(diffuse)
+    tan = premap and want_tan
+    lam_t = torch.empty_like(lamb_c) if tan else lamb_c.new_empty(0)
+    w_t = torch.empty_like(weight_c) if tan else weight_c.new_empty(0)
     d, v = _dirs(dev, eh, ew), _view(dev, R, C, fov, cam)
     with torch.cuda.device(dev):
-        _lib.call("sgr_fused_fwd", _ptr(albedo_c), _ptr(normal_c), _ptr(rough_c), _ptr(axis_c), _ptr(lamb_c),
-                  _ptr(weight_c), _ptr(d), _ptr(v), _ptr(env) if need_env else None, _ptr(diffuse), _ptr(spec),
+        _lib.call("sgr_fused_fwd_tan", _ptr(albedo_c), _ptr(normal_c), _ptr(rough_c), _ptr(axis_c), _ptr(lamb_c),
+                  _ptr(weight_c), _ptr(d), _ptr(v), _ptr(env) if need_env else None, _ptr(lam_t) if tan else None,
+                  _ptr(w_t) if tan else None, _ptr(diffuse), _ptr(spec),
                   bn, K, R, C, eh, ew, h, w, float(F0), int(premap), _stream(dev))
-    return env, diffuse, spec
+    return env, diffuse, spec, lam_t, w_t
 
 
 @fused_render.register_fake
-def _(albedo, normal, rough, axis, lamb, weight, eh, ew, fov, F0, cam, premap, need_env):
+def _(albedo, normal, rough, axis, lamb, weight, eh, ew, fov, F0, cam, premap, need_env, want_tan):
     bn, K, R, C = _check_sg(axis, lamb, weight, None)
     _check_brdf(albedo, normal, rough)
     env = albedo.new_empty((bn, 3, R, C, eh, ew)) if need_env else albedo.new_empty(0)
-    return env, albedo.new_empty((bn, 3, R, C)), albedo.new_empty((bn, 3, R, C))
+    tan = premap and want_tan
+    c = torch.contiguous_format
+    return (env, albedo.new_empty((bn, 3, R, C)), albedo.new_empty((bn, 3, R, C)),
+            torch.empty_like(lamb, memory_format=c) if tan else lamb.new_empty(0),
+            torch.empty_like(weight, memory_format=c) if tan else weight.new_empty(0))
 
 
 @torch.library.custom_op("sgrender::fused_render_bwd_sg", mutates_args=())
 def fused_render_bwd_sg(g_env: Optional[Tensor], g_diffuse: Tensor, g_spec: Tensor, albedo: Tensor, normal: Tensor, rough: Tensor,
                         axis: Tensor, lamb: Tensor, weight: Tensor, eh: int, ew: int, fov: float, F0: float, cam: List[float],
-                        premap: bool) -> Tuple[Tensor, Tensor, Tensor]:
-    """SG gradients of the fused pass; ``g_env`` is the env image's cotangent from its other consumers, if any."""
+                        premap: int) -> Tuple[Tensor, Tensor, Tensor]:
+    """SG gradients of the fused pass; ``g_env`` is the env image's cotangent from its other consumers, if any.
+    ``premap`` as in :func:`sg_to_env_bwd` (2: ``lamb`` / ``weight`` are the post-tan tensors the forward returned)."""
     dev = _require_hip(g_env, g_diffuse, g_spec, albedo, normal, rough, axis, lamb, weight)
     g_env = None if g_env is None else g_env.contiguous()
     g_diffuse, g_spec = g_diffuse.contiguous(), g_spec.contiguous()
@@ -373,18 +390,22 @@ def _(g_env, g_diffuse, g_spec, albedo, normal, rough, axis, lamb, weight, eh, e
 
 
 def _fused_setup(ctx, inputs, output):
-    albedo, normal, rough, axis, lamb, weight, eh, ew, fov, F0, cam, premap, need_env = inputs
+    albedo, normal, rough, axis, lamb, weight, eh, ew, fov, F0, cam, premap, need_env, want_tan = inputs
     env = output[0]
+    mode = int(premap)
+    if premap and want_tan:      # the backward reads the post-tan tensors the forward produced (premap mode 2)
+        lamb, weight, mode = output[3], output[4], 2
     # the env image, when it exists, feeds the BRDF-map gradients (the env-given kernel is faster than re-evaluating the SG)
     if need_env and any(ctx.needs_input_grad[:3]):
         ctx.save_for_backward(albedo, normal, rough, axis, lamb, weight, env)
     else:
         ctx.save_for_backward(albedo, normal, rough, axis, lamb, weight)
-    ctx.cfg = (eh, ew, fov, F0, list(cam), premap)
+    ctx.cfg = (eh, ew, fov, F0, list(cam), mode)
+    ctx.mark_non_differentiable(output[3], output[4])      # internal hand-off to the backward, not part of the layer's interface
     ctx.set_materialize_grads(False)
 
 
-def _fused_backward(ctx, g_env, g_diffuse, g_spec):
+def _fused_backward(ctx, g_env, g_diffuse, g_spec, _g_lam_t=None, _g_w_t=None):
     saved = ctx.saved_tensors
     albedo, normal, rough, axis, lamb, weight = saved[:6]
     env_saved = saved[6] if len(saved) > 6 else None
@@ -392,7 +413,7 @@ def _fused_backward(ctx, g_env, g_diffuse, g_spec):
     if g_env is not None and g_env.numel() == 0:
         g_env = None
     if g_env is None and g_diffuse is None and g_spec is None:
-        return (None,) * 13
+        return (None,) * 14
     bn, R, C = axis.shape[0], axis.shape[3], axis.shape[4]
     zeros = None
     if g_diffuse is None or g_spec is None:
@@ -406,13 +427,13 @@ def _fused_backward(ctx, g_env, g_diffuse, g_spec):
     if any(ctx.needs_input_grad[:3]):
         if env_saved is not None:
             ga, gn, gr = torch.ops.sgrender.render_bwd_brdf(g_diffuse, g_spec, albedo, normal, rough, env_saved, None, None, None,
-                                                             eh, ew, fov, F0, cam, premap)
+                                                             eh, ew, fov, F0, cam, premap == 1)
         else:
             ga, gn, gr = torch.ops.sgrender.render_bwd_brdf(g_diffuse, g_spec, albedo, normal, rough, None, axis, lamb, weight,
-                                                             eh, ew, fov, F0, cam, premap)
+                                                             eh, ew, fov, F0, cam, premap == 1)
         g_alb, g_nrm, g_rgh = (ga if ctx.needs_input_grad[0] else None, gn if ctx.needs_input_grad[1] else None,
                                gr if ctx.needs_input_grad[2] else None)
-    return (g_alb, g_nrm, g_rgh, g_axis, g_lamb, g_weight) + (None,) * 7
+    return (g_alb, g_nrm, g_rgh, g_axis, g_lamb, g_weight) + (None,) * 8
 
 
 fused_render.register_autograd(_fused_backward, setup_context=_fused_setup)

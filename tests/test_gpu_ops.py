@@ -31,14 +31,15 @@ def test_opcheck(sgr):
     x = _inputs()
     cam = [0.0, 0.0, 0.0]
     ops = torch.ops.sgrender
-    torch.library.opcheck(ops.fused_render, (x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], eh, ew, 57.0, 0.05, cam, True, True))
-    torch.library.opcheck(ops.fused_render, (x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], eh, ew, 57.0, 0.05, cam, True, False))
+    torch.library.opcheck(ops.fused_render, (x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], eh, ew, 57.0, 0.05, cam, True, True, True))
+    torch.library.opcheck(ops.fused_render, (x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], eh, ew, 57.0, 0.05, cam, True, False, False))
+    torch.library.opcheck(ops.fused_render, (x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], eh, ew, 57.0, 0.05, cam, False, False, False))
     torch.library.opcheck(ops.sg_to_env, (x["axis"], x["lamb"], x["weight"], eh, ew, True, True))
     env = ops.sg_to_env(x["axis"], x["lamb"], x["weight"], eh, ew, True, False)[0].detach().requires_grad_(True)
     torch.library.opcheck(ops.render_env, (x["albedo"], x["normal"], x["rough"], env, 57.0, 0.05, cam))
     g = torch.randn(bn, 3, R, C, device="cuda")
     torch.library.opcheck(ops.fused_render_bwd_sg, (None, g, g, x["albedo"].detach(), x["normal"].detach(), x["rough"].detach(), x["axis"].detach(),
-                                                    x["lamb"].detach(), x["weight"].detach(), eh, ew, 57.0, 0.05, cam, True))
+                                                    x["lamb"].detach(), x["weight"].detach(), eh, ew, 57.0, 0.05, cam, 1))
 
 
 def test_torch_compile_captures_the_layer(sgr):

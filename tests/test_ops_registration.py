@@ -34,16 +34,19 @@ def test_fake_shapes_forward_and_backward():
     assert tuple(d.shape) == tuple(s.shape) == (bn, 3, R, C)
     g = torch.autograd.grad([d.sum() + s.sum()], [alb, nrm, rgh, axis, lamb, weight])
     assert [tuple(t.shape) for t in g] == [tuple(t.shape) for t in (alb, nrm, rgh, axis, lamb, weight)]
-    env2, d2, s2 = ops.fused_render(alb, nrm, rgh, axis, lamb, weight, eh, ew, 57.0, 0.05, [0.0, 0.0, 0.0], True, True)
+    env2, d2, s2, lt2, wt2 = ops.fused_render(alb, nrm, rgh, axis, lamb, weight, eh, ew, 57.0, 0.05, [0.0, 0.0, 0.0], True, True, True)
     assert tuple(env2.shape) == (bn, 3, R, C, eh, ew) and tuple(d2.shape) == (bn, 3, R, C)
+    assert lt2.shape == lamb.shape and wt2.shape == weight.shape      # the post-tan hand-off to the backward (premap mode 2)
     g2 = torch.autograd.grad([env2.sum() + d2.sum()], [axis, lamb, weight, alb])
     assert [tuple(t.shape) for t in g2] == [tuple(axis.shape), tuple(lamb.shape), tuple(weight.shape), tuple(alb.shape)]
-    env3, d3, _ = ops.fused_render(alb, nrm, rgh, axis, lamb, weight, eh, ew, 57.0, 0.05, [0.0, 0.0, 0.0], True, False)
-    assert env3.numel() == 0 and tuple(d3.shape) == (bn, 3, R, C)
+    env3, d3, _, lt3, _ = ops.fused_render(alb, nrm, rgh, axis, lamb, weight, eh, ew, 57.0, 0.05, [0.0, 0.0, 0.0], True, False, False)
+    assert env3.numel() == 0 and lt3.numel() == 0 and tuple(d3.shape) == (bn, 3, R, C)
+    g3 = torch.autograd.grad([d3.sum()], [axis, lamb, weight])
+    assert [tuple(t.shape) for t in g3] == [tuple(axis.shape), tuple(lamb.shape), tuple(weight.shape)]
 
 
 def test_operators_reject_cpu_tensors():
     z = torch.zeros
     with pytest.raises(RuntimeError, match="no CPU path"):
         torch.ops.sgrender.fused_render(z(1, 3, 2, 2), z(1, 3, 2, 2), z(1, 1, 2, 2), z(1, 2, 3, 2, 2), z(1, 2, 2, 2), z(1, 6, 2, 2),
-                                        2, 4, 57.0, 0.05, [0.0, 0.0, 0.0], True, True)
+                                        2, 4, 57.0, 0.05, [0.0, 0.0, 0.0], True, True, False)
