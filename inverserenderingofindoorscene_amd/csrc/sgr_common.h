@@ -350,18 +350,27 @@ __device__ __forceinline__ void swap32(float& d, float& s) {
 // the flush reads it back with TD/4 lanes per pixel and streams it out
 // TD = directions per pixel row of the tile: 16 (one table row, 64-byte segments) or 32 (two rows, 128-byte segments)
 template <int TD> struct T32Out {
-  static constexpr int kStride = TD + 4;
+  // TD = 16: rows padded by 4 floats (conflict-free as they are).  TD >= 32: unpadded 128-byte rows with the 16-byte slots
+  // XOR-swizzled by (row >> 1) & 7 -- a 16-lane group of the owner's ds_write_b128 (rows r .. r+15, one column) and of the
+  // flush's ds_read_b128 (two rows x eight columns) both touch 16 different slots of the 64 banks -- so that the two-row tile
+  // of the 8x16 grid is 12 KB and three waves per SIMD (twelve per CU) fit the 160 KB of LDS.
+  static constexpr bool kSwz = TD >= 32;
+  static constexpr int kStride = kSwz ? TD : TD + 4;
   static constexpr int kFloats = 3 * kPx * kStride;
   static constexpr int kLanesPerRow = TD / 4;
   static constexpr int kRowsPerIt = kWave / kLanesPerRow;
   static constexpr int kIts = kPx / kRowsPerIt;
+  __device__ static __forceinline__ int col(int row, int c) {      // physical column of logical column c (a multiple of 4) in `row`
+    return kSwz ? ((((c >> 2) ^ ((row >> 1) & 7)) << 2) | (c & ~31)) : c;
+  }
 };
 template <int TD>
 __device__ __forceinline__ void tile32_write4(float* tile, int pl, int col, const float (&e0)[4], const float (&e1)[4], const float (&e2)[4]) {
   using T = T32Out<TD>;
-  *reinterpret_cast<float4*>(tile + (0 * kPx + pl) * T::kStride + col) = make_float4(e0[0], e0[1], e0[2], e0[3]);
-  *reinterpret_cast<float4*>(tile + (1 * kPx + pl) * T::kStride + col) = make_float4(e1[0], e1[1], e1[2], e1[3]);
-  *reinterpret_cast<float4*>(tile + (2 * kPx + pl) * T::kStride + col) = make_float4(e2[0], e2[1], e2[2], e2[3]);
+  const int pc = T::col(pl, col);
+  *reinterpret_cast<float4*>(tile + (0 * kPx + pl) * T::kStride + pc) = make_float4(e0[0], e0[1], e0[2], e0[3]);
+  *reinterpret_cast<float4*>(tile + (1 * kPx + pl) * T::kStride + pc) = make_float4(e1[0], e1[1], e1[2], e1[3]);
+  *reinterpret_cast<float4*>(tile + (2 * kPx + pl) * T::kStride + pc) = make_float4(e2[0], e2[1], e2[2], e2[3]);
 }
 // flush the first `nd` (16 or TD) directions of every pixel row, starting at direction j0 of the image
 template <int TD>
@@ -377,8 +386,10 @@ __device__ __forceinline__ void tile32_store_global(const float* tile, float* __
   for (int c = 0; c < 3; ++c) {
     float4 v[T::kIts];
 #pragma unroll
-    for (int it = 0; it < T::kIts; ++it)
-      v[it] = *reinterpret_cast<const float4*>(tile + (c * kPx + it * T::kRowsPerIt + lrow) * T::kStride + col);
+    for (int it = 0; it < T::kIts; ++it) {
+      const int row = it * T::kRowsPerIt + lrow;
+      v[it] = *reinterpret_cast<const float4*>(tile + (c * kPx + row) * T::kStride + T::col(row, col));
+    }
     float* cbase = env_img + ((size_t)c * RC + p0) * J + j0;   // wave-uniform
 #pragma unroll
     for (int it = 0; it < T::kIts; ++it) {

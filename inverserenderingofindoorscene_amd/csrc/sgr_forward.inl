@@ -185,13 +185,13 @@ static int fwd_pk_launch(const Args& a, hipStream_t st) {
   return (int)hipGetLastError();
 }
 // packed half-wave forward (envWidth 16, 6 < SGNum <= 12), OCC resident waves per SIMD
-template <bool WRITE_ENV, bool DO_RENDER, int OCC, int EW = 16>
+template <bool WRITE_ENV, bool DO_RENDER, int OCC, int EW = 16, int RPF = 1>
 static int fwd_pk_half_launch(const Args& a, hipStream_t st) {
   const dim3 grid((unsigned)(a.bn * ((a.R * a.C + kPx - 1) / kPx))), block(kWave);
   if (!DO_RENDER || (a.imH == a.R && a.imW == a.C))
-    hipLaunchKernelGGL((fwd_pk_half_kernel<1, WRITE_ENV, DO_RENDER, OCC, 6, EW>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((fwd_pk_half_kernel<1, WRITE_ENV, DO_RENDER, OCC, 6, EW, RPF>), grid, block, 0, st, a);
   else
-    hipLaunchKernelGGL((fwd_pk_half_kernel<2, WRITE_ENV, DO_RENDER, OCC, 6, EW>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((fwd_pk_half_kernel<2, WRITE_ENV, DO_RENDER, OCC, 6, EW, RPF>), grid, block, 0, st, a);
   return (int)hipGetLastError();
 }
 // packed half-wave forward with 12 lobes per half: 12 < SGNum <= 24, envWidth 16 or 32 (config 5)
@@ -204,41 +204,6 @@ static int fwd_pk_half24_launch(const Args& a, hipStream_t st) {
     hipLaunchKernelGGL((fwd_pk_half_kernel<2, WRITE_ENV, DO_RENDER, 2, 12, EW>), grid, block, 0, st, a);
   return (int)hipGetLastError();
 }
-// mixed grid (sgr_pk.inl, fwd_pk_mixed_kernel): whole rounds of 64-pixel units, the last partial round as 32-pixel half-wave units.
-// slots = resident one-pixel-per-lane waves on the device (2 per SIMD); SGR_FWD_SLOTS overrides, SGR_FWD_MIXED=0 disables.
-static inline int fwd_wave_slots() {
-  static const int forced = [] { const char* e = getenv("SGR_FWD_SLOTS"); return e ? atoi(e) : 0; }();
-  if (forced > 0) return forced;
-  static int per_device[64] = {0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 2048;
-  if (per_device[dev] == 0) {
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    per_device[dev] = cus * 4 * 2;
-  }
-  return per_device[dev];
-}
-static inline bool fwd_mixed_enabled() {
-  static const bool on = [] { const char* e = getenv("SGR_FWD_MIXED"); return !(e && atoi(e) == 0); }();
-  return on;
-}
-// number of leading 64-pixel units that run one pixel per lane; the rest are split.  The tail is split only when it fills at
-// most half of the slots (twice as many half-length waves then still fit one round); a fuller last round is left alone.
-static inline int fwd_mixed_nfull(int units) {
-  const int slots = fwd_wave_slots();
-  const int tail = units % slots;
-  return (tail != 0 && 2 * tail <= slots) ? units - tail : units;
-}
-template <int UNUSED = 0>      // a template so that only translation units that launch it instantiate the kernels
-static int fwd_pk_mixed_launch(const Args& a, hipStream_t st, int nfull) {
-  const int units = (int)wave_grid(a.bn, a.R, a.C).x;
-  const dim3 grid((unsigned)(nfull + 2 * (units - nfull))), block(kWave);
-  if (a.imH == a.R && a.imW == a.C) hipLaunchKernelGGL((fwd_pk_mixed_kernel<1>), grid, block, 0, st, a, nfull);
-  else hipLaunchKernelGGL((fwd_pk_mixed_kernel<2>), grid, block, 0, st, a, nfull);
-  return (int)hipGetLastError();
-}
-
 static inline int fwd_mode() {     // 4 packed (default; 7: one pixel per lane always, 5 / 6: half-wave always), 0 scalar one pixel per lane, 2 / 3 scalar half-wave kernel, -1 round-1 default
   static const int mode = [] {
     const char* e = getenv("SGR_FWD_MODE");
@@ -246,6 +211,8 @@ static inline int fwd_mode() {     // 4 packed (default; 7: one pixel per lane a
     if (!strcmp(e, "pk")) return 7;      // packed, one pixel per lane for every forward variant
     if (e && !strcmp(e, "pkhalf2")) return 5;
     if (e && !strcmp(e, "pkhalf3")) return 6;
+    if (e && !strcmp(e, "pkhalf2w")) return 8;     // half-wave, two table rows per env flush (128-byte segments), 2 / 3 waves per SIMD
+    if (e && !strcmp(e, "pkhalf3w")) return 9;
     if (e && !strcmp(e, "scalar")) return -1;
     if (e && !strcmp(e, "full")) return 0;
     if (e && !strcmp(e, "half2")) return 2;
@@ -263,17 +230,19 @@ static int fwd_fast_launch(const Args& a, hipStream_t st) {
     return a.ew == 16 ? fwd_pk_half24_launch<WRITE_ENV, DO_RENDER, 16>(a, st) : fwd_pk_half24_launch<WRITE_ENV, DO_RENDER, 32>(a, st);
   if (fwd_mode() >= 4 && a.ew == 32 && a.K > 6 && a.K <= 12)      // 16x32 grid, up to 12 lobes: six per half-wave, packed
     return fwd_pk_half_launch<WRITE_ENV, DO_RENDER, 3, 32>(a, st);
-  // packed kernels, measured at config 2 (kbench / bench loop): env + render: one pixel per lane 166-180 / 152 us, half-wave at 3
-  // waves per SIMD 177 / 147 us (and the backward behind it 5 us slower: a wash) -> one pixel per lane; env only
-  // (output2env.output2env alone): 172 vs 154 us -> half-wave; render only: 142 vs 150 us -> one pixel per lane
-  if (a.ew == 16 && a.K > 6 && a.K <= 12 && (fwd_mode() >= 5 || (fwd_mode() == 4 && WRITE_ENV && !DO_RENDER)))
-    return fwd_mode() == 5 ? fwd_pk_half_launch<WRITE_ENV, DO_RENDER, 2>(a, st) : fwd_pk_half_launch<WRITE_ENV, DO_RENDER, 3>(a, st);
-  if constexpr (WRITE_ENV && DO_RENDER) {
-    if (fwd_mode() == 4 && a.ew == 16 && a.K > 6 && a.K <= 12 && fwd_mixed_enabled()) {
-      const int units = (int)wave_grid(a.bn, a.R, a.C).x, nfull = fwd_mixed_nfull(units);
-      if (nfull < units) return fwd_pk_mixed_launch<>(a, st, nfull);
-    }
+  // packed kernels at 7..12 lobes on the 8x16 grid.  Round 3, measured in the bench loop (the only place where the working set
+  // cycles through HBM; relaunched on warm buffers the env stores land in the Infinity Cache): once the env image is written the
+  // forward is bound by the WRITE path, and 64-byte segments (one table row per pixel and colour) write at ~3 TB/s where whole
+  // 128-byte lines reach ~5 (profiles/r02b_storebench*).  The half-wave kernel's 32-pixel tile holds two table rows in 12 KB --
+  // three waves per SIMD still fit -- so it is the default whenever the env image is written: forward per image 9.2 us at
+  // batch 16 (one pixel per lane, 64-byte segments: 9.2), 9.0 against 10.7-11.3 at batch 32-64 (profiles/r03c_fwd_mode_sweep.txt).
+  // Render only (no env image): one pixel per lane.  SGR_FWD_MODE = pk | pkhalf2 | pkhalf3 | pkhalf2w | pkhalf3w forces one form.
+  if constexpr (WRITE_ENV) {
+    if (a.ew == 16 && a.K > 6 && a.K <= 12 && (fwd_mode() == 4 || fwd_mode() >= 8))
+      return fwd_mode() == 8 ? fwd_pk_half_launch<WRITE_ENV, DO_RENDER, 2, 16, 2>(a, st) : fwd_pk_half_launch<WRITE_ENV, DO_RENDER, 3, 16, 2>(a, st);
   }
+  if (a.ew == 16 && a.K > 6 && a.K <= 12 && (fwd_mode() == 5 || fwd_mode() == 6 || fwd_mode() >= 8))
+    return fwd_mode() == 5 || fwd_mode() == 8 ? fwd_pk_half_launch<WRITE_ENV, DO_RENDER, 2>(a, st) : fwd_pk_half_launch<WRITE_ENV, DO_RENDER, 3>(a, st);
   if (fwd_mode() >= 4 && a.ew == 16 && a.K <= 12)
     return a.K <= 6 ? fwd_pk_launch<6, WRITE_ENV, DO_RENDER>(a, st) : fwd_pk_launch<12, WRITE_ENV, DO_RENDER>(a, st);
   const int mode = (fwd_mode() >= 0 && fwd_mode() < 4) ? fwd_mode() : (WRITE_ENV ? 2 : 0);

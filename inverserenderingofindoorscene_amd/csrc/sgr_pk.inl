@@ -75,18 +75,6 @@ __device__ __forceinline__ Pix locate_unit(const Args& a, int u) {
   x.p = x.active ? (x.p0 + x.lane) : (RC - 1);
   return x;
 }
-// half `h` (pixels 32 h .. 32 h + 31) of the 64-pixel unit `u`, as a half-wave kernel's 32-pixel group
-__device__ __forceinline__ Pix locate_half_of_unit(const Args& a, int u, int h) {
-  Pix x;
-  x.lane = threadIdx.x;
-  const int RC = a.R * a.C, tiles = (RC + kWave - 1) / kWave, pl = x.lane & 31;
-  x.b = u / tiles;
-  x.p0 = (u - x.b * tiles) * kWave + h * kPx;
-  x.active = (x.p0 + pl) < RC;
-  x.p = x.active ? (x.p0 + pl) : (RC - 1);
-  return x;
-}
-
 // SG parameters of the lane's pixel in register pairs (KP even; lobes past K carry zero weights).
 // FOLD: axis pre-multiplied by lp = lam * log2e (forward and sg_bwd_pk_kernel); unit axes otherwise (objective backward).
 // The backward divides its sharpness gradient by lp again (see there), so a |lp| below kLpFloor = 2^-40 -- lam == 0 is
@@ -472,9 +460,12 @@ __global__ __launch_bounds__(kWave, 2) void fwd_pk_kernel(const Args a) {
 // KPW = 12, EW = 32 (OCC 2): SGNum up to 24 on the 16x32 grid of BASELINE config 5 -- the one-pixel-per-lane kernels would
 // need 24 lobes per lane there and spill.
 // `x` = the 32-pixel group of this wave (locate_group32 / locate_half_of_unit); `tile` = T32Out<EW>::kFloats floats of LDS when WRITE_ENV
-template <int POOL, bool WRITE_ENV, bool DO_RENDER, int KPW, int EW>
+// RPF = table rows per flush of the env tile: 1 = one row (EW floats per pixel and colour: 64-byte segments at EW 16), 2 = two
+// rows (128-byte segments = whole cache lines: the env stores are what bounds the forward once the working set cycles
+// through HBM, and 64-byte segments write at ~3.4 TB/s where 128-byte ones reach ~5, profiles/r02b_storebench*)
+template <int POOL, bool WRITE_ENV, bool DO_RENDER, int KPW, int EW, int RPF = 1>
 __device__ __forceinline__ void fwd_pk_half_body(const Args& a, const Pix x, float* tile) {
-  constexpr int HALF = EW / 2, NQ = HALF / 4, TD = EW;
+  constexpr int HALF = EW / 2, NQ = HALF / 4, TD = EW * RPF;
   SGR_TRACE_BEGIN
 
   const int lane = threadIdx.x, half = lane >> 5, pl = lane & 31;
@@ -574,12 +565,12 @@ __device__ __forceinline__ void fwd_pk_half_body(const Args& a, const Pix x, flo
           const float e0[4] = {tot[0][0].x, tot[0][0].y, tot[0][1].x, tot[0][1].y};
           const float e1[4] = {tot[1][0].x, tot[1][0].y, tot[1][1].x, tot[1][1].y};
           const float e2[4] = {tot[2][0].x, tot[2][0].y, tot[2][1].x, tot[2][1].y};
-          tile32_write4<TD>(tile, pl, own * HALF + aq * 4, e0, e1, e2);
+          tile32_write4<TD>(tile, pl, (e % RPF) * EW + own * HALF + aq * 4, e0, e1, e2);
         }
       }
-      if (WRITE_ENV) {
+      if (WRITE_ENV && ((e + 1) % RPF == 0 || e + 1 == eh)) {
         __syncthreads();
-        tile32_store_global<TD>(tile, a.env_out + img, x.p0, RC, a.J, e * EW, EW, lane);
+        tile32_store_global<TD>(tile, a.env_out + img, x.p0, RC, a.J, (e / RPF) * TD, (e % RPF + 1) * EW, lane);
         __syncthreads();
       }
     }
@@ -608,30 +599,10 @@ __device__ __forceinline__ void fwd_pk_half_body(const Args& a, const Pix x, flo
   }
   SGR_TRACE_END
 }
-template <int POOL, bool WRITE_ENV, bool DO_RENDER, int OCC, int KPW = 6, int EW = 16>
+template <int POOL, bool WRITE_ENV, bool DO_RENDER, int OCC, int KPW = 6, int EW = 16, int RPF = 1>
 __global__ __launch_bounds__(kWave, OCC) void fwd_pk_half_kernel(const Args a) {
-  __shared__ __attribute__((aligned(16))) float tile[WRITE_ENV ? T32Out<EW>::kFloats : 4];
-  fwd_pk_half_body<POOL, WRITE_ENV, DO_RENDER, KPW, EW>(a, locate_group32(a, (int)blockIdx.x), tile);
-}
-
-// ============================== forward, mixed grid: whole rounds one pixel per lane, the last partial round half-wave ==========
-// The one-pixel-per-lane kernel runs two waves per SIMD; a launch whose last round fills at most half of the slots leaves those
-// SIMDs with one wave each (which issues only ~55 % of the time on its own) for a whole unit's duration: 20 % of the kernel at
-// 16 images (4800 units on 2048 slots).  Here the first `nfull` 64-pixel units -- whole rounds -- run fwd_pk_body, and each of the
-// remaining units is launched as two 32-pixel half-wave units (fwd_pk_half_body: six lobes per lane, half the work per wave,
-// 12 % more instructions for the exchange), twice as many waves of about half the duration.  Workgroups are dispatched in
-// id order, so the short units are the last ones to start.  One LDS allocation serves both paths.
-template <int POOL>
-__global__ __launch_bounds__(kWave, 2) void fwd_pk_mixed_kernel(const Args a, const int nfull) {
-  __shared__ __attribute__((aligned(16))) float tile[Tile<SGR_PK_TJ>::kFloats];
-  static_assert(Tile<SGR_PK_TJ>::kFloats >= T32Out<16>::kFloats, "the half-wave tile lives in the same allocation");
-  const int id = (int)blockIdx.x;
-  if (id < nfull) {
-    fwd_pk_body<12, POOL, true, true, false>(a, id, tile, nullptr);
-  } else {
-    const int i = id - nfull;
-    fwd_pk_half_body<POOL, true, true, 6, 16>(a, locate_half_of_unit(a, nfull + (i >> 1), i & 1), tile);
-  }
+  __shared__ __attribute__((aligned(16))) float tile[WRITE_ENV ? T32Out<EW * RPF>::kFloats : 4];
+  fwd_pk_half_body<POOL, WRITE_ENV, DO_RENDER, KPW, EW, RPF>(a, locate_group32(a, (int)blockIdx.x), tile);
 }
 
 
@@ -791,14 +762,24 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
           const f32x2 Pv = pfma(SGR_HI(oq.vB), sa, SGR_LO(oq.vB) * ca);
           f32x2 wt, sp;
           shade_pair<ORTHO>(q, oq, rc, orow, own, ca, sa, Pv, xt, (aoff + ap) * 2, wt, sp);
+          // what travels between the halves is the specular term alone (2 swaps; the weight as well for degenerate frames,
+          // where it depends on the direction): the cotangent  wt (gD A/pi + gS spec)  of both half rows is then formed by
+          // every lane -- 12 packed instructions either way, four (two) v_permlane32_swap fewer than trading the six products
+          float dx = sp.x, sx = sp.x, dy = sp.y, sy = sp.y;
+          swap32(dx, sx);
+          swap32(dy, sy);
+          const f32x2 sp1 = {dx, dy}, sp0 = {sx, sy};      // half row 1: evaluated by lanes 0..31; half row 0: by lanes 32..63
+          f32x2 wt1 = wt, wt0 = wt;
+          if (!ORTHO) {
+            float ux = wt.x, vx = wt.x, uy = wt.y, vy = wt.y;
+            swap32(ux, vx);
+            swap32(uy, vy);
+            wt1 = f32x2{ux, uy}; wt0 = f32x2{vx, vy};
+          }
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            const f32x2 r_ = wt * pfma(SGR_HI(gds[c]), sp, SGR_LO(gds[c]));
-            float dx = r_.x, sx = r_.x, dy = r_.y, sy = r_.y;
-            swap32(dx, sx);
-            swap32(dy, sy);
-            g[1][c] += f32x2{dx, dy};     // evaluated by lanes 0..31
-            g[0][c] += f32x2{sx, sy};     // evaluated by lanes 32..63
+            g[1][c] = pfma(wt1, pfma(SGR_HI(gds[c]), sp1, SGR_LO(gds[c])), g[1][c]);
+            g[0][c] = pfma(wt0, pfma(SGR_HI(gds[c]), sp0, SGR_LO(gds[c])), g[0][c]);
           }
         }
         const f32x2 srv = splat2(sr);

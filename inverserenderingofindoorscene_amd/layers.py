@@ -122,7 +122,7 @@ class renderingLayer:
         _require_hip(diffusePred, normalPred, roughPred, axisOrig, lambOrig, weightOrig)
         a, n, r = _prepool(diffusePred, normalPred, roughPred, R, C)
         # the post-tan sharpness / intensity leave the forward kernel only when a backward will read them
-        want_tan = bool(premap) and torch.is_grad_enabled() and (axisOrig.requires_grad or lambOrig.requires_grad or weightOrig.requires_grad)
+        want_tan = bool(premap) and ops.tan_handoff() and torch.is_grad_enabled() and (axisOrig.requires_grad or lambOrig.requires_grad or weightOrig.requires_grad)
         env, d, s, _, _ = torch.ops.sgrender.fused_render(a, n, r, axisOrig, lambOrig, weightOrig, self.envHeight, self.envWidth,
                                                           self.fov_deg, float(self.F0), list(self._cam), bool(premap), bool(need_env), want_tan)
         return (env if need_env else None), d, s

@@ -23,6 +23,7 @@ import torch.distributed as dist
 import torch.nn.functional as F
 
 from . import _lib
+from . import ops as _ops
 from .layers import _check_brdf, _check_sg, _dirs, _prepool, _ptr, _require_hip, _stream, _view
 
 __all__ = ["LSregress", "LSregressDiffSpec", "render_loss", "recon_loss", "combine_loss_parts", "light_objective",
@@ -308,7 +309,9 @@ class _LightObjective(torch.autograd.Function):
         ws = torch.empty(lib.sgr_fused_recon_workspace_floats(bn, R, C), **f32)
         ws_r = _workspace(bn, dev)
         g_axis, g_lamb, g_weight = torch.empty_like(axis_c), torch.empty_like(lamb_c), torch.empty_like(weight_c)
-        lam_t, w_t = torch.empty_like(lamb_c), torch.empty_like(weight_c)      # post-tan values: written by the forward pass, read by the backward pass
+        handoff = _ops.tan_handoff()
+        # post-tan values: written by the forward pass, read by the backward pass (premap mode 2)
+        lam_t, w_t = (torch.empty_like(lamb_c), torch.empty_like(weight_c)) if handoff else (lamb_c, weight_c)
         d, v = _dirs(dev, eh, ew), _view(dev, R, C, fov, cam)
         st = _stream(dev)
         sg_args = (_ptr(albedo_c), _ptr(normal_c), _ptr(rough_c), _ptr(axis_c), _ptr(lamb_c), _ptr(weight_c), _ptr(d), _ptr(v))
@@ -319,7 +322,8 @@ class _LightObjective(torch.autograd.Function):
                 seg_small = seg_c
             else:
                 seg_small = F.avg_pool2d(seg_c, 2)
-            _lib.call("sgr_fused_fwd_recon_tan", *sg_args, _ptr(gt), _ptr(seg_small), _ptr(ind), _ptr(lam_t), _ptr(w_t), _ptr(diffuse),
+            _lib.call("sgr_fused_fwd_recon_tan", *sg_args, _ptr(gt), _ptr(seg_small), _ptr(ind), _ptr(lam_t) if handoff else None,
+                      _ptr(w_t) if handoff else None, _ptr(diffuse),
                       _ptr(spec), _ptr(mask), _ptr(coef), _ptr(parts_f), _ptr(ws), bn, K, R, C, eh, ew, h, w, float(F0), 1, st)
             _lib.call("sgr_render_loss_fwd", _ptr(diffuse), _ptr(spec), _ptr(im_c), _ptr(seg_c), _ptr(im_s), _ptr(seg_s),
                       _ptr(rendered), _ptr(coef_ds), _ptr(parts_r), _ptr(ws_r), bn, R, C, imH, imW, st)
@@ -331,7 +335,7 @@ class _LightObjective(torch.autograd.Function):
             den_e_c = den_e.reshape(1).contiguous() if sharded else None
             _lib.call("sgr_fused_bwd_recon", *sg_args_tan, _ptr(gt), _ptr(mask), _ptr(coef), _ptr(den_e_c), _ptr(g_d), _ptr(g_s),
                       _ptr(g_axis), _ptr(g_lamb), _ptr(g_weight), _ptr(parts_b), _ptr(ws),
-                      bn, K, R, C, eh, ew, h, w, float(F0), 2, float(offset), float(rec_w), st)
+                      bn, K, R, C, eh, ew, h, w, float(F0), 2 if handoff else 1, float(offset), float(rec_w), st)
             num_r, num_e, _ = _global_pair(parts_r[0], parts_b[0], group)
         render_err = num_r / torch.clamp(den_r, min=1e-5) / 3.0
         recon_err = num_e / torch.clamp(den_e, min=1e-5) / (3.0 * eh * ew)

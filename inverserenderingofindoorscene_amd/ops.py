@@ -117,6 +117,17 @@ def _check_brdf(albedo, normal, rough):
     return bn, h, w
 
 
+def tan_handoff() -> bool:
+    """Whether the fused forward passes hand the post-tan sharpness / intensity to their backward (premap mode 2) instead
+    of the backward re-evaluating the pre-map.  ``SGR_TAN_HANDOFF=0|1`` overrides the default (read per call: a tuning knob)."""
+    import os
+    v = os.environ.get("SGR_TAN_HANDOFF")
+    return _TAN_HANDOFF_DEFAULT if v is None else v not in ("0", "")
+
+
+_TAN_HANDOFF_DEFAULT = False     # measured at config 2: +45 us of stores in the (write-bound) forward for -12 us in the backward
+
+
 def _none(t: Tensor) -> Optional[Tensor]:
     """Operators return tensors only: an output that was not asked for is an empty tensor."""
     return None if t.numel() == 0 else t

@@ -46,6 +46,9 @@ int main(int argc, char** argv) {
   SYM(sgr_sg_to_env_fwd) SYM(sgr_render_env_fwd) SYM(sgr_fused_fwd) SYM(sgr_sg_to_env_bwd) SYM(sgr_fused_bwd_sg)
   SYM(sgr_render_env_bwd_env) SYM(sgr_render_bwd_brdf) SYM(sgr_render_loss_fwd) SYM(sgr_render_loss_bwd) SYM(sgr_loss_workspace_floats)
   SYM(sgr_fused_fwd_recon) SYM(sgr_fused_bwd_recon) SYM(sgr_fused_recon_workspace_floats) SYM(sgr_recon_loss_fwd) SYM(sgr_recon_loss_bwd) SYM(sgr_recon_workspace_floats)
+  // round-3 entry points (absent from older builds of the library: their lines are skipped then)
+  auto sgr_fused_fwd_tan_p = (decltype(&sgr_fused_fwd_tan))dlsym(lib, "sgr_fused_fwd_tan");
+  auto sgr_fused_fwd_recon_tan_p = (decltype(&sgr_fused_fwd_recon_tan))dlsym(lib, "sgr_fused_fwd_recon_tan");
   const int K = argc > 4 ? atoi(argv[4]) : 12;
   const int imH = 240, imW = 320, R = 120, C = 160, eh = 8, ew = 16, J = eh * ew, q = 4;
   const size_t RC = (size_t)R * C, P = (size_t)bn * RC;
@@ -108,10 +111,14 @@ int main(int argc, char** argv) {
   };
   printf("# %s  bn=%d  K=%d  P=%zu shaded px  reps=%d  SGR_GENERIC=%s  %s\n", libpath, bn, K, P, reps, getenv("SGR_GENERIC") ? "1" : "0", cold ? "COLD (1 GB memset between launches)" : "warm (same buffers relaunched)");
   bench("sgr_fused_fwd (env written)", Bbrdf + Bsg + Benv + Bout, [&] { return sgr_fused_fwd_p(albedo, normal, rough, axis, lamb, weight, dirs, view, env, diffuse, spec, bn, K, R, C, eh, ew, imH, imW, F0d, 1, st); });
+  if (sgr_fused_fwd_tan_p)
+    bench("sgr_fused_fwd_tan (env + tan)", Bbrdf + Bsg + Benv + Bout + Bsg * 4.0 / 7.0, [&] { return sgr_fused_fwd_tan_p(albedo, normal, rough, axis, lamb, weight, dirs, view, env, lam_t, w_t, diffuse, spec, bn, K, R, C, eh, ew, imH, imW, F0d, 1, st); });
   bench("sgr_fused_fwd (render only)", Bbrdf + Bsg + Bout, [&] { return sgr_fused_fwd_p(albedo, normal, rough, axis, lamb, weight, dirs, view, (float*)nullptr, diffuse, spec, bn, K, R, C, eh, ew, imH, imW, F0d, 1, st); });
   bench("sgr_sg_to_env_fwd (+tan outputs)", Bsg + Benv + Bsg * 4.0 / 7.0, [&] { return sgr_sg_to_env_fwd_p(axis, lamb, weight, dirs, env, lam_t, w_t, bn, K, R, C, eh, ew, 1, st); });
   bench("sgr_render_env_fwd", Bbrdf + Benv + Bout, [&] { return sgr_render_env_fwd_p(albedo, normal, rough, env, dirs, view, diffuse, spec, bn, R, C, eh, ew, imH, imW, F0d, st); });
   bench("sgr_fused_bwd_sg (g_env + gD,gS)", Bbrdf + Bsg + Bout + Benv + Bsg, [&] { return sgr_fused_bwd_sg_p(g_env, g_d, g_s, albedo, normal, rough, axis, lamb, weight, dirs, view, g_axis, g_lamb, g_weight, bn, K, R, C, eh, ew, imH, imW, F0d, 1, st); });
+  if (sgr_fused_fwd_tan_p)
+    bench("sgr_fused_bwd_sg (premap 2: tan read)", Bbrdf + Bsg + Bout + Benv + Bsg, [&] { return sgr_fused_bwd_sg_p(g_env, g_d, g_s, albedo, normal, rough, axis, lam_t, w_t, dirs, view, g_axis, g_lamb, g_weight, bn, K, R, C, eh, ew, imH, imW, F0d, 2, st); });
   bench("sgr_fused_bwd_sg (gD,gS only)", Bbrdf + Bsg + Bout + Bsg, [&] { return sgr_fused_bwd_sg_p((float*)nullptr, g_d, g_s, albedo, normal, rough, axis, lamb, weight, dirs, view, g_axis, g_lamb, g_weight, bn, K, R, C, eh, ew, imH, imW, F0d, 1, st); });
   bench("sgr_sg_to_env_bwd", Bsg + Benv + Bsg, [&] { return sgr_sg_to_env_bwd_p(g_env, axis, lamb, weight, dirs, g_axis, g_lamb, g_weight, bn, K, R, C, eh, ew, 1, st); });
   bench("sgr_render_env_bwd_env", Bbrdf + Bout + Benv, [&] { return sgr_render_env_bwd_env_p(g_d, g_s, albedo, normal, rough, dirs, view, env, bn, R, C, eh, ew, imH, imW, F0d, st); });
@@ -126,6 +133,10 @@ int main(int argc, char** argv) {
   bench("sgr_recon_loss_fwd (2 passes)", 4 * Benv, [&] { return sgr_recon_loss_fwd_p(env, env_gt, seg_s, ind, mask, rcoef, rparts, rws, bn, R, C, eh, ew, 1.0f, st); });
   bench("sgr_recon_loss_bwd", 3 * Benv, [&] { return sgr_recon_loss_bwd_p(g_num, env, env_gt, mask, rcoef, g_env, bn, R, C, eh, ew, 1.0f, st); });
   bench("sgr_fused_fwd_recon", Bbrdf + Bsg + Benv + Bout, [&] { return sgr_fused_fwd_recon_p(albedo, normal, rough, axis, lamb, weight, dirs, view, env_gt, seg_s, ind, diffuse, spec, mask, rcoef, rparts, fws, bn, K, R, C, eh, ew, imH, imW, F0d, 1, st); });
+  if (sgr_fused_fwd_recon_tan_p) {
+    bench("sgr_fused_fwd_recon_tan", Bbrdf + Bsg + Benv + Bout + Bsg * 4.0 / 7.0, [&] { return sgr_fused_fwd_recon_tan_p(albedo, normal, rough, axis, lamb, weight, dirs, view, env_gt, seg_s, ind, lam_t, w_t, diffuse, spec, mask, rcoef, rparts, fws, bn, K, R, C, eh, ew, imH, imW, F0d, 1, st); });
+    bench("sgr_fused_bwd_recon (premap 2)", Bbrdf + Bsg + Bout + Benv + Bsg, [&] { return sgr_fused_bwd_recon_p(albedo, normal, rough, axis, lam_t, w_t, dirs, view, env_gt, mask, rcoef, (float*)nullptr, g_d, g_s, g_axis, g_lamb, g_weight, rparts, fws, bn, K, R, C, eh, ew, imH, imW, F0d, 2, 1.0f, 10.0f, st); });
+  }
   bench("sgr_fused_bwd_recon", Bbrdf + Bsg + Bout + Benv + Bsg, [&] { return sgr_fused_bwd_recon_p(albedo, normal, rough, axis, lamb, weight, dirs, view, env_gt, mask, rcoef, (float*)nullptr, g_d, g_s, g_axis, g_lamb, g_weight, rparts, fws, bn, K, R, C, eh, ew, imH, imW, F0d, 1, 1.0f, 10.0f, st); });
   return 0;
 }
