@@ -42,7 +42,7 @@ def main():
         blob[f"{tag}_env"] = r["env"].detach()[:, :, ::S_ENV, ::S_ENV].numpy().astype(np.float32)
         blob[f"{tag}_diffuse"] = r["diffuse"].detach().numpy().astype(np.float32)
         blob[f"{tag}_spec"] = r["spec"].detach().numpy().astype(np.float32)
-        for k in ("axis", "lamb", "weight"):
+        for k in ("axis", "lamb", "weight", "albedo", "normal", "rough"):      # the BRDF-map gradients too (round 3): a10 at size
             g = r[f"glin_{k}"].detach()
             blob[f"{tag}_glin_{k}"] = g[..., ::S_SG, ::S_SG].numpy().astype(np.float32)
             blob[f"{tag}_glin_{k}_norm"] = np.array([g.double().norm().item()])
@@ -50,7 +50,7 @@ def main():
     path = os.path.join(OUT, "g7_cfg2_one_image.npz")
     np.savez_compressed(path, **blob)
     print("wrote", path, f"{os.path.getsize(path) / 1e6:.2f} MB")
-    for k in ("env", "diffuse", "spec", "glin_axis", "glin_lamb", "glin_weight"):
+    for k in ("env", "diffuse", "spec", "glin_axis", "glin_lamb", "glin_weight", "glin_albedo", "glin_normal", "glin_rough"):
         a, b = torch.from_numpy(blob["ref32_" + k]).double(), torch.from_numpy(blob["ref64_" + k]).double()
         print(f"  reference fp32 vs fp64 {k:12s} rel-L2 {((a - b).norm() / b.norm()).item():.2e}")
 

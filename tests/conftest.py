@@ -41,3 +41,41 @@ def rel_max(a, b):
 @pytest.fixture(params=GOLDEN_CASES)
 def golden(request):
     return (request.param,) + load_golden(request.param)
+
+
+# --------------------------------------------------------------------------- #
+# the oracle as arbiter AND as yardstick (GPU tests)                            #
+# --------------------------------------------------------------------------- #
+NAMES6 = ("albedo", "normal", "rough", "axis", "lamb", "weight")
+
+
+def oracle_fwd_bwd(O, inp, cts, eh, ew, wrt, dtype, device, b=None, fov=57.0, F0=0.05):
+    """``oracle.render_from_sg`` forward + gradients of ``<env,ct_env> + <diffuse,ct_d> + <spec,ct_s>`` w.r.t. ``wrt``,
+    evaluated in ``dtype`` on ``device`` -- fp64 ON THE GPU for whole images at BASELINE sizes (the restatement is
+    device-generic torch; an image of config 2 takes about a second there instead of twenty on the host).  ``b``: one image of
+    the batch.  Returns ``dict(env, diffuse, spec, g_<name>...)`` of detached tensors on ``device``."""
+    sl = (lambda t: t) if b is None else (lambda t: t[b:b + 1])
+    x = {k: sl(inp[k]).to(device=device, dtype=dtype).clone().requires_grad_(k in wrt) for k in NAMES6}
+    env, d, s = O.render_from_sg(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], eh, ew, fov, F0)
+    ct = [sl(c).to(device=device, dtype=dtype) for c in cts]
+    grads = torch.autograd.grad([env, d, s], [x[k] for k in wrt], grad_outputs=ct)
+    out = dict(env=env.detach(), diffuse=d.detach(), spec=s.detach())
+    out.update({f"g_{k}": g for k, g in zip(wrt, grads)})
+    return out
+
+
+def oracle_with_noise(O, inp, cts, eh, ew, wrt, device, b=None, fov=57.0, F0=0.05):
+    """``(ref64, ref32, e32)``: the oracle in fp64 (the arbiter), in fp32, and the rel-L2 distance between the two per output --
+    the fp32 rounding noise of the reference's ALGORITHM on these inputs.  Where no reference-made fixture supplies the
+    reference's own fp32-vs-fp64 error (g1..g3, g7, g8 do), this is the ``e_ref`` of BASELINE.md section 3's tolerance
+    ``max(2 e_ref, 1e-4)``: a restatement's noise, i.e. a proxy -- the two agree to within a factor ~1.5 where both exist."""
+    r64 = oracle_fwd_bwd(O, inp, cts, eh, ew, wrt, torch.float64, device, b, fov, F0)
+    r32 = oracle_fwd_bwd(O, inp, cts, eh, ew, wrt, torch.float32, device, b, fov, F0)
+    e32 = {k: rel_l2(r32[k], r64[k]) for k in r64}
+    return r64, r32, e32
+
+
+def tol2(e_ref, floor=1e-4):
+    """BASELINE.md section 3 / north_star: no worse than twice the reference's own fp32 error, floored at the 1e-4 the
+    contract names."""
+    return max(2.0 * e_ref, floor)

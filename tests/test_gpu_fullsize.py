@@ -1,26 +1,26 @@
-"""GPU: parity AT SIZE.  BASELINE config 2 (batch 16, 240x320 -> 120x160, SGNum 12, 8x16) swept over all sixteen images,
-forward and backward, against the fp64 oracle; one image against the reference-made fixture g7_cfg2_one_image.npz
-(oracle/make_golden_fullsize.py: the unmodified reference in fp32 and fp64), which supplies the reference's own fp32 error
-as the yardstick -- tolerance max(2 x e_ref, 1e-4) instead of a bare constant; one full image of config 5 (480x640 ->
-240x320, SGNum 24, 16x32); and a fixed-seed randomised shape sweep (the former tools/fuzz_parity.py).
+"""GPU: parity AT SIZE, whole images.  BASELINE config 2 (batch 16, 240x320 -> 120x160, SGNum 12, 8x16): ALL sixteen images,
+every env cell, forward and backward w.r.t. the SG parameters AND the BRDF maps, against the fp64 oracle; one image against the
+reference-made fixture g7_cfg2_one_image.npz (oracle/make_golden_fullsize.py: the unmodified reference in fp32 and fp64), which
+supplies the reference's own fp32 error e_ref as the yardstick; one full image of config 5 (480x640 -> 240x320, SGNum 24,
+16x32) with e_ref from the reference-made fixture g8_cfg5_small.npz (oracle/make_golden_cfg5.py), which is also compared
+against directly; and a fixed-seed randomised shape sweep.  Every tolerance is ``max(2 e_ref, 1e-4)`` (BASELINE.md section 3 /
+north_star), capped at 2e-4 for the normal / roughness gradients, whose reference fp32 evaluation is itself only good to 1e-3
+at size (the adjoint here evaluates the GGX denominator without the reference's cancellation, sgr_math.h: brdf_dir_bwd).
 
-The GPU always runs the full batch.  The fp64 oracle is evaluated on one WINDOW of every image (a quarter of the env grid,
-a different quadrant from image to image; every operation of the path is per env cell, so a window of the full result is
-the result of the window -- oracle.render_env(window=...); config 5: one sixteenth of its single image): about 40 s of
-host time instead of 6 minutes.  SGR_FULL_SWEEP=1
-evaluates whole images (the log of such a run is committed under profiles/)."""
+The GPU runs the full batch through the HIP kernels; the fp64 oracle (device-generic torch) is evaluated ON THE GPU as well, image
+by image: about a second per image of config 2 instead of twenty on the host, so nothing is windowed any more."""
 import os
 
 import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN_DIR, rel_l2, rel_max
+from conftest import GOLDEN_DIR, NAMES6, oracle_fwd_bwd, oracle_with_noise, rel_l2, rel_max, tol2
 
 pytestmark = pytest.mark.gpu
-FULL_SWEEP = os.environ.get("SGR_FULL_SWEEP", "0") not in ("", "0")
-NAMES = ("albedo", "normal", "rough", "axis", "lamb", "weight")
+NAMES = NAMES6
 SG = ("axis", "lamb", "weight")
+BRDF = ("albedo", "normal", "rough")
 
 
 @pytest.fixture(scope="module")
@@ -31,49 +31,50 @@ def sgr():
     return pkg
 
 
-@pytest.fixture(scope="module")
-def g7():
-    z = np.load(os.path.join(GOLDEN_DIR, "g7_cfg2_one_image.npz"))
+def _fixture_with_eref(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name))
     cfg = {k: v for k, v in zip(z["cfg_keys"].tolist(), z["cfg_vals"].tolist())}
     for k in ("bn", "imH", "imW", "R", "C", "K", "eh", "ew", "seed"):
         cfg[k] = int(cfg[k])
-    e_ref = {k: rel_l2(z["ref32_" + k], z["ref64_" + k]) for k in ("env", "diffuse", "spec", "glin_axis", "glin_lamb", "glin_weight")}
+    keys = ("env", "diffuse", "spec") + tuple(f"glin_{k}" for k in SG + BRDF)
+    e_ref = {k: rel_l2(z["ref32_" + k], z["ref64_" + k]) for k in keys}
     return z, cfg, e_ref
 
 
-def _window(inp, cts, b, R, C, q, quadrant, div=2):
-    """Image b's inputs / cotangents cropped to one window of the env grid -- cell `quadrant` of a div x div tiling --
-    (fp64 leaves), and the oracle's window spec."""
-    if FULL_SWEEP:
-        r0, c0, Rw, Cw = 0, 0, R, C
-    else:
-        Rw, Cw = R // div, C // div
-        r0, c0 = (quadrant // div) * Rw, (quadrant % div) * Cw
-    img = lambda t: t[b:b + 1, :, q * r0:q * (r0 + Rw), q * c0:q * (c0 + Cw)].double().contiguous()
-    sub = dict(albedo=img(inp["albedo"]), normal=img(inp["normal"]), rough=img(inp["rough"]),
-               axis=inp["axis"][b:b + 1, :, :, r0:r0 + Rw, c0:c0 + Cw].double().contiguous(),
-               lamb=inp["lamb"][b:b + 1, :, r0:r0 + Rw, c0:c0 + Cw].double().contiguous(),
-               weight=inp["weight"][b:b + 1, :, r0:r0 + Rw, c0:c0 + Cw].double().contiguous())
-    for k in SG:
-        sub[k].requires_grad_(True)
-    ct = [cts[0][b:b + 1, :, r0:r0 + Rw, c0:c0 + Cw].double(), cts[1][b:b + 1, :, r0:r0 + Rw, c0:c0 + Cw].double(),
-          cts[2][b:b + 1, :, r0:r0 + Rw, c0:c0 + Cw].double()]
-    crop = lambda t: t[b:b + 1, ..., r0:r0 + Rw, c0:c0 + Cw] if t.dim() != 6 else t[b:b + 1, :, r0:r0 + Rw, c0:c0 + Cw]
-    return sub, ct, (R, C, r0, c0), crop
+@pytest.fixture(scope="module")
+def g7():
+    return _fixture_with_eref("g7_cfg2_one_image.npz")
 
 
-def _fwd_bwd(sgr, inp, cts, R, C, eh=8, ew=16):
+@pytest.fixture(scope="module")
+def g8():
+    return _fixture_with_eref("g8_cfg5_small.npz")
+
+
+def _fwd_bwd(sgr, inp, cts, R, C, eh=8, ew=16, wrt=SG):
     x = {k: inp[k].cuda() for k in NAMES}
-    for k in SG:
+    for k in wrt:
         x[k].requires_grad_(True)
     layer = sgr.renderingLayer(imWidth=C, imHeight=R, envWidth=ew, envHeight=eh)
     env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=True)
-    grads = torch.autograd.grad([env, d, s], [x[k] for k in SG], grad_outputs=[c.cuda() for c in cts])
-    return env.detach(), d.detach(), s.detach(), grads
+    grads = torch.autograd.grad([env, d, s], [x[k] for k in wrt], grad_outputs=[c.cuda() for c in cts])
+    return env.detach(), d.detach(), s.detach(), dict(zip(wrt, grads))
+
+
+def _regular_normals(inp, b, R, C):
+    """Mask (image resolution) of the pixels whose pooled normal is not (anti)parallel to `up` and not near zero: there the local
+    frame is singular and the reference's normal gradient is O(1e20) garbage -- excluded, as in the
+    fixture tests."""
+    n = inp["normal"][b:b + 1]
+    pn = torch.nn.functional.adaptive_avg_pool2d(n, (R, C))
+    nn = (pn * pn).sum(1, keepdim=True)
+    un = pn / nn.clamp(1e-6, 1).sqrt()
+    ok = ((un[:, 1:2].abs() < 0.999) & (nn > 1e-4)).float()
+    return torch.nn.functional.interpolate(ok, size=tuple(n.shape[2:]), mode="nearest") > 0.5
 
 
 def test_one_image_vs_reference_fixture(sgr, g7):
-    """The reference itself at full size: fp32 values, and fp64 values as the arbiter."""
+    """The reference itself at full size: fp32 values, and fp64 values as the arbiter; SG and BRDF-map gradients."""
     from oracle import sg_oracle as O
     z, cfg, e_ref = g7
     inp = O.synthetic_inputs(cfg["bn"], cfg["imH"], cfg["imW"], cfg["R"], cfg["C"], cfg["K"], cfg["eh"], cfg["ew"], seed=cfg["seed"])
@@ -84,63 +85,97 @@ def test_one_image_vs_reference_fixture(sgr, g7):
     R, C, eh, ew = cfg["R"], cfg["C"], cfg["eh"], cfg["ew"]
     cts = [torch.randn((1, 3, R, C, eh, ew), generator=g), torch.randn((1, 3, R, C), generator=g), torch.randn((1, 3, R, C), generator=g)]
     assert np.allclose([c.double().sum().item() for c in cts], z["ct_checksums"], rtol=1e-12)
-    env, d, s, grads = _fwd_bwd(sgr, inp, cts, R, C, eh, ew)
+    env, d, s, grads = _fwd_bwd(sgr, inp, cts, R, C, eh, ew, wrt=SG + BRDF)
     se, ss = [int(v) for v in z["strides"]]
-    got = dict(env=env[:, :, ::se, ::se], diffuse=d, spec=s,
-               **{f"glin_{k}": gk[..., ::ss, ::ss] for k, gk in zip(SG, grads)})
+    got = dict(env=env[:, :, ::se, ::se], diffuse=d, spec=s, **{f"glin_{k}": gk[..., ::ss, ::ss] for k, gk in grads.items()})
+    report = {}
     for k, v in got.items():
         v = v.cpu()
-        assert rel_l2(v, z["ref32_" + k]) < 1e-4, (k, "vs reference fp32", rel_l2(v, z["ref32_" + k]))
-        assert rel_l2(v, z["ref64_" + k]) <= max(2.0 * e_ref[k], 1e-5), (k, "vs reference fp64", rel_l2(v, z["ref64_" + k]), e_ref[k])
+        e32, e64 = rel_l2(v, z["ref32_" + k]), rel_l2(v, z["ref64_" + k])
+        report[k] = (e32, e64, e_ref[k])
+        loose = k in ("glin_normal", "glin_rough")      # the reference's own fp32 gradients are good to 1e-3 there
+        assert e64 <= (2.0 * e_ref[k] if loose else tol2(e_ref[k], 1e-5)), (k, "vs reference fp64", e64, e_ref[k])
+        assert e32 <= (3.0 * e_ref[k] if loose else 1e-4), (k, "vs reference fp32", e32, e_ref[k])
+    print("config 2, one image vs the reference-made fixture: (vs ref32, vs ref64, e_ref)", {k: tuple(f"{x:.2e}" for x in v) for k, v in report.items()})
     assert rel_max(d.cpu(), z["ref32_diffuse"]) < 2e-4 and rel_max(s.cpu(), z["ref32_spec"]) < 2e-4
     assert abs(env.double().norm().item() - float(z["ref32_env_norm"][0])) < 1e-5 * float(z["ref32_env_norm"][0])
-    for k, gk in zip(SG, grads):
+    for k in SG:
         n = float(z[f"ref32_glin_{k}_norm"][0])
-        assert abs(gk.double().norm().item() - n) < 1e-4 * n, k
+        assert abs(grads[k].double().norm().item() - n) < 1e-4 * n, k
 
 
 def test_config2_all_sixteen_images_forward_backward(sgr, g7):
-    """Every image of the contract batch against the fp64 oracle; tolerance from the reference's own fp32 error."""
+    """Every image of the contract batch, every cell, against the fp64 oracle evaluated on the GPU; SG and BRDF-map gradients;
+    tolerances from the reference's own fp32 error at this size (fixture g7)."""
     from oracle import sg_oracle as O
     _, _, e_ref = g7
     bn, imH, imW, R, C, K = 16, 240, 320, 120, 160, 12
     inp = O.synthetic_inputs(bn, imH, imW, R, C, K, seed=20202)
     g = torch.Generator().manual_seed(11)
     cts = [torch.randn((bn, 3, R, C, 8, 16), generator=g), torch.randn((bn, 3, R, C), generator=g), torch.randn((bn, 3, R, C), generator=g)]
-    env, d, s, grads = _fwd_bwd(sgr, inp, cts, R, C)
-    env, d, s, grads = env.cpu(), d.cpu(), s.cpu(), [t.cpu() for t in grads]
+    env, d, s, grads = _fwd_bwd(sgr, inp, cts, R, C, wrt=SG + BRDF)
+    assert all(torch.isfinite(t).all() for t in [env, d, s] + list(grads.values()))
     worst = {}
     for b in range(bn):
-        sub, ct, win, crop = _window(inp, cts, b, R, C, 2, b % 4)
-        eo, do, so = O.render_from_sg(sub["albedo"], sub["normal"], sub["rough"], sub["axis"], sub["lamb"], sub["weight"], window=win)
-        gro = torch.autograd.grad([eo, do, so], [sub[k] for k in SG], grad_outputs=ct)
-        errs = dict(env=rel_l2(crop(env), eo.detach()), diffuse=rel_l2(crop(d), do.detach()), spec=rel_l2(crop(s), so.detach()),
-                    **{f"glin_{k}": rel_l2(crop(gk), r) for k, gk, r in zip(SG, grads, gro)})
+        ref = oracle_fwd_bwd(O, inp, cts, 8, 16, SG + BRDF, torch.float64, "cuda", b)
+        ok_n = _regular_normals(inp, b, R, C).cuda().expand(1, 3, imH, imW)
+        errs = dict(env=rel_l2(env[b:b + 1], ref["env"]), diffuse=rel_l2(d[b:b + 1], ref["diffuse"]), spec=rel_l2(s[b:b + 1], ref["spec"]))
+        for k in SG + BRDF:
+            a, r = grads[k][b:b + 1], ref["g_" + k]
+            errs["glin_" + k] = rel_l2(a[ok_n], r[ok_n]) if k == "normal" else rel_l2(a, r)
         for k, e in errs.items():
-            assert e <= max(2.0 * e_ref[k], 1e-4), (b, k, e, e_ref[k])
+            lim = min(tol2(e_ref[k]), 2e-4)      # normal / roughness: 2 e_ref would be 2e-3 (the reference's fp32 gradients carry 1e-3)
+            assert e <= lim, (b, k, e, e_ref[k])
             worst[k] = max(worst.get(k, 0.0), e)
-    assert all(torch.isfinite(t).all() for t in [env, d, s] + list(grads))
-    print("config 2, worst rel-L2 over 16 images vs fp64 oracle", "(whole images)" if FULL_SWEEP else "(one quadrant of each)", ":",
-          {k: f"{v:.2e}" for k, v in worst.items()},
-          "reference's own:", {k: f"{v:.2e}" for k, v in e_ref.items()})
+        del ref
+    print("config 2, worst rel-L2 over 16 WHOLE images vs the fp64 oracle:", {k: f"{v:.2e}" for k, v in worst.items()},
+          "reference's own fp32 error (g7):", {k: f"{v:.2e}" for k, v in e_ref.items()})
 
 
-def test_config5_one_full_image(sgr):
-    """BASELINE configs[4]: 480x640 maps, env grid 240x320, SGNum 24, 16x32 directions; one image."""
+def test_config5_small_vs_reference_fixture(sgr, g8):
+    """SGNum 24 on the 16x32 grid against the unmodified reference (12 x 16 cells): values and all six gradients."""
     from oracle import sg_oracle as O
+    z, cfg, e_ref = g8
+    R, C, K, eh, ew = cfg["R"], cfg["C"], cfg["K"], cfg["eh"], cfg["ew"]
+    inp = O.synthetic_inputs(cfg["bn"], cfg["imH"], cfg["imW"], R, C, K, eh, ew, seed=cfg["seed"])
+    chk = np.array([inp[k].double().sum().item() for k in NAMES])
+    if not np.allclose(chk, z["in_checksums"], rtol=1e-12):
+        pytest.skip("torch's CPU generator produced different synthetic inputs on this machine")
+    g = torch.Generator().manual_seed(cfg["seed"] + 7)
+    cts = [torch.randn((1, 3, R, C, eh, ew), generator=g), torch.randn((1, 3, R, C), generator=g), torch.randn((1, 3, R, C), generator=g)]
+    assert np.allclose([c.double().sum().item() for c in cts], z["ct_checksums"], rtol=1e-12)
+    env, d, s, grads = _fwd_bwd(sgr, inp, cts, R, C, eh, ew, wrt=SG + BRDF)
+    st = int(z["env_stride"][0])
+    got = dict(env=env[:, :, ::st, ::st], diffuse=d, spec=s, **{f"glin_{k}": gk for k, gk in grads.items()})
+    for k, v in got.items():
+        v = v.cpu()
+        e32, e64 = rel_l2(v, z["ref32_" + k]), rel_l2(v, z["ref64_" + k])
+        loose = k in ("glin_normal", "glin_rough")
+        assert e64 <= (2.0 * e_ref[k] if loose else tol2(e_ref[k], 2e-5)), (k, "vs reference fp64", e64, e_ref[k])
+        assert e32 <= (3.0 * e_ref[k] if loose else 1e-4), (k, "vs reference fp32", e32, e_ref[k])
+
+
+def test_config5_one_full_image(sgr, g8):
+    """BASELINE configs[4]: 480x640 maps, env grid 240x320, SGNum 24, 16x32 directions; one whole image against
+    the fp64 oracle on the GPU, SG and BRDF-map gradients; e_ref from the reference-made fixture at these parameters (g8)."""
+    from oracle import sg_oracle as O
+    _, _, e_ref = g8
     bn, imH, imW, R, C, K, eh, ew = 1, 480, 640, 240, 320, 24, 16, 32
     inp = O.synthetic_inputs(bn, imH, imW, R, C, K, eh, ew, seed=20205)
     g = torch.Generator().manual_seed(12)
     cts = [torch.randn((bn, 3, R, C, eh, ew), generator=g), torch.randn((bn, 3, R, C), generator=g), torch.randn((bn, 3, R, C), generator=g)]
-    env, d, s, grads = _fwd_bwd(sgr, inp, cts, R, C, eh, ew)
-    env, d, s, grads = env.cpu(), d.cpu(), s.cpu(), [t.cpu() for t in grads]
-    assert all(torch.isfinite(t).all() for t in [env, d, s] + list(grads))
-    sub, ct, win, crop = _window(inp, cts, 0, R, C, 2, 9, div=4)      # the oracle's window: 60 x 80 cells off-centre (whole image: SGR_FULL_SWEEP=1)
-    eo, do, so = O.render_from_sg(sub["albedo"], sub["normal"], sub["rough"], sub["axis"], sub["lamb"], sub["weight"], eh, ew, window=win)
-    gro = torch.autograd.grad([eo, do, so], [sub[k] for k in SG], grad_outputs=ct)
-    assert rel_l2(crop(env), eo.detach()) < 1e-4 and rel_l2(crop(d), do.detach()) < 1e-4 and rel_l2(crop(s), so.detach()) < 1.5e-4
-    for k, gk, r in zip(SG, grads, gro):
-        assert rel_l2(crop(gk), r) < 2e-4, (k, rel_l2(crop(gk), r))
+    env, d, s, grads = _fwd_bwd(sgr, inp, cts, R, C, eh, ew, wrt=SG + BRDF)
+    assert all(torch.isfinite(t).all() for t in [env, d, s] + list(grads.values()))
+    ref = oracle_fwd_bwd(O, inp, cts, eh, ew, SG + BRDF, torch.float64, "cuda", 0)
+    ok_n = _regular_normals(inp, 0, R, C).cuda().expand(1, 3, imH, imW)
+    errs = dict(env=rel_l2(env, ref["env"]), diffuse=rel_l2(d, ref["diffuse"]), spec=rel_l2(s, ref["spec"]))
+    for k in SG + BRDF:
+        a, r = grads[k], ref["g_" + k]
+        errs["glin_" + k] = rel_l2(a[ok_n], r[ok_n]) if k == "normal" else rel_l2(a, r)
+    print("config 5, one WHOLE image vs the fp64 oracle:", {k: f"{v:.2e}" for k, v in errs.items()}, "e_ref (g8):", {k: f"{v:.2e}" for k, v in e_ref.items()})
+    for k, e in errs.items():
+        lim = min(tol2(e_ref[k]), 2e-4)
+        assert e <= lim, (k, e, e_ref[k])
 
 
 def _rand_case(g):
@@ -152,34 +187,48 @@ def _rand_case(g):
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_randomised_shapes_fixed_seeds(sgr, seed):
     """8 random (batch, grid, pooling ratio, lobe count, envHeight) cases per seed through the fused forward + backward and
-    the fused light objective, against the fp64 oracle."""
+    the fused light objective, against the fp64 oracle; tolerance max(2 e32, 1e-4) with e32 the fp32 noise of the oracle's
+    restatement on the same inputs (conftest.oracle_with_noise)."""
     from oracle import sg_oracle as O
     g = torch.Generator().manual_seed(seed)
+    worst = 0.0
     for case in range(8):
         c = _rand_case(g)
         bn, R, C, K, eh, ew = c["bn"], c["R"], c["C"], c["K"], c["eh"], 16
         inp = O.synthetic_inputs(bn, R * c["q"], C * c["q"], R, C, K, eh, ew, seed=1000 * (seed + 1) + case, benign=c["benign"])
         ind = (torch.rand(bn, 1, 1, 1, generator=g) < 0.8).float()
         x = {k: v.cuda() for k, v in inp.items()}
-        xo = {k: v.double() for k, v in inp.items()}
         for k in SG:
             x[k].requires_grad_(True)
-            xo[k] = xo[k].clone().requires_grad_(True)
         layer = sgr.renderingLayer(imWidth=C, imHeight=R, envWidth=ew, envHeight=eh)
         env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=True)
-        eo, do, so = O.render_from_sg(xo["albedo"], xo["normal"], xo["rough"], xo["axis"], xo["lamb"], xo["weight"], eh, ew)
         ct = [torch.randn(t.shape, generator=g) for t in (env, d, s)]
         gr = torch.autograd.grad([env, d, s], [x[k] for k in SG], grad_outputs=[t.cuda() for t in ct])
-        go = torch.autograd.grad([eo, do, so], [xo[k] for k in SG], grad_outputs=[t.double() for t in ct], retain_graph=True)
-        errs = dict(env=rel_l2(env.detach().cpu(), eo.detach()), d=rel_l2(d.detach().cpu(), do.detach()), s=rel_l2(s.detach().cpu(), so.detach()),
-                    **{f"g_{k}": rel_l2(a.cpu(), b) for k, a, b in zip(SG, gr, go)})
+        r64, _, e32 = oracle_with_noise(O, inp, ct, eh, ew, SG, "cuda")
+        errs = dict(env=rel_l2(env.detach(), r64["env"]), diffuse=rel_l2(d.detach(), r64["diffuse"]), spec=rel_l2(s.detach(), r64["spec"]),
+                    **{f"g_{k}": rel_l2(a, r64["g_" + k]) for k, a in zip(SG, gr)})
+        for k, e in errs.items():
+            assert e <= tol2(e32[k]), (seed, case, c, k, e, e32[k])
+            worst = max(worst, e / tol2(e32[k]))
+        # the fused light objective: its gradient against the oracle's, yardstick = the same objective's gradient in fp32
         obj = sgr.light_objective(layer, x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], x["im"], x["seg"],
                                   x["env_gt"], ind.cuda(), 1.0, 10.0)
         go2 = torch.autograd.grad(obj[0], [x[k] for k in SG])
-        ro, _, _, _ = O.render_loss(do, so, xo["im"], xo["seg"], R, C)
-        co, _, _, _ = O.recon_loss(eo, xo["env_gt"], xo["seg"], ind.double(), R, C)
-        g3 = torch.autograd.grad(ro + 10.0 * co, [xo[k] for k in SG])
-        errs.update(render=abs(obj[1].item() - ro.item()) / max(1.0, ro.item()), recon=abs(obj[2].item() - co.item()) / max(1.0, co.item()),
-                    **{f"o_{k}": rel_l2(a.cpu(), b) for k, a, b in zip(SG, go2, g3)})
-        assert all(torch.isfinite(t).all() for t in list(gr) + list(go2)), (seed, case, c)
-        assert max(errs.values()) < 5e-4, (seed, case, c, errs)
+
+        def objective(dtype):
+            xo = {k: v.to("cuda", dtype) for k, v in inp.items()}
+            for k in SG:
+                xo[k].requires_grad_(True)
+            eo, do, so = O.render_from_sg(xo["albedo"], xo["normal"], xo["rough"], xo["axis"], xo["lamb"], xo["weight"], eh, ew)
+            ro, _, _, _ = O.render_loss(do, so, xo["im"], xo["seg"], R, C)
+            co, _, _, _ = O.recon_loss(eo, xo["env_gt"], xo["seg"], ind.to("cuda", dtype), R, C)
+            return ro.detach(), co.detach(), torch.autograd.grad(ro + 10.0 * co, [xo[k] for k in SG])
+
+        ro, co, g64 = objective(torch.float64)
+        _, _, g32 = objective(torch.float32)
+        assert abs(obj[1].item() - ro.item()) <= 1e-4 * max(1.0, ro.item()) and abs(obj[2].item() - co.item()) <= 1e-4 * max(1.0, co.item())
+        for k, a, r, r32 in zip(SG, go2, g64, g32):
+            assert torch.isfinite(a).all(), (seed, case, c)
+            e, e_o = rel_l2(a, r), rel_l2(r32, r)
+            assert e <= tol2(e_o), (seed, case, c, "objective", k, e, e_o)
+    print(f"seed {seed}: worst error / tolerance = {worst:.2f}")

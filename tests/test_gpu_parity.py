@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_l2, rel_max
+from conftest import NAMES6, oracle_fwd_bwd, oracle_with_noise, rel_l2, rel_max, tol2
 
 pytestmark = pytest.mark.gpu
 
@@ -68,9 +68,10 @@ def _check_grads(name, z, cfg, grads, which="glin"):
         m = np.broadcast_to(mask, g.shape) if k == "normal" else np.ones(g.shape, bool)
         assert np.isfinite(g).all(), (name, k)
         e_ref = rel_l2(ref32[m], ref64[m])
-        # primary: the reference's own fp32 gradients (for ratio-1 unit normals the |N|^2 == 1 clamp kink
-        # makes fp32 and fp64 gradients differ by O(1); the kernels follow the fp32 rounding)
-        assert rel_l2(g[m], ref32[m]) < max(3e-4, 4 * min(e_ref, 1e-3)), (name, k, rel_l2(g[m], ref32[m]), e_ref)
+        # primary: the reference's own fp32 gradients.  Where fp64 is a valid arbiter both are within e_ref / 2 e_ref of it, so
+        # 3 e_ref bounds their distance; for ratio-1 unit normals the |N|^2 == 1 clamp kink makes the reference's fp32 and
+        # fp64 gradients differ by O(1) (e_ref ~ 1): the kernels follow the fp32 rounding, and only the contract's 1e-4 is left
+        assert rel_l2(g[m], ref32[m]) < max(3 * e_ref if e_ref < 1e-3 else 0.0, 1e-4), (name, k, rel_l2(g[m], ref32[m]), e_ref)
         if e_ref < 1e-3:
             e = rel_l2(g[m], ref64[m])
             assert e < max(2 * e_ref, 1e-5), (name, k, e, e_ref)
@@ -149,17 +150,20 @@ def test_sg_only_grads_like_trainlight(sgr, golden):
     _, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=False)
     _, cd, cs = _cotangents(z)
     g = torch.autograd.grad((d * cd).sum() + (s * cs).sum(), [x["axis"], x["lamb"], x["weight"]])
-    # same thing through the oracle in fp64
+    # same thing through the oracle in fp64 -- and in fp32, whose distance from the former is the yardstick
     from oracle import sg_oracle as O
-    xo = {k: torch.from_numpy(z["in_" + k]).double() for k in NAMES}
-    for k in ("axis", "lamb", "weight"):
-        xo[k].requires_grad_(True)
-    _, do, so = O.render_from_sg(xo["albedo"], xo["normal"], xo["rough"], xo["axis"], xo["lamb"], xo["weight"],
-                                 cfg["eh"], cfg["ew"], cfg["fov"], cfg["F0"])
-    go = torch.autograd.grad((do * cd.cpu().double()).sum() + (so * cs.cpu().double()).sum(),
-                             [xo["axis"], xo["lamb"], xo["weight"]])
-    for k, a, b in zip(("axis", "lamb", "weight"), g, go):
-        assert rel_l2(a.cpu(), b) < 3e-4, (name, k, rel_l2(a.cpu(), b))
+
+    def oracle(dtype):
+        xo = {k: torch.from_numpy(z["in_" + k]).to("cuda", dtype) for k in NAMES}
+        for k in ("axis", "lamb", "weight"):
+            xo[k].requires_grad_(True)
+        _, do, so = O.render_from_sg(xo["albedo"], xo["normal"], xo["rough"], xo["axis"], xo["lamb"], xo["weight"],
+                                     cfg["eh"], cfg["ew"], cfg["fov"], cfg["F0"])
+        return torch.autograd.grad((do * cd.to(dtype)).sum() + (so * cs.to(dtype)).sum(), [xo["axis"], xo["lamb"], xo["weight"]])
+
+    go, go32 = oracle(torch.float64), oracle(torch.float32)
+    for k, a, b, b32 in zip(("axis", "lamb", "weight"), g, go, go32):
+        assert rel_l2(a, b) <= tol2(rel_l2(b32, b)), (name, k, rel_l2(a, b), rel_l2(b32, b))
 
 
 @pytest.mark.parametrize("shape", [
@@ -184,31 +188,24 @@ def test_shapes_vs_oracle(sgr, shape):
     x = {k: inp[k].cuda().requires_grad_(True) for k in NAMES}
     layer = sgr.renderingLayer(imWidth=shape["C"], imHeight=shape["R"], envWidth=shape["ew"], envHeight=shape["eh"])
     env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=True)
-    xo = {k: inp[k].double().requires_grad_(True) for k in NAMES}
-    envo, do, so = O.render_from_sg(xo["albedo"], xo["normal"], xo["rough"], xo["axis"], xo["lamb"], xo["weight"],
-                                    shape["eh"], shape["ew"])
-    assert rel_l2(env.detach().cpu(), envo.detach()) < TOL_L2
-    assert rel_l2(d.detach().cpu(), do.detach()) < TOL_L2
-    assert rel_l2(s.detach().cpu(), so.detach()) < 2e-4
     g = torch.Generator().manual_seed(7)
-    ce, cd, cs = torch.randn(env.shape, generator=g), torch.randn(d.shape, generator=g), torch.randn(s.shape, generator=g)
-    grads = torch.autograd.grad((env * ce.cuda()).sum() + (d * cd.cuda()).sum() + (s * cs.cuda()).sum(), [x[k] for k in NAMES])
-    gro = torch.autograd.grad((envo * ce.double()).sum() + (do * cd.double()).sum() + (so * cs.double()).sum(),
-                              [xo[k] for k in NAMES])
-    # The normal gradient is discontinuous at |N|^2 == 1 (two-sided clamp, models.py:467-468): with unit
-    # input normals and no pooling, fp32 and fp64 evaluations of |N|^2 land on different sides of the
-    # kink pixel by pixel.  The reference semantics are the fp32 ones, so that gradient is compared with
-    # the oracle evaluated in fp32.
-    x32 = {k: inp[k].clone().requires_grad_(True) for k in NAMES}
-    e32, d32, s32 = O.render_from_sg(x32["albedo"], x32["normal"], x32["rough"], x32["axis"], x32["lamb"], x32["weight"],
-                                     shape["eh"], shape["ew"])
-    g32 = torch.autograd.grad((e32 * ce).sum() + (d32 * cd).sum() + (s32 * cs).sum(), [x32[k] for k in NAMES])
-    for k, a, b, b32 in zip(NAMES, grads, gro, g32):
+    cts = [torch.randn(env.shape, generator=g), torch.randn(d.shape, generator=g), torch.randn(s.shape, generator=g)]
+    r64, r32, e32 = oracle_with_noise(O, inp, cts, shape["eh"], shape["ew"], NAMES, "cuda")
+    for k, v in (("env", env), ("diffuse", d), ("spec", s)):
+        assert rel_l2(v.detach(), r64[k]) <= tol2(e32[k]), (shape, k, rel_l2(v.detach(), r64[k]), e32[k])
+    grads = torch.autograd.grad([env, d, s], [x[k] for k in NAMES], grad_outputs=[c.cuda() for c in cts])
+    # The normal gradient is discontinuous at |N|^2 == 1 (two-sided clamp, models.py:467-468): with unit input normals and no
+    # pooling, fp32 and fp64 evaluations of |N|^2 land on different sides of the kink pixel by pixel (e32 of that gradient is
+    # then O(1)).  The reference semantics are the fp32 ones, which the kernels follow (|N|^2 with torch's own rounding), so
+    # there the gradient is compared with the oracle evaluated in fp32; likewise roughness, which sees the same pixels.
+    for k, a in zip(NAMES, grads):
         assert torch.isfinite(a).all(), k
-        if k == "normal":
-            assert rel_l2(a.cpu(), b32) < 2e-3, (shape, k, rel_l2(a.cpu(), b32))
+        e, noise = rel_l2(a, r64["g_" + k]), e32["g_" + k]
+        if k in ("normal", "rough") and noise > 1e-3:
+            e_f32 = rel_l2(a, r32["g_" + k])
+            assert e_f32 <= 2e-3, (shape, k, "vs the fp32 oracle (clamp kink: fp64 is no arbiter)", e_f32, noise)
         else:
-            assert rel_l2(a.cpu(), b) < (2e-3 if k == "rough" else 5e-4), (shape, k, rel_l2(a.cpu(), b))
+            assert e <= (2.0 * noise if k in ("normal", "rough") and noise > 5e-5 else tol2(noise)), (shape, k, e, noise)
 
 
 def test_full_size_properties(sgr):
@@ -243,37 +240,54 @@ def test_full_size_properties(sgr):
     e1 = o2e.fromSGtoIm(x["axis"], lam_t, w_t)
     e2 = o2e.fromSGtoIm(x["axis"], lam_t, 2.0 * w_t)
     assert torch.equal(e2, 2.0 * e1)
-    # two images against the fp64 oracle
-    for b in (0, 15):
-        sub = {k: inp[k][b:b + 1].double() for k in NAMES}
-        eo, do, so = O.render_from_sg(sub["albedo"], sub["normal"], sub["rough"], sub["axis"], sub["lamb"], sub["weight"])
-        assert rel_l2(env[b:b + 1].cpu(), eo) < TOL_L2
-        assert rel_l2(d[b:b + 1].cpu(), do) < TOL_L2
-        assert rel_l2(s[b:b + 1].cpu(), so) < TOL_L2
+    # (all sixteen images, whole, against the fp64 oracle: tests/test_gpu_fullsize.py)
 
 
-def test_full_size_backward_one_image(sgr):
+def test_tan_handoff_matches_recompute(sgr, monkeypatch):
+    """premap mode 2 of the backward entry points (include/sgrender.h): the forward returns the post-tan sharpness / intensity,
+    the backward reads them and applies the pre-map's chain rule from those values alone -- same gradients as the backward
+    that re-evaluates the pre-map (mode 1), for the fused layer, the two-call drop-in sequence (where the reference returns the
+    post-tan tensors anyway) and the fused light objective."""
     from oracle import sg_oracle as O
-    bn, imH, imW, R, C, K = 2, 240, 320, 120, 160, 12
-    inp = O.synthetic_inputs(bn, imH, imW, R, C, K, seed=20203)
-    x = {k: inp[k].cuda() for k in NAMES}
+    bn, imH, imW, R, C, K, eh, ew = 2, 20, 28, 10, 14, 12, 8, 16
+    inp = O.synthetic_inputs(bn, imH, imW, R, C, K, eh, ew, seed=99)
+    layer = sgr.renderingLayer(imWidth=C, imHeight=R, envWidth=ew, envHeight=eh)
+    o2e = sgr.output2env(K, ew, eh)
+    g = torch.Generator().manual_seed(5)
+    cts = [torch.randn((bn, 3, R, C, eh, ew), generator=g).cuda(), torch.randn((bn, 3, R, C), generator=g).cuda(), torch.randn((bn, 3, R, C), generator=g).cuda()]
+    ind = torch.ones(bn, 1, 1, 1).cuda()
+
+    def run(handoff):
+        monkeypatch.setenv("SGR_TAN_HANDOFF", "1" if handoff else "0")
+        x = {k: v.cuda() for k, v in inp.items()}
+        for k in ("axis", "lamb", "weight"):
+            x[k].requires_grad_(True)
+        sg = [x[k] for k in ("axis", "lamb", "weight")]
+        env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], *sg, need_env=True)
+        g_fused = torch.autograd.grad([env, d, s], sg, grad_outputs=cts)
+        obj = sgr.light_objective(layer, x["albedo"], x["normal"], x["rough"], *sg, x["im"], x["seg"], x["env_gt"], ind, 1.0, 10.0)
+        g_obj = torch.autograd.grad(obj[0], sg)
+        return env.detach(), g_fused, g_obj, obj[0].detach()
+
+    e1, f1, o1, v1 = run(True)
+    e0, f0, o0, v0 = run(False)
+    assert torch.equal(e1, e0) and torch.equal(v1, v0)
+    for a, b in zip(f1 + o1, f0 + o0):
+        assert rel_l2(a, b) < 2e-6, rel_l2(a, b)
+    # the two-call sequence saves the post-tan tensors it returns (always mode 2): against the fused layer's gradients
+    x = {k: v.cuda() for k, v in inp.items()}
     for k in ("axis", "lamb", "weight"):
         x[k].requires_grad_(True)
-    layer = sgr.renderingLayer(imWidth=C, imHeight=R)
-    env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=True)
-    g = torch.Generator().manual_seed(11)
-    ce, cd, cs = torch.randn(env.shape, generator=g), torch.randn(d.shape, generator=g), torch.randn(s.shape, generator=g)
-    grads = torch.autograd.grad((env * ce.cuda()).sum() + (d * cd.cuda()).sum() + (s * cs.cuda()).sum(),
-                                [x["axis"], x["lamb"], x["weight"]])
-    b = 1
-    sub = {k: inp[k][b:b + 1].double() for k in NAMES}
+    env, _, lam_t, w_t = o2e.output2env(x["axis"], x["lamb"], x["weight"])
+    g2 = torch.autograd.grad([env, lam_t, w_t], [x["axis"], x["lamb"], x["weight"]], grad_outputs=[cts[0], torch.ones_like(lam_t), torch.ones_like(w_t)])
+    y = {k: v.cuda() for k, v in inp.items()}
     for k in ("axis", "lamb", "weight"):
-        sub[k].requires_grad_(True)
-    eo, do, so = O.render_from_sg(sub["albedo"], sub["normal"], sub["rough"], sub["axis"], sub["lamb"], sub["weight"])
-    gro = torch.autograd.grad((eo * ce[b:b + 1].double()).sum() + (do * cd[b:b + 1].double()).sum() + (so * cs[b:b + 1].double()).sum(),
-                              [sub["axis"], sub["lamb"], sub["weight"]])
-    for k, a, r in zip(("axis", "lamb", "weight"), grads, gro):
-        assert rel_l2(a[b:b + 1].cpu(), r) < 3e-4, (k, rel_l2(a[b:b + 1].cpu(), r))
+        y[k].requires_grad_(True)
+    env_f, _, _ = layer.forwardSG(y["albedo"], y["normal"], y["rough"], y["axis"], y["lamb"], y["weight"], need_env=True)
+    lt, wt = torch.tan(np.pi / 2 * (0.999 * y["lamb"])), torch.tan(np.pi / 2 * (0.999 * y["weight"]))
+    g3 = torch.autograd.grad([env_f, lt, wt], [y["axis"], y["lamb"], y["weight"]], grad_outputs=[cts[0], torch.ones_like(lt), torch.ones_like(wt)])
+    for a, b in zip(g2, g3):
+        assert rel_l2(a, b) < 1e-5, rel_l2(a, b)
 
 
 def test_error_behaviour(sgr):
@@ -295,7 +309,7 @@ def test_error_behaviour(sgr):
 
 def test_zero_sharpness_lobes(sgr):
     """lamb == 0 exactly is what the decoder's clamp produces (models.py:338-340): exp(0 * t) = 1 in every direction.  The
-    packed backward folds lam into the axes and divides the sharpness gradient by it again, with a 1e-30 floor standing in for
+    packed backward folds lam into the axes and divides the sharpness gradient by it again, with a 2^-40 floor standing in for
     zero -- values and gradients of such lobes (and of weight == 0, lamb == 1 lobes) against the fp64 oracle, fused layer and
     fused objective."""
     from oracle import sg_oracle as O
@@ -316,15 +330,23 @@ def test_zero_sharpness_lobes(sgr):
     eo, do, so = O.render_from_sg(xo["albedo"], xo["normal"], xo["rough"], xo["axis"], xo["lamb"], xo["weight"], eh, ew)
     g = torch.Generator().manual_seed(3)
     ct = [torch.randn(t.shape, generator=g) for t in (env, d, s)]
-    gr = torch.autograd.grad([env, d, s], [x[k] for k in ("axis", "lamb", "weight")], grad_outputs=[t.cuda() for t in ct])
+    gr = torch.autograd.grad([env, d, s], [x[k] for k in ("axis", "lamb", "weight")], grad_outputs=[t.cuda() for t in ct], retain_graph=True)
     go = torch.autograd.grad([eo, do, so], [xo[k] for k in ("axis", "lamb", "weight")], grad_outputs=[t.double() for t in ct], retain_graph=True)
     assert rel_l2(env.detach().cpu(), eo.detach()) < TOL_L2 and rel_l2(d.detach().cpu(), do.detach()) < TOL_L2
+    _, _, e32 = oracle_with_noise(O, inp, ct, eh, ew, ("axis", "lamb", "weight"), "cuda")
     for k, a, b in zip(("axis", "lamb", "weight"), gr, go):
         assert torch.isfinite(a).all(), k
-        assert rel_l2(a.cpu(), b) < 3e-4, (k, rel_l2(a.cpu(), b))
+        assert rel_l2(a.cpu(), b) <= tol2(e32["g_" + k]), (k, rel_l2(a.cpu(), b), e32["g_" + k])
     # the zero-sharpness lobes on their own: axis gradient exactly zero, sharpness gradient that of the oracle
     assert float(gr[0][:, 0].abs().max()) == 0.0 and float(gr[0][:, 7].abs().max()) == 0.0
-    assert rel_l2(gr[1][:, [0, 7]].cpu(), go[1][:, [0, 7]]) < 3e-4
+    assert rel_l2(gr[1][:, [0, 7]].cpu(), go[1][:, [0, 7]]) <= tol2(e32["g_lamb"])
+    # the same with cotangents the size a normalised training loss produces (1e-9): the lp floor must keep the folded
+    # sharpness sums clear of the denormal range
+    tiny = 1e-9
+    gr_t = torch.autograd.grad([env, d, s], [x[k] for k in ("axis", "lamb", "weight")], grad_outputs=[(t * tiny).cuda() for t in ct], retain_graph=True)
+    for k, a, b in zip(("axis", "lamb", "weight"), gr_t, go):
+        assert rel_l2(a.cpu().double() / tiny, b) <= tol2(e32["g_" + k]), (k, "1e-9 cotangents", rel_l2(a.cpu().double() / tiny, b))
+    assert rel_l2(gr_t[1][:, [0, 7]].cpu().double() / tiny, go[1][:, [0, 7]]) <= tol2(e32["g_lamb"])
     ind = torch.ones(bn, 1, 1, 1)
     obj = sgr.light_objective(layer, x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], x["im"], x["seg"],
                               x["env_gt"], ind.cuda(), 1.0, 10.0)
@@ -332,7 +354,13 @@ def test_zero_sharpness_lobes(sgr):
     ro, _, _, _ = O.render_loss(do, so, xo["im"], xo["seg"], R, C)
     co, _, _, _ = O.recon_loss(eo, xo["env_gt"], xo["seg"], ind.double(), R, C)
     g3 = torch.autograd.grad(ro + 10.0 * co, [xo[k] for k in ("axis", "lamb", "weight")])
-    for k, a, b in zip(("axis", "lamb", "weight"), g2, g3):
+    x32 = {k: v.clone() for k, v in inp.items()}      # the same objective through the oracle in fp32: the yardstick
+    for k in ("axis", "lamb", "weight"):
+        x32[k].requires_grad_(True)
+    e32_, d32_, s32_ = O.render_from_sg(x32["albedo"], x32["normal"], x32["rough"], x32["axis"], x32["lamb"], x32["weight"], eh, ew)
+    g3_32 = torch.autograd.grad(O.render_loss(d32_, s32_, x32["im"], x32["seg"], R, C)[0] + 10.0 * O.recon_loss(e32_, x32["env_gt"], x32["seg"], ind, R, C)[0],
+                                [x32[k] for k in ("axis", "lamb", "weight")])
+    for k, a, b, b32 in zip(("axis", "lamb", "weight"), g2, g3, g3_32):
         assert torch.isfinite(a).all(), k
-        assert rel_l2(a.cpu(), b) < 5e-4, (k, rel_l2(a.cpu(), b))
+        assert rel_l2(a.cpu(), b) <= tol2(rel_l2(b32, b)), (k, rel_l2(a.cpu(), b), rel_l2(b32, b))
     assert float(g2[0][:, 0].abs().max()) == 0.0
