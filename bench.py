@@ -22,6 +22,16 @@ Timing: `--reps` (default 5) repetitions of the K-step loop, each bracketed by b
 synchronise on both sides and maximised over ranks; the line reports the MEDIAN repetition
 (`ms_per_step`) and lists all of them (`config.ms_per_step_repetitions`).
 
+Informational legs (single process only; they can never fail the contract line): the cascade-0 light objective fused / unfused
+(`ms_per_step_light_objective_*`), and BASELINE config 3 -- the synthetic trainLight step: decoder-head activations ->
+light objective -> backward -> Adam over the 103 MB of decoder outputs (`config3`: eager, and the whole step replayed from a HIP
+graph with the fused capturable Adam).  Round 2's HIP-graph replay legs of the two- and few-kernel steps are gone: with nothing but
+long kernels in the step there is no launch gap to remove, and a replay pays ~10-40 us of graph-launch latency per step that
+eager launches hide behind the running kernel (driver, round 2: 0.469 vs 0.422 ms).
+
+`roofline` is the HBM roofline north_star names (algorithmic bytes / live kernel time); `roofline_valu` is the resource that
+actually binds the fused kernels -- VALU issue -- from the SQ counters of the same workload (profiles/sq.json, tools/pmc_sq.sh).
+
 Rank 0 prints ONE JSON line; see README/DESIGN.md for the field definitions.
 """
 from __future__ import annotations
@@ -170,41 +180,12 @@ def main() -> None:
     headline_dts = plain_dts if world == 1 else loss_dts
     dt = median(headline_dts)
 
-    # informational: the same two-kernel step captured once in a HIP graph and replayed (no per-launch host work, no
-    # event markers between the kernels); per-kernel timing is not possible inside a graph, so the contract line above
-    # stays the eager loop
-    graph_ms = None
-    try:
-        if world > 1:      # stream capture and the process group's watchdog thread do not mix; single-process only
-            raise RuntimeError("skipped under torch.distributed")
-        if args.layer_only:
-            raise RuntimeError("skipped (--layer-only)")
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                step()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static_grads = step()
-        graph.replay()
-        barrier()
-        t3 = time.perf_counter()
-        for _ in range(args.steps):
-            graph.replay()
-        barrier()
-        graph_ms = (time.perf_counter() - t3) / args.steps * 1e3
-        del static_grads, graph
-    except Exception as exc:       # informational leg: never fail the bench over it
-        graph_ms = None
-        if rank == 0 and world == 1 and not args.layer_only:
-            print(f"# hip-graph leg skipped: {str(exc)[:160]}", file=sys.stderr)
-
     # informational: the whole cascade-0 light objective (render loss + 10 x env reconstruction loss,
-    # wrapperBRDFLight.py:167-207) -- fused (env image never written, sgr.light_objective) and unfused
-    obj_ms = obj_unfused_ms = obj_graph_ms = None
-    if args.config == 2 and need_env and not args.layer_only and pkg.light_objective_supported(K, R, C, eh, ew):
+    # wrapperBRDFLight.py:167-207) -- fused (env image never written, sgr.light_objective) and unfused.  Single process only:
+    # a leg that failed on one rank would leave the others in its barrier
+    obj_ms = obj_unfused_ms = None
+    cfg3 = None
+    if world == 1 and need_env and not args.layer_only:
         ind = torch.ones(bn, 1, 1, 1, device=dev)
 
         def clear():
@@ -224,43 +205,28 @@ def main() -> None:
             (err + 10.0 * rec).backward()
             clear()
 
-        try:
-            res = []
-            for fn in (step_obj_fused, step_obj_unfused):
+        def loop_ms(fn, n):
+            fn()
+            barrier()
+            t2 = time.perf_counter()
+            for _ in range(n):
                 fn()
-                barrier()
-                t2 = time.perf_counter()
-                for _ in range(args.steps):
-                    fn()
-                barrier()
-                res.append((time.perf_counter() - t2) / args.steps * 1e3)
-            obj_ms, obj_unfused_ms = res
+            barrier()
+            return (time.perf_counter() - t2) / n * 1e3
+
+        try:
+            obj_ms = loop_ms(step_obj_fused, args.steps)
+            obj_unfused_ms = loop_ms(step_obj_unfused, args.steps)
         except Exception as exc:       # informational legs: never fail the bench over them
             obj_ms = obj_unfused_ms = None
-            if rank == 0:
-                print(f"# light-objective legs skipped: {str(exc)[:160]}", file=sys.stderr)
-        # the fused objective (two heavy kernels + ~15 small ones) replayed from a HIP graph: no launch gaps
-        if world == 1 and obj_ms is not None:
-            try:
-                side = torch.cuda.Stream(device=dev)
-                side.wait_stream(torch.cuda.current_stream(dev))
-                with torch.cuda.stream(side):
-                    step_obj_fused()
-                torch.cuda.current_stream(dev).wait_stream(side)
-                og = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(og):
-                    step_obj_fused()
-                og.replay()
-                barrier()
-                t5 = time.perf_counter()
-                for _ in range(args.steps):
-                    og.replay()
-                barrier()
-                obj_graph_ms = (time.perf_counter() - t5) / args.steps * 1e3
-                del og
-            except Exception as exc:
-                obj_graph_ms = None
-                print(f"# objective hip-graph leg skipped: {str(exc)[:160]}", file=sys.stderr)
+            print(f"# light-objective legs skipped: {str(exc)[:160]}", file=sys.stderr)
+
+        # BASELINE config 3: the synthetic trainLight cascade-0 step (trainLight.py:203-244 around wrapperBRDFLight.py:158-207):
+        # learnable decoder outputs -> output activations (sgr.light_heads) -> light objective -> backward -> Adam
+        try:
+            cfg3 = config3_legs(pkg, layer, x, ind, bn, R, C, K, args.steps, barrier)
+        except Exception as exc:
+            cfg3 = {"error": str(exc)[:200]}
 
     if rank == 0:
         P = bn * R * C                      # shaded (env-grid) pixels per GPU per step
@@ -281,7 +247,7 @@ def main() -> None:
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         import re
         want = ([r"sg_bwd_pk_kernel<", r"sg_bwd_half_kernel<", r"sg_bwd_split_kernel<", r"sg_bwd_fast_kernel<"]
-                if dom[0] == "bwd" else [r"fwd_pk_kernel<", r"fwd_half_kernel<", r"fwd_fast_kernel<"])
+                if dom[0] == "bwd" else [r"fwd_pk_half_kernel<", r"fwd_pk_kernel<", r"fwd_half_kernel<", r"fwd_fast_kernel<"])
         if os.path.isfile(tpath):
             try:
                 recs = json.load(open(tpath)).get(tkey, {})
@@ -292,6 +258,12 @@ def main() -> None:
                         break
             except Exception:
                 traffic = None
+        # the resource that actually binds the fused kernels: VALU issue.  SQ counters of the same workload (tools/pmc_sq.sh ->
+        # profiles/sq.json): SQ_ACTIVE_INST_VALU counts, per SIMD quad, the cycles a VALU instruction is in flight; x 4 / SIMDs
+        # against the kernel's duration in shader-clock cycles (GRBM_GUI_ACTIVE / XCDs) is the fraction of issue cycles used
+        valu, limited_by = valu_roofline(tkey, want, dom[1]), "hbm"
+        if valu is not None and valu.get("frac") is not None and valu["frac"] > dom[3] / HBM_PEAK_GBPS:
+            limited_by = "valu_issue"
         mpix = lambda ms: round(world * img_px / (ms * 1e-3) / 1e6, 1)
         out = {
             "metric": "Mpix/s shaded (fwd+bwd), 240x320x12-SG render layer" if args.config == 2 else "Mpix/s shaded (fwd+bwd), 480x640x24-SG 16x32 render layer (stress config)",
@@ -316,14 +288,15 @@ def main() -> None:
                        "ms_per_step_repetitions": [round(t / args.steps * 1e3, 4) for t in headline_dts],
                        "ms_per_step_layer_only": round(plain_ms, 4), "Mpix_per_s_layer_only": mpix(plain_ms),
                        "ms_per_step_with_render_loss": round(loss_step_ms, 4), "Mpix_per_s_with_render_loss": mpix(loss_step_ms),
-                       "ms_per_step_hipgraph_replay": None if graph_ms is None else round(graph_ms, 4),
                        "ms_per_step_light_objective_fused": None if obj_ms is None else round(obj_ms, 4),
                        "ms_per_step_light_objective_unfused": None if obj_unfused_ms is None else round(obj_unfused_ms, 4),
-                       "ms_per_step_light_objective_fused_hipgraph_replay": None if obj_graph_ms is None else round(obj_graph_ms, 4),
+                       "config3": cfg3,
                        "parallelism": f"batch-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(dom[3], 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(dom[3] / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": dom[2], "avg_launch_ms": round(dom[1], 4)},
+                         "algorithmic_bytes_per_launch": dom[2], "avg_launch_ms": round(dom[1], 4),
+                         "limited_by": limited_by},
+            "roofline_valu": valu,
             "kernels": {"forward (sgr_fused_fwd)": {"ms": round(fwd_ms, 4), "GBps": round(fwd_gbps, 1), "frac": round(fwd_gbps / HBM_PEAK_GBPS, 4),
                                                        "bytes": fwd_bytes},
                         "backward (sgr_fused_bwd_sg)": {"ms": round(bwd_ms, 4), "GBps": round(bwd_gbps, 1), "frac": round(bwd_gbps / HBM_PEAK_GBPS, 4),
@@ -345,6 +318,89 @@ def main() -> None:
 
     if world > 1:
         dist.destroy_process_group()
+
+
+def valu_roofline(tkey, patterns, live_ms):
+    """`roofline_valu` from profiles/sq.json[tkey] for the first kernel matching `patterns` (the dominant kernel of the line)."""
+    import re
+    path = os.path.join(ROOT, "profiles", "sq.json")
+    if not os.path.isfile(path):
+        return None
+    try:
+        recs = json.load(open(path)).get(tkey, {})
+        for pat in patterns:
+            hits = [n for n in recs if re.search("::" + pat, n)]
+            if not hits:
+                continue
+            n = max(hits, key=lambda h: recs[h].get("valu_busy_cycles_per_simd", 0))
+            r = recs[n]
+            busy, total = r["valu_busy_cycles_per_simd"], r["kernel_cycles"]
+            return {"bound": "valu_issue", "kernel": n.split("::")[-1], "achieved": round(busy), "peak": round(total),
+                    "unit": "SIMD issue cycles per launch (SQ_ACTIVE_INST_VALU x 4 / SIMDs vs GRBM_GUI_ACTIVE / XCDs)",
+                    "frac": round(busy / total, 4), "valu_instructions_per_wave": r.get("valu_insts_per_wave"),
+                    "transcendental_share": r.get("trans_share"), "pmc_kernel_ms": r.get("kernel_ms"), "live_kernel_ms": round(live_ms, 4),
+                    "source": "profiles/sq.json (tools/pmc_sq.sh on this workload; counters are per launch, not re-measured live)"}
+    except Exception:
+        return None
+    return None
+
+
+def config3_legs(pkg, layer, x, ind, bn, R, C, K, steps, barrier) -> dict:
+    """BASELINE config 3 at config-2 shapes: decoder-output tensors as parameters, sgr.light_heads, sgr.light_objective,
+    backward, Adam (trainLight.py:178-181: lr 1e-4 scaled, betas (0.5, 0.999)).  Eager, and the whole step replayed from one
+    HIP graph (fused + capturable Adam: the optimizer's ~30 foreach launches become one kernel, the ~25 small launches of
+    the step lose their gaps)."""
+    dev = x["albedo"].device
+    g = torch.Generator().manual_seed(7)
+    shapes = ((bn, 3 * K, R, C), (bn, K, R, C), (bn, 3 * K, R, C))
+    out = {}
+    for mode in ("eager", "hipgraph"):
+        params = [torch.nn.Parameter((torch.randn(s, generator=g) * 0.5).to(dev)) for s in shapes]
+        opt = torch.optim.Adam(params, lr=1e-3, betas=(0.5, 0.999), fused=True, capturable=(mode == "hipgraph"))
+
+        def one():
+            opt.zero_grad(set_to_none=True)
+            axis, lam, w, _ = pkg.light_heads(params[0], params[1], params[2])
+            total = pkg.light_objective(layer, x["albedo"], x["normal"], x["rough"], axis, lam, w, x["im"], x["seg"], x["env_gt"], ind, 1.0, 10.0)[0]
+            total.backward()
+            opt.step()
+            return total
+
+        if mode == "eager":
+            for _ in range(3):
+                one()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                one()
+            barrier()
+            out["ms_per_step_config3"] = round((time.perf_counter() - t0) / steps * 1e3, 4)
+        else:
+            try:
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        one()
+                torch.cuda.current_stream(dev).wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    static_total = one()
+                graph.replay()
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    graph.replay()
+                barrier()
+                out["ms_per_step_config3_hipgraph"] = round((time.perf_counter() - t0) / steps * 1e3, 4)
+                out["objective_after_replays"] = round(float(static_total.item()), 6)
+                del graph
+            except Exception as exc:
+                out["ms_per_step_config3_hipgraph"] = None
+                out["hipgraph_error"] = str(exc)[:160]
+    out["step"] = ("light_heads -> light_objective (fused) -> backward -> Adam(fused) over 3 decoder-output tensors "
+                   f"({sum(torch.Size(s).numel() for s in shapes) * 4 / 1e6:.0f} MB), batch {bn}")
+    return out
 
 
 def eager_gpu_baseline(O, dev, imH, imW, R, C, K, eh, ew) -> dict:

@@ -164,10 +164,12 @@ int sgr_render_loss_bwd(const float* g_num, const float* diffuse, const float* s
                         float* g_diffuse, float* g_spec, int bn, int R, int C, void* stream);
 
 /* The two steps around the all-reduce of `parts` under batch sharding, kept on the device:
- *   sgr_loss_finalize:  out[0] = parts[0] / max(parts[1], 1e-5) / divisor  (renderErr, wrapperBRDFLight.py:192,205-207:
- *                       divisor 3; reconstErr, :179-188: divisor 3 * envHeight * envWidth),  out[1] = d out[0] / d parts[0];
- *   sgr_render_loss_bwd_scaled:  sgr_render_loss_bwd with *g_num = *g_loss * *g_scale (g_scale = &out[1]; NULL = 1). */
-int sgr_loss_finalize(const float* parts /* [2], rank-summed */, float* out /* [2] */, float divisor, void* stream);
+ *   sgr_loss_finalize:  *loss = parts[0] / max(parts[1], 1e-5) / divisor  (renderErr, wrapperBRDFLight.py:192,205-207:
+ *                       divisor 3; reconstErr, :179-188: divisor 3 * envHeight * envWidth),  *scale = d loss / d parts[0]
+ *                       (two separate device scalars: one is returned to the caller, the other kept for the backward pass);
+ *   sgr_render_loss_bwd_scaled:  sgr_render_loss_bwd with *g_num = *g_loss * *g_scale (g_scale = scale; NULL = 1). */
+int sgr_loss_finalize(const float* parts /* [2], rank-summed */, float* loss /* [1] */, float* scale /* [1] */, float divisor, void* stream);
+
 int sgr_render_loss_bwd_scaled(const float* g_loss, const float* g_scale /* nullable */, const float* diffuse, const float* spec,
                                const float* im_small, const float* seg_small, const float* coef,
                                float* g_diffuse, float* g_spec, int bn, int R, int C, void* stream);

@@ -7,16 +7,26 @@
 
 namespace sgr {
 
-static thread_local char g_err[256] = "";
+static thread_local char g_err[384] = "";
+static thread_local char g_foreign[128] = "";     // a HIP error found pending at one of our entry points (not caused by it)
+
+void note_pending_error() {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_foreign, sizeof(g_foreign), " [a HIP error was already pending on this thread when sgrender was entered: %s]", hipGetErrorString(e));
+    if (!g_err[0]) snprintf(g_err, sizeof(g_err), "no sgrender failure%s", g_foreign);
+  }
+}
 
 void set_error(const char* msg) {
-  strncpy(g_err, msg, sizeof(g_err) - 1);
-  g_err[sizeof(g_err) - 1] = 0;
+  snprintf(g_err, sizeof(g_err), "%s%s", msg, g_foreign);
+  g_foreign[0] = 0;
 }
 
 int sgr_check(int hip_rc, const char* who) {
   if (hip_rc != 0) {
-    snprintf(g_err, sizeof(g_err), "%s: %s", who, hipGetErrorString((hipError_t)hip_rc));
+    snprintf(g_err, sizeof(g_err), "%s: %s%s", who, hipGetErrorString((hipError_t)hip_rc), g_foreign);
+    g_foreign[0] = 0;
   }
   return hip_rc;
 }

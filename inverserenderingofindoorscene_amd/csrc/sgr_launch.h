@@ -8,13 +8,16 @@
 namespace sgr {
 void set_error(const char* msg);
 int sgr_check(int hip_rc, const char* who);
+void note_pending_error();
 }  // namespace sgr
 
-// Every entry point starts with SGR_REQUIRE: it also drops a (non-sticky) error some other library left pending on this
-// thread, so that the hipGetLastError() after our own launch reports OUR launch and nothing else.
+// Every entry point starts with SGR_REQUIRE.  Its first act is note_pending_error(): a (non-sticky) HIP error some earlier
+// call on this thread left pending -- ours or another library's -- is taken off the error slot so that the hipGetLastError()
+// after OUR launch reports our launch and nothing else, but it is not discarded: it is remembered (thread-local) and
+// appended to the message of the next failure this library reports, and sgr_last_error() shows it until then.
 #define SGR_REQUIRE(cond, msg)          \
   do {                                  \
-    (void)hipGetLastError();            \
+    ::sgr::note_pending_error();        \
     if (!(cond)) {                      \
       ::sgr::set_error(msg);            \
       return SGR_ERR_BAD_ARG;           \

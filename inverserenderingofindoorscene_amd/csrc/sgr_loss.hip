@@ -187,12 +187,21 @@ __global__ __launch_bounds__(kLossThreads) void loss_stage_d(const float* __rest
 }
 
 // ---- loss value and gradient scale from the (rank-summed) totals: wrapperBRDFLight.py:192,205-207 --------
-//   out[0] = num / max(den, 1e-5) / divisor,   out[1] = d out[0] / d num
-__global__ void loss_finalize(const float* __restrict__ parts, float* __restrict__ out, float divisor) {
-  const float den = fmaxf(parts[1], 1e-5f);
-  out[0] = parts[0] / den / divisor;
-  out[1] = 1.0f / den / divisor;
+//   loss = num / max(den, 1e-5) / divisor,   scale = d loss / d num      (two separate outputs: the host layer returns the
+//   first and saves the second for the backward pass, and they must not share a buffer / version counter)
+__device__ __forceinline__ void finalize_pair(const float num, const float den_raw, float divisor, float* loss, float* scale) {
+  const float den = fmaxf(den_raw, 1e-5f);
+  loss[0] = num / den / divisor;
+  scale[0] = 1.0f / den / divisor;
 }
+__global__ void loss_finalize(const float* __restrict__ parts, float* __restrict__ loss, float* __restrict__ scale, float divisor) {
+  finalize_pair(parts[0], parts[1], divisor, loss, scale);
+}
+
+// (Round 3 measured the four stages in ONE cooperative launch -- per-image device barriers between the passes, the batch fold by
+// the last workgroup: 68-85 us against 29 us for the four launches including their gaps.  The workgroups of an image sit on
+// different XCDs, so every barrier is a device-scope release + acquire, i.e. an L2 write-back and invalidate per workgroup and
+// barrier, which costs more than the launch gaps it removes.  Removed)
 
 // ---- backward: d(num)/d{diffuse, spec} * g_num ------------------------------------------------
 // num = sum (clamp(kd D + ks S, 0, 1) - imS)^2 seg ; kd, ks are constants HERE because the images that define them arrive
@@ -326,9 +335,9 @@ extern "C" int sgr_render_loss_bwd(const float* g_num, const float* diffuse, con
   return sgr_render_loss_bwd_scaled(g_num, nullptr, diffuse, spec, im_small, seg_small, coef, g_diffuse, g_spec, bn, R, C, stream);
 }
 
-extern "C" int sgr_loss_finalize(const float* parts, float* out, float divisor, void* stream) {
-  SGR_REQUIRE(parts && out && divisor > 0.0f, "sgr_loss_finalize: bad argument");
-  hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(1), 0, (hipStream_t)stream, parts, out, divisor);
+extern "C" int sgr_loss_finalize(const float* parts, float* loss, float* scale, float divisor, void* stream) {
+  SGR_REQUIRE(parts && loss && scale && divisor > 0.0f, "sgr_loss_finalize: bad argument");
+  hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(1), 0, (hipStream_t)stream, parts, loss, scale, divisor);
   return sgr_check((int)hipGetLastError(), "sgr_loss_finalize");
 }
 

@@ -130,27 +130,28 @@ class _RenderLoss(torch.autograd.Function):
         rendered = torch.empty_like(im_s)
         coef = torch.empty((bn, 2), device=dev, dtype=torch.float32)
         parts = torch.empty(2, device=dev, dtype=torch.float32)
-        out = torch.empty(2, device=dev, dtype=torch.float32)
+        loss = torch.empty((), device=dev, dtype=torch.float32)      # returned as it is (0-d, no view); `scale` = d loss / d numerator is kept for backward
+        scale = torch.empty(1, device=dev, dtype=torch.float32)      # (separate buffers: no shared version counter)
         ws = _workspace(bn, dev)
         with torch.cuda.device(dev):
             _lib.call("sgr_render_loss_fwd", _ptr(d), _ptr(s), _ptr(im_c), _ptr(seg_c), _ptr(im_s), _ptr(seg_s),
                       _ptr(rendered), _ptr(coef), _ptr(parts), _ptr(ws), bn, R, C, imH, imW, _stream(dev))
             if _sharded(group):
                 dist.all_reduce(parts, op=dist.ReduceOp.SUM, group=group)      # [num, den] of the global batch (RCCL over xGMI)
-            _lib.call("sgr_loss_finalize", _ptr(parts), _ptr(out), 3.0, _stream(dev))
-        ctx.save_for_backward(d, s, im_s, seg_s, coef, out)
+            _lib.call("sgr_loss_finalize", _ptr(parts), _ptr(loss), _ptr(scale), 3.0, _stream(dev))
+        ctx.save_for_backward(d, s, im_s, seg_s, coef, scale)
         ctx.mark_non_differentiable(rendered)
-        return out[0], rendered
+        return loss, rendered
 
     @staticmethod
     def backward(ctx, g_loss, _g_ren):
-        d, s, im_s, seg_s, coef, out = ctx.saved_tensors
+        d, s, im_s, seg_s, coef, scale = ctx.saved_tensors
         dev = d.device
         bn, _, R, C = d.shape
         g_loss = g_loss.contiguous().reshape(1).to(torch.float32)
         g_d, g_s = torch.empty_like(d), torch.empty_like(s)
         with torch.cuda.device(dev):
-            _lib.call("sgr_render_loss_bwd_scaled", _ptr(g_loss), _ptr(out[1:]), _ptr(d), _ptr(s), _ptr(im_s), _ptr(seg_s), _ptr(coef),
+            _lib.call("sgr_render_loss_bwd_scaled", _ptr(g_loss), _ptr(scale), _ptr(d), _ptr(s), _ptr(im_s), _ptr(seg_s), _ptr(coef),
                       _ptr(g_d), _ptr(g_s), bn, R, C, _stream(dev))
         return g_d, g_s, None, None, None, None, None
 

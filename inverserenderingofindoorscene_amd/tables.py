@@ -53,9 +53,12 @@ def packed_direction_table(env_height: int, env_width: int) -> np.ndarray:
     ext[:, 0], ext[:, 1], ext[:, 2] = ca * ca, 2 * ca * sa, sa * sa
     cols[env_width:env_width + 4 * half] = ext.reshape(-1)
     #   at float offset 4*ew: [ew/4][4] = (ca_a, ca_a+1, sa_a, sa_a+1) per azimuth pair (packed-math kernels)
-    if half % 2 == 0:
-        pairs = np.stack([ca[0::2], ca[1::2], sa[0::2], sa[1::2]], axis=1)
-        cols[4 * env_width:4 * env_width + 4 * (half // 2)] = pairs.reshape(-1)
+    #   (an odd half row leaves the last pair half-filled with zeros, exactly like sgr_fill_direction_table; the packed
+    #   kernels only run on envWidth 16 / 32)
+    pairs = np.zeros(((half + 1) // 2, 4))
+    pairs[np.arange(half) // 2, np.arange(half) % 2] = ca
+    pairs[np.arange(half) // 2, 2 + np.arange(half) % 2] = sa
+    cols[4 * env_width:4 * env_width + pairs.size] = pairs.reshape(-1)
     return np.concatenate([gen.reshape(-1), rows.astype(np.float32).reshape(-1), cols.astype(np.float32)])
 
 

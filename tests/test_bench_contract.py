@@ -28,8 +28,8 @@ def test_algorithmic_bytes_match_survey_8d():
 
 def test_traffic_records_are_keyed_by_workload_and_name_the_dispatched_kernels():
     recs = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-    for key, fwd, bwd, alg_fwd, alg_bwd in (("config2_batch16_env", r"::fwd_pk_kernel<12, 2, true, true", r"::sg_bwd_pk_kernel<2, true, true", 616857600, 720076800),
-                                            ("config5_batch4_env", r"::fwd_pk_half_kernel<2, true, true, 2, 12, 32>", r"::sg_bwd_pk_kernel<2, true, true, 32>", 2135654400, 2342092800)):
+    for key, fwd, bwd, alg_fwd, alg_bwd in (("config2_batch16_env", r"::fwd_pk_half_kernel<2, true, true, 3, 6, 16, 2>", r"::sg_bwd_pk_kernel<2, true, true", 616857600, 720076800),
+                                            ("config5_batch4_env", r"::fwd_pk_half_kernel<2, true, true, 2, 12, 32, 1>", r"::sg_bwd_pk_kernel<2, true, true, 32>", 2135654400, 2342092800)):
         assert key in recs, key
         names = list(recs[key])
         f = [n for n in names if re.search(fwd, n)]
@@ -38,3 +38,18 @@ def test_traffic_records_are_keyed_by_workload_and_name_the_dispatched_kernels()
         # measured HBM bytes: never below the algorithmic bytes (minus counter noise), and no gross re-reads
         assert 0.98 * alg_fwd <= recs[key][f[0]]["hbm_bytes"] <= 1.10 * alg_fwd, (key, recs[key][f[0]])
         assert 0.98 * alg_bwd <= recs[key][g[0]]["hbm_bytes"] <= 1.25 * alg_bwd, (key, recs[key][g[0]])
+
+
+def test_sq_records_feed_the_valu_roofline():
+    """profiles/sq.json (tools/pmc_sq.sh): VALU-issue figures of the dispatched kernels per workload; bench.valu_roofline turns the
+    record of the dominant kernel into the `roofline_valu` object of the contract line."""
+    b = _bench()
+    recs = json.load(open(os.path.join(ROOT, "profiles", "sq.json")))
+    for key in ("config2_batch16_env", "config5_batch4_env"):
+        assert key in recs, key
+        v = b.valu_roofline(key, [r"sg_bwd_pk_kernel<"], 0.25)
+        assert v is not None and v["bound"] == "valu_issue" and 0.3 < v["frac"] < 1.0, v
+        assert abs(v["frac"] - v["achieved"] / v["peak"]) < 1e-3
+        f = b.valu_roofline(key, [r"fwd_pk_half_kernel<"], 0.15)
+        assert f is not None and 0.3 < f["frac"] < 1.0, f
+    assert b.valu_roofline("no_such_workload", [r"sg_bwd_pk_kernel<"], 0.25) is None

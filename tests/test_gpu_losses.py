@@ -154,3 +154,27 @@ def test_recon_loss_masks_and_dark_envs(sgr):
     err = sgr.recon_loss(env.cuda(), gt.cuda(), seg.cuda(), ind.cuda(), R, C)
     eo, _, _, _ = O.recon_loss(env.double(), gt.double(), seg.double(), ind.double(), R, C)
     assert abs(err.item() - eo.item()) < 1e-5 * max(1.0, eo.item())
+
+
+def test_render_loss_is_deterministic_and_its_result_may_be_modified_in_place(sgr):
+    """The loss value and the gradient scale the backward pass needs live in separate buffers (they used to be two
+    elements of one, and ``err *= w`` on the returned scalar broke backward); repeated evaluations are bit-identical."""
+    from oracle import sg_oracle as O
+    for bn, imH, imW, R, C in ((16, 240, 320, 120, 160), (3, 18, 26, 9, 13)):
+        inp = O.synthetic_inputs(bn, imH, imW, R, C, 12, seed=5)
+        g = torch.Generator().manual_seed(2)
+        d0, s0 = torch.rand(bn, 3, R, C, generator=g).cuda(), torch.rand(bn, 3, R, C, generator=g).cuda() * 0.3
+        im, seg = inp["im"].cuda(), inp["seg"].cuda()
+
+        def run(scale):
+            d, s = d0.clone().requires_grad_(True), s0.clone().requires_grad_(True)
+            err, ren = sgr.render_loss(d, s, im, seg, R, C)
+            val = err.detach().clone()
+            err *= scale                                      # in place on the returned scalar
+            gd, gs = torch.autograd.grad(err, [d, s])
+            return val, ren, gd, gs
+
+        a, b, c = run(1.0), run(1.0), run(2.0)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+        assert torch.equal(c[0], a[0]) and torch.equal(c[2], 2.0 * a[2]) and torch.equal(c[3], 2.0 * a[3])

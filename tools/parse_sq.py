@@ -1,0 +1,50 @@
+"""Summarise rocprofv3 --pmc SQ passes (tools/pmc_sq.sh) into per-kernel VALU-issue figures per launch.
+
+  valu_busy_cycles_per_simd = SQ_ACTIVE_INST_VALU x 4 / SIMDs      (the counter ticks per SIMD quad while a VALU instruction is in flight)
+  kernel_cycles             = GRBM_GUI_ACTIVE / XCDs               (the kernel's duration in shader-clock cycles; the counter is summed over the 8 XCDs)
+  valu_insts_per_wave       = SQ_INSTS_VALU / SQ_WAVES
+Writes {kernel: {...}} under the workload tag into the target json (profiles/sq.json: what bench.py's `roofline_valu` reads)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+SIMDS, XCDS = 1024, 8
+root, tag, target = sys.argv[1], sys.argv[2], sys.argv[3]
+acc = defaultdict(lambda: defaultdict(list))
+dur = defaultdict(list)
+for f in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if "sgr::" in k:
+            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for f in glob.glob(os.path.join(root, "a", "**", "*kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if "sgr::" in k:
+            dur[k].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-6)
+out = {}
+for k, v in sorted(acc.items()):
+    m = {c: sum(x) / len(x) for c, x in v.items()}
+    if "SQ_ACTIVE_INST_VALU" not in m or "GRBM_GUI_ACTIVE" not in m:
+        continue
+    rec = {"valu_busy_cycles_per_simd": m["SQ_ACTIVE_INST_VALU"] * 4.0 / SIMDS, "kernel_cycles": m["GRBM_GUI_ACTIVE"] / XCDS,
+           "valu_insts_per_wave": round(m["SQ_INSTS_VALU"] / max(m.get("SQ_WAVES", 1.0), 1.0), 1) if "SQ_INSTS_VALU" in m else None,
+           "waves": m.get("SQ_WAVES"), "kernel_ms": round(sum(dur[k]) / len(dur[k]), 4) if dur.get(k) else None,
+           "trans_share": round(m["SQ_INSTS_VALU_TRANS_F32"] / m["SQ_INSTS_VALU"], 4) if m.get("SQ_INSTS_VALU_TRANS_F32") and m.get("SQ_INSTS_VALU") else None,
+           "counters": {c: round(x, 1) for c, x in m.items()}}
+    rec["frac"] = round(rec["valu_busy_cycles_per_simd"] / rec["kernel_cycles"], 4)
+    rec["effective_clock_GHz"] = round(rec["kernel_cycles"] / (rec["kernel_ms"] * 1e6), 3) if rec["kernel_ms"] else None
+    out[k] = rec
+    print(f"{k:72s} VALU-busy {rec['frac']:.3f}  ({rec['valu_busy_cycles_per_simd']:.0f} of {rec['kernel_cycles']:.0f} cycles)  "
+          f"{rec['valu_insts_per_wave']} VALU instr/wave  trans share {rec['trans_share']}  {rec['kernel_ms']} ms  clock {rec['effective_clock_GHz']} GHz")
+try:
+    allrec = json.load(open(target))
+except Exception:
+    allrec = {}
+allrec["_comment"] = ("VALU-issue figures per launch from SQ counters (tools/pmc_sq.sh + tools/parse_sq.py), keyed by workload then kernel; "
+                      "bench.py's roofline_valu reports a figure only for the workload it was measured on")
+allrec[tag] = out
+json.dump(allrec, open(target, "w"), indent=1)
