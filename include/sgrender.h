@@ -213,7 +213,7 @@ int sgr_recon_loss_bwd(const float* g_num, const float* env, const float* env_gt
 
 /* ---- trainLight objective without the env image (fully fused) --------------
  * wrapperBRDFLight.py:172-207 in two heavy passes; neither the predicted env image (:177) nor its
- * cotangent is ever written.  Needs ew == 16 and K <= 12 (sgr_fused_recon_supported; SGR_ERR_UNSUPPORTED
+ * cotangent is ever written.  Needs ew == 16 or 32 and K <= 24 (sgr_fused_recon_supported; SGR_ERR_UNSUPPORTED
  * otherwise -- use sgr_fused_fwd + sgr_recon_loss_* there).  Workspace is shared by the two calls. */
 int sgr_fused_recon_supported(int K, int R, int C, int eh, int ew);
 int sgr_fused_recon_workspace_floats(int bn, int R, int C);

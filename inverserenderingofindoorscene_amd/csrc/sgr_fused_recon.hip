@@ -281,19 +281,70 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_kernel(const Args a) {
 // Per azimuth pair and lobe: 8 packed instructions + 4 v_exp for the exponentials and the partial radiance, 23 packed for the
 // gradient accumulation (the exponentials are kept, u / t are re-formed: registers); per pair 6 swaps + 3 packed adds for the
 // radiance, 6 v_rcp + 6 v_log for loss and cotangent, 6 swaps to hand the cotangents round.
-template <int POOL>
-__global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a) {
-  constexpr int EW = 16, HALF = 8, NP = 4, KPW = 6;
-  __shared__ __attribute__((aligned(16))) float tile[2 * kT32Floats];          // ground-truth rows, double-buffered
+//
+// Round 3: EW = 32 walks a table row as two virtual rows of 8 + 8 directions (tile32_dma_issue_vrow, as sg_bwd_pk_kernel), and
+// NG = 4 lane groups per pixel (one wave = 16 pixels x 4 groups of 6 lobes: lanes pl, pl + 16, pl + 32, pl + 48) carry up to 24
+// lobes -- twelve lobes plus their gradient sets do not fit one lane, and unlike the layer's backward this pass cannot split the
+// lobes over workgroups: the loss cotangent of a direction needs the radiance of ALL lobes.  The groups trade values in two
+// stages, v_permlane32_swap between the halves (as with NG = 2) and gfx950's v_permlane16_swap between the 16-lane rows of a
+// half (swap(D, S): D's odd rows <-> S's even rows), so that group (half, sub) ends up with the total radiance of ONE direction
+// of the azimuth pair -- sign 1 - half, azimuth component 1 - sub -- evaluates loss, reconstruction and render cotangent for
+// it (scalar: the transcendental count per pixel is what it was), and the four cotangents travel back the same way:
+// 6 + 3 swaps for the reduce-scatter, 3 + 6 for the all-gather.
+#ifndef SGR_RECON_FENCES
+#define SGR_RECON_FENCES 1      // loop-body register fences of sg_bwd_recon_pk_kernel: 1 = lobes + row constants (default), 2 = also the BRDF / cotangent constants (round 2: 36 more bytes of scratch, +1 %), 0 = none (op_sel broadcasts get hoisted into register pairs: 543 vs 330 us)
+#endif
+__device__ __forceinline__ void swap16(float& d, float& s) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(d), __float_as_uint(s), false, false);
+  d = __uint_as_float(r[0]);
+  s = __uint_as_float(r[1]);
+}
+// virtual row `vr` of a 16-pixel tile: [3][16 px][16 floats] (3 KB), 16-byte slots XOR-swizzled by (row >> 2) & 3; three DMA instructions
+template <int AUX, int EW>
+__device__ __forceinline__ void tile16_dma_issue_vrow(float* tile, __amdgpu_buffer_rsrc_t rsrc, int p0, int RC, int J, int vr, int lane) {
+  const int e = EW == 16 ? vr : (vr >> 1), q = EW == 16 ? 0 : (vr & 1);
+  const int row = lane >> 2, slot = lane & 3;
+  const int ls = slot ^ ((row >> 2) & 3);                                            // logical 16-byte slot this lane fills
+  const int col = EW == 16 ? 4 * ls : 4 * ls + 8 * q + (ls >= 2 ? 8 : 0);            // slots 0,1: half row 0; slots 2,3: half row 1
+  const int voff = (row * J + col) * 4;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int soff = (int)((((size_t)c * RC + p0) * J + e * EW) * 4);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)(tile + c * 16 * 16), 16, voff, soff, 0, AUX);
+  }
+}
+template <> __device__ __forceinline__ void wait_vmcnt<3>() { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
 
-  const int lane = threadIdx.x, half = lane >> 5, pl = lane & 31;
-  const int own = 1 - half;                         // the half row (sign) this half-wave evaluates the cotangent of
+template <int POOL, int EW = 16, int NG = 2>
+__global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a) {
+  constexpr int HALF = 8, NP = 4, KPW = 6, Q = EW / 16, PXW = kWave / NG;       // PXW pixels per wave
+  constexpr int kTile = 3 * PXW * 16;                                           // floats per ground-truth virtual-row tile
+  __shared__ __attribute__((aligned(16))) float tile[2 * kTile];               // double-buffered
+  static_assert(NG == 2 || NG == 4, "two or four lane groups per pixel");
+
+  const int lane = threadIdx.x, half = lane >> 5, sub = (lane >> 4) & 1, pl = lane & (PXW - 1);
+  const int grp = NG == 2 ? half : (lane >> 4);       // this lane's group of six lobes
+  const int own = 1 - half;                            // the half row (sign) this lane evaluates the cotangent of
+  const int oaz = 1 - sub;                             // NG = 4: and the azimuth component (0: x, 1: y) of the pair
   const int RC = a.R * a.C, K = a.K;
-  const Pix x = locate_group32(a, (int)blockIdx.x);
+  Pix x;
+  x.lane = lane;
+  {
+    const int tiles = (RC + PXW - 1) / PXW;
+    x.b = (int)blockIdx.x / tiles;
+    x.p0 = ((int)blockIdx.x - x.b * tiles) * PXW;
+    x.active = (x.p0 + pl) < RC;
+    x.p = x.active ? (x.p0 + pl) : (RC - 1);
+  }
   const int b = x.b, p = x.p;
+  const int nvr = a.eh * Q;
 
   __amdgpu_buffer_rsrc_t gimg = env_rsrc(a.env_gt + (size_t)b * 3 * RC * a.J, RC, a.J);
-  tile32_dma_issue(tile, gimg, x.p0, RC, a.J, 0, lane);
+  auto issue = [&](float* dst, int vr) {
+    if constexpr (NG == 2) tile32_dma_issue_vrow<SGR_DMA_AUX, EW>(dst, gimg, x.p0, RC, a.J, vr, lane);
+    else tile16_dma_issue_vrow<SGR_DMA_AUX, EW>(dst, gimg, x.p0, RC, a.J, vr, lane);
+  };
+  issue(tile, 0);
 
   float alb[3];
   const Frame f = load_frame<POOL>(a, x, alb);
@@ -324,7 +375,7 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
   f32x2 lossp = splat2(0.0f);
 
   LobesPk<KPW> P;      // axes pre-multiplied by lp = lam * log2e (floored), as in sg_bwd_pk_kernel
-  load_lobes_pk<KPW, true>(a, b, (unsigned)p, x.active, half * KPW, P, false);
+  load_lobes_pk<KPW, true>(a, b, (unsigned)p, x.active, grp * KPW, P, false);
   f32x2 gw0[KPW], gw1[KPW], gw2[KPW], gl[KPW], gz[KPW], gx[KPW], gy[KPW];
 #pragma unroll
   for (int k = 0; k < KPW; ++k) gw0[k] = gw1[k] = gw2[k] = gl[k] = gz[k] = gx[k] = gy[k] = splat2(0.f);
@@ -332,15 +383,15 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
   const SepTable rows = as_sep_table(a.rows);
   const PairTable cpt = as_pair_table(a.cols, EW);
   const XTable xt = (XTable)(a.cols + EW);
-  const int eh = a.eh;
 
   auto row_loop = [&](auto ortho_c) {
     constexpr bool ORTHO = decltype(ortho_c)::value;
-    for (int e = 0; e < eh; ++e) {
-      const float* cur = tile + (e & 1) * kT32Floats;
-      if (e + 1 < eh) {
-        tile32_dma_issue(tile + ((e + 1) & 1) * kT32Floats, gimg, x.p0, RC, a.J, (e + 1) * EW, lane);
-        wait_vmcnt<6>();        // row e has landed; row e+1 stays in flight
+    for (int vr = 0; vr < nvr; ++vr) {
+      const int e = Q == 1 ? vr : (vr >> 1), aoff = Q == 1 ? 0 : (vr & 1) * NP;      // table row; first azimuth pair of this virtual row
+      const float* cur = tile + (vr & 1) * kTile;
+      if (vr + 1 < nvr) {
+        issue(tile + ((vr + 1) & 1) * kTile, vr + 1);
+        if constexpr (NG == 2) wait_vmcnt<6>(); else wait_vmcnt<3>();      // this virtual row has landed; the next stays in flight
       } else {
         wait_vmcnt<0>();
       }
@@ -355,17 +406,23 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
 
 #pragma unroll 1
       for (int ap = 0; ap < NP; ++ap) {
+#if SGR_RECON_FENCES >= 1
         fence_lobes<KPW>(P);
 #pragma unroll
-        for (int mm = 0; mm < KPW / 2; ++mm) { SGR_FENCE2(czr[mm]); SGR_FENCE2(P.lpp[mm]); }
+        for (int mm = 0; mm < KPW / 2; ++mm) { SGR_FENCE2(czr[mm]); }
+#endif
+#if SGR_RECON_FENCES >= 2
+#pragma unroll
+        for (int mm = 0; mm < KPW / 2; ++mm) { SGR_FENCE2(P.lpp[mm]); }
 #pragma unroll
         for (int c = 0; c < 3; ++c) SGR_FENCE2(gds[c]);
         SGR_FENCE2(grec);
         if (ORTHO) { SGR_FENCE2(oq.vB); SGR_FENCE2(oq.ff); SGR_FENCE2(oq.vvk); SGR_FENCE2(orow.nwc); SGR_FENCE2(orow.cvc); }
-        const f32x4 cs = cpt[ap];
+#endif
+        const f32x4 cs = cpt[aoff + ap];
         const f32x2 ca = {cs[0], cs[1]}, sa = {cs[2], cs[3]};
         const f32x2 srv = splat2(sr);
-        // ---- 1. this half's lobes: exponentials and partial radiance of the 4 directions -----------------
+        // ---- 1. this group's lobes: exponentials and partial radiance of the 4 directions -----------------
         f32x2 ep[KPW], em[KPW];
         f32x2 v[2][3];        // [half row][colour], the azimuth pair
 #pragma unroll
@@ -391,34 +448,79 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
           swap32(dy, sy);
           tot[c] = f32x2{dx + sx, dy + sy};
         }
-        // ---- 3. its cotangent: reconstruction term (and loss) + render term --------------------------------
-        float gt[3][2];
-        tile32_read_pair(cur, pl, own * HALF + ap * 2, gt);
-        const f32x2 Pv = pfma(SGR_HI(oq.vB), sa, SGR_LO(oq.vB) * ca);
-        f32x2 wt, sp;
-        shade_pair<ORTHO>(q, oq, rc, orow, own, ca, sa, Pv, xt, ap * 2, wt, sp);
-        f32x2 go[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const f32x2 xx = pfma(splat2(cf), tot[c], splat2(off));
-          const f32x2 r = {__builtin_amdgcn_rcpf(xx.x), __builtin_amdgcn_rcpf(xx.y)};
-          const f32x2 ar = (f32x2{gt[c][0], gt[c][1]} + splat2(off)) * r;
-          const f32x2 dl = {-__builtin_amdgcn_logf(ar.x), -__builtin_amdgcn_logf(ar.y)};   // log2(x / (gt + off))
-          lossp = pfma(dl, dl, lossp);
-          const f32x2 gr = pfma(SGR_HI(gds[c]), sp, SGR_LO(gds[c]));
-          go[c] = pfma(grec * dl, r, wt * gr);
-        }
-        // ---- 4. both half rows' cotangents to all lanes --------------------------------------------------------
         f32x2 g[2][3];
+        if constexpr (NG == 2) {
+          // ---- 3. its cotangent: reconstruction term (and loss) + render term --------------------------------
+          float gt[3][2];
+          tile32_read_pair(cur, pl, own * HALF + ap * 2, gt);
+          const f32x2 Pv = pfma(SGR_HI(oq.vB), sa, SGR_LO(oq.vB) * ca);
+          f32x2 wt, sp;
+          shade_pair<ORTHO>(q, oq, rc, orow, own, ca, sa, Pv, xt, (aoff + ap) * 2, wt, sp);
+          f32x2 go[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          float dx = go[c].x, sx = go[c].x, dy = go[c].y, sy = go[c].y;
-          swap32(dx, sx);
-          swap32(dy, sy);
-          g[1][c] = f32x2{dx, dy};     // from lanes 0..31
-          g[0][c] = f32x2{sx, sy};     // from lanes 32..63
+          for (int c = 0; c < 3; ++c) {
+            const f32x2 xx = pfma(splat2(cf), tot[c], splat2(off));
+            const f32x2 r = {__builtin_amdgcn_rcpf(xx.x), __builtin_amdgcn_rcpf(xx.y)};
+            const f32x2 ar = (f32x2{gt[c][0], gt[c][1]} + splat2(off)) * r;
+            const f32x2 dl = {-__builtin_amdgcn_logf(ar.x), -__builtin_amdgcn_logf(ar.y)};   // log2(x / (gt + off))
+            lossp = pfma(dl, dl, lossp);
+            const f32x2 gr = pfma(SGR_HI(gds[c]), sp, SGR_LO(gds[c]));
+            go[c] = pfma(grec * dl, r, wt * gr);
+          }
+          // ---- 4. both half rows' cotangents to all lanes --------------------------------------------------------
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            float dx = go[c].x, sx = go[c].x, dy = go[c].y, sy = go[c].y;
+            swap32(dx, sx);
+            swap32(dy, sy);
+            g[1][c] = f32x2{dx, dy};     // from lanes 0..31
+            g[0][c] = f32x2{sx, sy};     // from lanes 32..63
+          }
+        } else {
+          // ---- 2b. second stage of the reduce-scatter: rows of 16 lanes.  swap16(D = y totals, S = x totals); D + S leaves
+          // even rows (sub 0) with the full radiance of azimuth y and odd rows with that of azimuth x
+          float t1[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            float d_ = tot[c].y, s_ = tot[c].x;
+            swap16(d_, s_);
+            t1[c] = d_ + s_;
+          }
+          // ---- 3. cotangent of this group's ONE direction (sign own, azimuth 2 (aoff + ap) + oaz): loss, reconstruction, render
+          const int jj = own * HALF + ap * 2 + oaz;
+          const unsigned addr = lds_addr(cur) + (unsigned)(pl * 64) + (unsigned)((((jj >> 2) ^ ((pl >> 2) & 3)) * 4 + (jj & 3)) * 4);
+          float gt[3];
+          asm volatile("ds_read_b32 %0, %1" : "=v"(gt[0]) : "v"(addr) : "memory");
+          asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(gt[1]) : "v"(addr), "n"(1 * 16 * 64) : "memory");
+          asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(gt[2]) : "v"(addr), "n"(2 * 16 * 64) : "memory");
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          const float ca1 = oaz ? ca.y : ca.x, sa1 = oaz ? sa.y : sa.x;
+          float wt1, sp1;
+          shade_dir<ORTHO>(q, rc, own, ca1, sa1, xt, (aoff + ap) * 2 + oaz, wt1, sp1);
+          float go1[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float xx = fmaf(cf, t1[c], off);
+            const float r = __builtin_amdgcn_rcpf(xx);
+            const float dl = -__builtin_amdgcn_logf((gt[c] + off) * r);
+            lossp.x = fmaf(dl, dl, lossp.x);
+            go1[c] = fmaf(grec.x * dl, r, wt1 * fmaf(gds[c].y, sp1, gds[c].x));
+          }
+          // ---- 4. all-gather: rows first (swap16(D = go, S = go): D = the even row's value = azimuth y, S = the odd row's =
+          // azimuth x, in both rows of the half), then the halves
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            float d_ = go1[c], s_ = go1[c];
+            swap16(d_, s_);
+            float dx = s_, sx = s_, dy = d_, sy = d_;
+            swap32(dx, sx);
+            swap32(dy, sy);
+            g[1][c] = f32x2{dx, dy};     // from lanes 0..31
+            g[0][c] = f32x2{sx, sy};     // from lanes 32..63
+          }
         }
-        // ---- 5. this half's lobes: gradient accumulation (sg_bwd_pk_kernel's inner loop with the kept exponentials)
+        // ---- 5. this group's lobes: gradient accumulation (sg_bwd_pk_kernel's inner loop with the kept exponentials)
         const f32x2 sca = srv * ca, ssa = srv * sa;
 #pragma unroll
         for (int k = 0; k < KPW; ++k) {
@@ -441,7 +543,7 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
   };
   if (ortho) row_loop(std::true_type{}); else row_loop(std::false_type{});
 
-  // loss partial of the tile: sum_p m_p sum_{c,j} (ln x - ln(gt+off))^2   (each half holds its half rows' share)
+  // loss partial of the tile: sum_p m_p sum_{c,j} (ln x - ln(gt+off))^2   (each group holds its directions' share)
   {
     float r0 = m * (lossp.x + lossp.y) * (kLn2 * kLn2);
 #pragma unroll
@@ -451,13 +553,13 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
 
   if (x.active) {
     // wave-uniform plane base of lobe slot k + the lane's 32-bit byte offset (see load_lobes_pk)
-    const unsigned o3_own = ((unsigned)(half * KPW * 3 * RC) + (unsigned)p) * 4u, o1_own = ((unsigned)(half * KPW * RC) + (unsigned)p) * 4u;
+    const unsigned o3_own = ((unsigned)(grp * KPW * 3 * RC) + (unsigned)p) * 4u, o1_own = ((unsigned)(grp * KPW * RC) + (unsigned)p) * 4u;
     char* g_axis_b = reinterpret_cast<char*>(a.g_axis + (size_t)b * K * 3 * RC);
     char* g_lamb_b = reinterpret_cast<char*>(a.g_lamb + (size_t)b * K * RC);
     char* g_weight_b = reinterpret_cast<char*>(a.g_weight + (size_t)b * K * 3 * RC);
 #pragma unroll
     for (int k = 0; k < KPW; ++k) {
-      const int kk = half * KPW + k;
+      const int kk = grp * KPW + k;
       if (kk < K) {
         const float lpk = (k & 1) ? P.lpp[k / 2].y : P.lpp[k / 2].x;
         const float w0 = P.w01[k].x, w1 = P.w01[k].y, w2 = (k & 1) ? P.w2p[k / 2].y : P.w2p[k / 2].x;
@@ -505,17 +607,19 @@ __global__ void set_scalar_kernel(float* dst, const float* src) { dst[0] = src[0
 using namespace sgr;
 
 static int recon_tiles(int RC) { return (RC + kWave - 1) / kWave; }
+// fused objective kernels: 8x16-style (envWidth 16) and 16x32-style (envWidth 32) grids, up to 24 lobes
 static bool fused_recon_ok(int K, int R, int C, int eh, int ew) {
   const long long env_bytes = 3LL * R * C * eh * ew * 4;
-  return ew == 16 && K <= 12 && K >= 1 && env_bytes < (1LL << 31);
+  return (ew == 16 || ew == 32) && K <= 24 && K >= 1 && env_bytes < (1LL << 31);
 }
 
 extern "C" int sgr_fused_recon_supported(int K, int R, int C, int eh, int ew) { return fused_recon_ok(K, R, C, eh, ew) ? 1 : 0; }
 
 static int recon_tiles32(int RC) { return (RC + kPx - 1) / kPx; }
-// workspace: [bn] per-image mask sums | [4] scale | [bn,tiles,3] forward partials (tiles32 slots) | [bn,tiles32] loss partials
+static int recon_tiles16(int RC) { return (RC + 15) / 16; }
+// workspace: [bn] per-image mask sums | [4] scale | [bn,tiles32,3] forward partials | [bn,tiles16] loss partials
 extern "C" int sgr_fused_recon_workspace_floats(int bn, int R, int C) {
-  return bn + 4 + bn * recon_tiles32(R * C) * 3 + bn * recon_tiles32(R * C);
+  return bn + 4 + bn * recon_tiles32(R * C) * 3 + bn * recon_tiles16(R * C);
 }
 
 static int fused_fwd_recon_impl(const float* albedo, const float* normal, const float* rough, const float* axis, const float* lamb,
@@ -527,7 +631,7 @@ static int fused_fwd_recon_impl(const float* albedo, const float* normal, const 
                   spec && mask && coef && parts && workspace,
               "sgr_fused_fwd_recon: NULL tensor");
   SGR_REQUIRE(bn > 0 && K > 0 && R > 0 && C > 0 && eh > 0 && ew > 0, "sgr_fused_fwd_recon: non-positive size");
-  SGR_SUPPORTED(fused_recon_ok(K, R, C, eh, ew), "sgr_fused_fwd_recon: needs envWidth 16, SGNum <= 12 (use the unfused calls)");
+  SGR_SUPPORTED(fused_recon_ok(K, R, C, eh, ew), "sgr_fused_fwd_recon: needs envWidth 16 or 32 and SGNum <= 24 (use the unfused calls)");
   if (int rc = check_pool(R, C, imH, imW, "sgr_fused_fwd_recon: BRDF-map / env-grid ratio must be 1 or 2 (pool first)")) return rc;
   Args a{};
   a.albedo = albedo; a.normal = normal; a.rough = rough; a.axis = axis; a.lamb = lamb; a.weight = weight;
@@ -538,14 +642,26 @@ static int fused_fwd_recon_impl(const float* albedo, const float* normal, const 
   a.F0 = F0; a.premap = premap == 1 ? 1 : 0;
   // SGR_F1_MODE=half: half-wave statistics kernel (32-pixel work units); scalar: round 1's one pixel per lane; default: packed fp32
   static const int f1_mode = [] { const char* e = getenv("SGR_F1_MODE"); return !e ? 0 : (!strcmp(e, "half") ? 1 : (!strcmp(e, "scalar") ? 2 : 0)); }();
-  const bool f1_half = f1_mode == 1 && K > 6;
-  const int tiles = f1_half ? recon_tiles32(R * C) : recon_tiles(R * C);
+  const bool wide = K > 12 || ew == 32;      // beyond the 12-lobe 8x16 kernels: packed half-wave statistics kernel (12 lobes per half for K > 12)
+  const bool f1_half = !wide && f1_mode == 1 && K > 6;
+  const int tiles = (f1_half || wide) ? recon_tiles32(R * C) : recon_tiles(R * C);
   float* den_img = workspace;
   float* ws0 = workspace + bn + 4;
   a.ws = ws0;
   const hipStream_t st = (hipStream_t)stream;
   const bool p1 = (imH == R && imW == C);
-  if (f1_half) {
+  if (wide) {
+    const dim3 grid((unsigned)(bn * tiles)), block(kWave);
+#define SGR_LAUNCH_GT(KPW_, EW_)                                                                              \
+    do {                                                                                                      \
+      if (p1) hipLaunchKernelGGL((fwd_pk_half_gt_kernel<1, KPW_, EW_>), grid, block, 0, st, a);               \
+      else hipLaunchKernelGGL((fwd_pk_half_gt_kernel<2, KPW_, EW_>), grid, block, 0, st, a);                  \
+    } while (0)
+    if (K <= 12) SGR_LAUNCH_GT(6, 32);
+    else if (ew == 16) SGR_LAUNCH_GT(12, 16);
+    else SGR_LAUNCH_GT(12, 32);
+#undef SGR_LAUNCH_GT
+  } else if (f1_half) {
     const dim3 grid((unsigned)(bn * tiles)), block(kWave);
     if (p1) hipLaunchKernelGGL((fwd_half_kernel<1, false, true, 2, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((fwd_half_kernel<2, false, true, 2, true>), grid, block, 0, st, a);
@@ -600,7 +716,7 @@ extern "C" int sgr_fused_bwd_recon(const float* albedo, const float* normal, con
               "sgr_fused_bwd_recon: NULL tensor");
   SGR_REQUIRE(bn > 0 && K > 0 && R > 0 && C > 0 && eh > 0 && ew > 0, "sgr_fused_bwd_recon: non-positive size");
   SGR_REQUIRE(premap >= 0 && premap <= 2, "sgr_fused_bwd_recon: premap must be 0, 1 or 2");
-  SGR_SUPPORTED(fused_recon_ok(K, R, C, eh, ew), "sgr_fused_bwd_recon: needs envWidth 16, SGNum <= 12 (use the unfused calls)");
+  SGR_SUPPORTED(fused_recon_ok(K, R, C, eh, ew), "sgr_fused_bwd_recon: needs envWidth 16 or 32 and SGNum <= 24 (use the unfused calls)");
   if (int rc = check_pool(R, C, imH, imW, "sgr_fused_bwd_recon: BRDF-map / env-grid ratio must be 1 or 2 (pool first)")) return rc;
   Args a{};
   a.albedo = albedo; a.normal = normal; a.rough = rough; a.axis = axis; a.lamb = lamb; a.weight = weight;
@@ -610,22 +726,32 @@ extern "C" int sgr_fused_bwd_recon(const float* albedo, const float* normal, con
   set_dims(a, bn, K, R, C, eh, ew, imH, imW);
   a.F0 = F0; a.premap = premap;
   const int tiles32 = recon_tiles32(R * C);
+  const bool four = K > 12;                          // four lane groups of six lobes per pixel: 16 pixels per wave
+  const int tiles = four ? recon_tiles16(R * C) : tiles32;
   float* den_img = workspace;
   float* ws1 = workspace + bn + 4 + (size_t)bn * tiles32 * 3;
   a.ws = ws1; a.den_img = den_img; a.den_global = den_global; a.rec_w3j = rec_weight / (3.0f * (float)(eh * ew));
   const hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((unsigned)(bn * tiles32)), block(kWave);
-  // SGR_B1_MODE=scalar: round 1's kernel; default: the same pass in packed fp32
+  const dim3 grid((unsigned)(bn * tiles)), block(kWave);
+  // SGR_B1_MODE=scalar: round 1's kernel (envWidth 16, SGNum <= 12 only); default: the same pass in packed fp32
   static const bool b1_scalar = [] { const char* e = getenv("SGR_B1_MODE"); return e && !strcmp(e, "scalar"); }();
   const bool p1 = (imH == R && imW == C);
-  if (b1_scalar) {
+  if (b1_scalar && !four && ew == 16) {
     if (p1) hipLaunchKernelGGL((sg_bwd_recon_kernel<1>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((sg_bwd_recon_kernel<2>), grid, block, 0, st, a);
   } else {
-    if (p1) hipLaunchKernelGGL((sg_bwd_recon_pk_kernel<1>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((sg_bwd_recon_pk_kernel<2>), grid, block, 0, st, a);
+#define SGR_LAUNCH_BR(EW_, NG_)                                                                              \
+    do {                                                                                                     \
+      if (p1) hipLaunchKernelGGL((sg_bwd_recon_pk_kernel<1, EW_, NG_>), grid, block, 0, st, a);              \
+      else hipLaunchKernelGGL((sg_bwd_recon_pk_kernel<2, EW_, NG_>), grid, block, 0, st, a);                 \
+    } while (0)
+    if (!four && ew == 16) SGR_LAUNCH_BR(16, 2);
+    else if (!four) SGR_LAUNCH_BR(32, 2);
+    else if (ew == 16) SGR_LAUNCH_BR(16, 4);
+    else SGR_LAUNCH_BR(32, 4);
+#undef SGR_LAUNCH_BR
   }
-  hipLaunchKernelGGL(recon_fold1, dim3(1), dim3(kRThreads), 0, st, ws1, den_img, parts, bn, tiles32);     // parts = (loss numerator, local sum of the env mask)
+  hipLaunchKernelGGL(recon_fold1, dim3(1), dim3(kRThreads), 0, st, ws1, den_img, parts, bn, tiles);     // parts = (loss numerator, local sum of the env mask)
   return sgr_check((int)hipGetLastError(), "sgr_fused_bwd_recon");
 }
 

@@ -450,6 +450,35 @@ __global__ __launch_bounds__(kWave, 2) void fwd_pk_kernel(const Args a) {
 }
 
 
+// EW = 32 (BASELINE config 5's 16 x 32 grid): a table row is walked as Q = 2 "virtual rows" of 8 + 8 directions -- the
+// azimuths [8 q, 8 q + 8) of both half rows -- whose cotangents are gathered into the SAME 16-float-per-pixel LDS tile
+// layout by giving the DMA lanes the matching source columns (two 32-byte pieces per pixel and colour), so the loop body is
+// the EW = 16 one with the azimuth tables indexed at 4 q + ap.  More than 12 lobes: one workgroup per (32-pixel group,
+// group of 12 lobes), the workgroups of a pixel group 8 ids apart (same XCD, shared L2; see sg_bwd_fast_kernel).
+template <int AUX, int EW>
+__device__ __forceinline__ void tile32_dma_issue_vrow(float* tile, __amdgpu_buffer_rsrc_t rsrc, int p0, int RC, int J, int vr, int lane) {
+  if (EW == 16) {
+    tile32_dma_issue<AUX>(tile, rsrc, p0, RC, J, vr * 16, lane);
+  } else {
+    const int e = vr >> 1, q = vr & 1;
+    const int lrow = lane >> 2, slot = lane & 3;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int row = it * 16 + lrow;
+      const int ls = slot ^ ((row >> 2) & 3);                              // logical 16-byte slot this lane fills
+      const int col = 4 * ls + 8 * q + (ls >= 2 ? 8 : 0);                  // slots 0,1: half row 0; slots 2,3: half row 1
+      const int voff = (row * J + col) * 4;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int soff = (int)((((size_t)c * RC + p0) * J + e * 32) * 4);
+        float* dst = tile + (c * kPx + it * 16) * 16;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)dst, 16, voff, soff, 0, AUX);
+      }
+    }
+  }
+}
+
+
 // ============================== forward, half-wave lobe split, packed ==============================================
 // fwd_half_kernel's decomposition (sgr_fast.inl: one wave = 32 pixels x 2 groups of 6 lobes; swap(D = share of half row 1,
 // S = share of half row 0); D + S leaves lanes 0..31 with the radiance of half row 1 and lanes 32..63 with that of half
@@ -463,9 +492,16 @@ __global__ __launch_bounds__(kWave, 2) void fwd_pk_kernel(const Args a) {
 // RPF = table rows per flush of the env tile: 1 = one row (EW floats per pixel and colour: 64-byte segments at EW 16), 2 = two
 // rows (128-byte segments = whole cache lines: the env stores are what bounds the forward once the working set cycles
 // through HBM, and 64-byte segments write at ~3.4 TB/s where 128-byte ones reach ~5, profiles/r02b_storebench*)
-template <int POOL, bool WRITE_ENV, bool DO_RENDER, int KPW, int EW, int RPF = 1>
-__device__ __forceinline__ void fwd_pk_half_body(const Args& a, const Pix x, float* tile) {
-  constexpr int HALF = EW / 2, NQ = HALF / 4, TD = EW * RPF;
+// HAS_GT (fused objective without the env image, any SGNum <= 24 on 16- and 32-wide grids; fwd_pk_kernel<.., HAS_GT> covers
+// SGNum <= 12 on the 8x16 grid): the ground-truth env streams in by LDS-DMA one VIRTUAL row at a time (8 + 8 directions: the
+// azimuths [8 q, 8 q + 8) of both half rows, gathered into the 16-float-per-pixel tile layout of the backward kernels --
+// tile32_dma_issue_vrow; on the 8x16 grid a virtual row is a table row), double-buffered, and each half accumulates
+// <pred, gt>, <pred, pred>, sum gt over the half rows whose totals it holds; `gtile` = 2 x kT32Floats floats of LDS, `unit` =
+// the 32-pixel group's slot in a.ws.
+template <int POOL, bool WRITE_ENV, bool DO_RENDER, int KPW, int EW, int RPF = 1, bool HAS_GT = false>
+__device__ __forceinline__ void fwd_pk_half_body(const Args& a, const Pix x, float* tile, float* gtile = nullptr, int unit = 0) {
+  static_assert(!(HAS_GT && WRITE_ENV), "the statistics variant does not write the env image");
+  constexpr int HALF = EW / 2, NQ = HALF / 4, TD = EW * RPF, Q = EW / 16;
   SGR_TRACE_BEGIN
 
   const int lane = threadIdx.x, half = lane >> 5, pl = lane & 31;
@@ -492,6 +528,10 @@ __device__ __forceinline__ void fwd_pk_half_body(const Args& a, const Pix x, flo
   const size_t img = (size_t)b * 3 * RC * a.J;
   const int eh = a.eh;
   f32x2 dacc[3] = {splat2(0.f), splat2(0.f), splat2(0.f)}, sacc[3] = {splat2(0.f), splat2(0.f), splat2(0.f)};
+  f32x2 s_pg = splat2(0.f), s_pp = splat2(0.f), s_g = splat2(0.f);
+  __amdgpu_buffer_rsrc_t gimg = env_rsrc(HAS_GT ? a.env_gt + img : a.view, RC, a.J);
+  const int nvr = eh * Q;
+  if (HAS_GT) tile32_dma_issue_vrow<SGR_DMA_AUX, EW>(gtile, gimg, x.p0, RC, a.J, 0, lane);
   SGR_TRACE_MARK
 
   auto row_loop = [&](auto ortho_c) {
@@ -507,6 +547,17 @@ __device__ __forceinline__ void fwd_pk_half_body(const Args& a, const Pix x, flo
       OrthoRow orow = make_ortho_row(rc.ro);
 #pragma unroll 1
       for (int aq = 0; aq < NQ; ++aq) {
+        const int vr = e * Q + (aq >> 1);               // virtual row of this quad (two quads each)
+        const float* gcur = gtile + (HAS_GT ? (vr & 1) * kT32Floats : 0);
+        if (HAS_GT && (aq & 1) == 0) {
+          // the next virtual row goes into the other buffer (its last reader finished a virtual row ago); this one has landed
+          if (vr + 1 < nvr) {
+            tile32_dma_issue_vrow<SGR_DMA_AUX, EW>(gtile + ((vr + 1) & 1) * kT32Floats, gimg, x.p0, RC, a.J, vr + 1, lane);
+            wait_vmcnt<6>();
+          } else {
+            wait_vmcnt<0>();
+          }
+        }
         fence_lobes<KPW>(P);
 #pragma unroll
         for (int m = 0; m < KPW / 2; ++m) SGR_FENCE2(Ck[m]);
@@ -561,6 +612,20 @@ __device__ __forceinline__ void fwd_pk_half_body(const Args& a, const Pix x, flo
             }
           }
         }
+        if (HAS_GT) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            float gt[3][2];
+            tile32_read_pair(gcur, pl, own * 8 + (aq & 1) * 4 + 2 * h, gt);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const f32x2 gv = {gt[c][0], gt[c][1]};
+              s_pg = pfma(tot[c][h], gv, s_pg);
+              s_pp = pfma(tot[c][h], tot[c][h], s_pp);
+              s_g += gv;
+            }
+          }
+        }
         if (WRITE_ENV) {
           const float e0[4] = {tot[0][0].x, tot[0][0].y, tot[0][1].x, tot[0][1].y};
           const float e1[4] = {tot[1][0].x, tot[1][0].y, tot[1][1].x, tot[1][1].y};
@@ -577,6 +642,30 @@ __device__ __forceinline__ void fwd_pk_half_body(const Args& a, const Pix x, flo
   };
   if (ortho) row_loop(std::true_type{}); else row_loop(std::false_type{});
 
+  if (HAS_GT) {
+    // each half holds the statistics of its half rows: add the two, then env mask of the pixel (wrapperBRDFLight.py:172-174) and
+    // the wave's share of the per-image sums (lower half only: both halves now hold the same totals)
+    float st[3] = {s_pg.x + s_pg.y, s_pp.x + s_pp.y, s_g.x + s_g.y};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float d_ = st[i], s_ = st[i];
+      swap32(d_, s_);
+      st[i] = d_ + s_;
+    }
+    const float not_dark = (st[2] / (3.0f * (float)a.J)) > 0.001f ? 1.0f : 0.0f;
+    const float m = x.active ? (a.seg_small + (size_t)b * RC)[(unsigned)p] * a.env_ind[b] * not_dark : 0.0f;
+    if (x.active && half == 0) (a.mask + (size_t)b * RC)[(unsigned)p] = m;
+    const float hm = half == 0 ? m : 0.0f;
+    float r0 = hm * m * st[0], r1 = hm * m * st[1], r2 = hm;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      r0 += __shfl_xor(r0, off, 64); r1 += __shfl_xor(r1, off, 64); r2 += __shfl_xor(r2, off, 64);
+    }
+    if (lane == 0) {
+      float* w = a.ws + (size_t)unit * 3;
+      w[0] = r0; w[1] = r1; w[2] = r2;
+    }
+  }
   if (DO_RENDER) {
     // each half integrated one half row: add the two
     float v[6] = {dacc[0].x + dacc[0].y, dacc[1].x + dacc[1].y, dacc[2].x + dacc[2].y, sacc[0].x + sacc[0].y, sacc[1].x + sacc[1].y, sacc[2].x + sacc[2].y};
@@ -604,6 +693,12 @@ __global__ __launch_bounds__(kWave, OCC) void fwd_pk_half_kernel(const Args a) {
   __shared__ __attribute__((aligned(16))) float tile[WRITE_ENV ? T32Out<EW * RPF>::kFloats : 4];
   fwd_pk_half_body<POOL, WRITE_ENV, DO_RENDER, KPW, EW, RPF>(a, locate_group32(a, (int)blockIdx.x), tile);
 }
+// the statistics variant (fused light objective): render + <pred, gt>, <pred, pred>, sum gt against the streamed ground truth
+template <int POOL, int KPW, int EW>
+__global__ __launch_bounds__(kWave, 2) void fwd_pk_half_gt_kernel(const Args a) {
+  __shared__ __attribute__((aligned(16))) float gtile[2 * kT32Floats];
+  fwd_pk_half_body<POOL, false, true, KPW, EW, 1, true>(a, locate_group32(a, (int)blockIdx.x), nullptr, gtile, (int)blockIdx.x);
+}
 
 
 // ============================== backward w.r.t. the SG parameters, half-wave, packed ===============
@@ -626,34 +721,6 @@ __device__ __forceinline__ void tile32_read_two_pairs2(const float* tile, int pl
   asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(gB[2]) : "v"(aB), "n"(2 * kPx * 64) : "memory");
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
-}
-
-// EW = 32 (BASELINE config 5's 16 x 32 grid): a table row is walked as Q = 2 "virtual rows" of 8 + 8 directions -- the
-// azimuths [8 q, 8 q + 8) of both half rows -- whose cotangents are gathered into the SAME 16-float-per-pixel LDS tile
-// layout by giving the DMA lanes the matching source columns (two 32-byte pieces per pixel and colour), so the loop body is
-// the EW = 16 one with the azimuth tables indexed at 4 q + ap.  More than 12 lobes: one workgroup per (32-pixel group,
-// group of 12 lobes), the workgroups of a pixel group 8 ids apart (same XCD, shared L2; see sg_bwd_fast_kernel).
-template <int AUX, int EW>
-__device__ __forceinline__ void tile32_dma_issue_vrow(float* tile, __amdgpu_buffer_rsrc_t rsrc, int p0, int RC, int J, int vr, int lane) {
-  if (EW == 16) {
-    tile32_dma_issue<AUX>(tile, rsrc, p0, RC, J, vr * 16, lane);
-  } else {
-    const int e = vr >> 1, q = vr & 1;
-    const int lrow = lane >> 2, slot = lane & 3;
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int row = it * 16 + lrow;
-      const int ls = slot ^ ((row >> 2) & 3);                              // logical 16-byte slot this lane fills
-      const int col = 4 * ls + 8 * q + (ls >= 2 ? 8 : 0);                  // slots 0,1: half row 0; slots 2,3: half row 1
-      const int voff = (row * J + col) * 4;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const int soff = (int)((((size_t)c * RC + p0) * J + e * 32) * 4);
-        float* dst = tile + (c * kPx + it * 16) * 16;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)dst, 16, voff, soff, 0, AUX);
-      }
-    }
-  }
 }
 
 template <int POOL, bool HAS_GENV, bool HAS_RENDER, int EW = 16>

@@ -264,7 +264,8 @@ def recon_loss(envmapsPredImage, envmapsBatch, segBRDFBatch, envmapsIndBatch, en
 # the whole trainLight objective, env image never materialised                 #
 # --------------------------------------------------------------------------- #
 def light_objective_supported(SGNum: int, envRow: int, envCol: int, envHeight: int = 8, envWidth: int = 16) -> bool:
-    """Whether :func:`light_objective` has a fused kernel for this configuration (envWidth 16, SGNum <= 12)."""
+    """Whether :func:`light_objective` has a fused kernel for this configuration (envWidth 16 or 32, SGNum <= 24: the reference's
+    8x16 training grid and the 16x32 grid of its ground-truth envmaps, BASELINE config 5)."""
     return bool(_lib.load().sgr_fused_recon_supported(int(SGNum), int(envRow), int(envCol), int(envHeight), int(envWidth)))
 
 
@@ -389,7 +390,7 @@ def light_objective(renderLayer, albedoPred, normalPred, roughPred, axisPred, la
     ``axisPred, lambPred, weightPred`` are the raw decoder outputs (pre-tan), exactly what
     ``output2env.output2env`` takes.  Differentiable w.r.t. those three only.
 
-    Configurations without a fused kernel (envWidth != 16 or SGNum > 12, see :func:`light_objective_supported`)
+    Configurations without a fused kernel (envWidth other than 16 / 32 or SGNum > 24, see :func:`light_objective_supported`)
     are evaluated by the unfused HIP kernels (forwardSG + render_loss + recon_loss) with the same return values.
 
     Returns ``(objective, renderErr, reconstErr, renderedImPred, envScale)``; the two error terms are reported

@@ -178,10 +178,54 @@ def test_config5_one_full_image(sgr, g8):
         assert e <= lim, (k, e, e_ref[k])
 
 
+def test_config5_fused_objective_one_full_image(sgr):
+    """The fused light objective at config 5's size and parameters (24 lobes, 16x32: the half-wave statistics forward and the
+    four-lane-group backward): values and SG gradients against the fp64 oracle on the GPU, yardstick = the same objective through
+    the oracle in fp32; and against the unfused HIP pipeline."""
+    from oracle import sg_oracle as O
+    bn, imH, imW, R, C, K, eh, ew = 1, 480, 640, 240, 320, 24, 16, 32
+    assert sgr.light_objective_supported(K, R, C, eh, ew)
+    inp = O.synthetic_inputs(bn, imH, imW, R, C, K, eh, ew, seed=20205)
+    ind = torch.ones(bn, 1, 1, 1)
+    x = {k: v.cuda() for k, v in inp.items()}
+    for k in SG:
+        x[k].requires_grad_(True)
+    layer = sgr.renderingLayer(imWidth=C, imHeight=R, envWidth=ew, envHeight=eh)
+    obj = sgr.light_objective(layer, x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], x["im"], x["seg"], x["env_gt"],
+                              ind.cuda(), 1.0, 10.0)
+    grads = torch.autograd.grad(obj[0], [x[k] for k in SG])
+
+    def objective(dtype):
+        xo = {k: v.to("cuda", dtype) for k, v in inp.items()}
+        for k in SG:
+            xo[k].requires_grad_(True)
+        eo, do, so = O.render_from_sg(xo["albedo"], xo["normal"], xo["rough"], xo["axis"], xo["lamb"], xo["weight"], eh, ew)
+        ro, _, _, _ = O.render_loss(do, so, xo["im"], xo["seg"], R, C)
+        co, _, _, _ = O.recon_loss(eo, xo["env_gt"], xo["seg"], ind.to("cuda", dtype), R, C)
+        return ro.detach(), co.detach(), torch.autograd.grad(ro + 10.0 * co, [xo[k] for k in SG])
+
+    ro, co, g64 = objective(torch.float64)
+    _, _, g32 = objective(torch.float32)
+    assert abs(obj[1].item() - ro.item()) <= 1e-4 * max(1.0, ro.item()) and abs(obj[2].item() - co.item()) <= 1e-4 * max(1.0, co.item())
+    errs = {}
+    for k, a, r, r32 in zip(SG, grads, g64, g32):
+        assert torch.isfinite(a).all(), k
+        errs[k] = (rel_l2(a, r), rel_l2(r32, r))
+        assert errs[k][0] <= tol2(errs[k][1]), (k, errs[k])
+    print("config 5, fused objective, one whole image: SG gradient error vs fp64 oracle / the fp32 oracle's own:", {k: tuple(f"{v:.2e}" for v in e) for k, e in errs.items()})
+    env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=True)
+    r2, _ = sgr.render_loss(d, s, x["im"], x["seg"], R, C)
+    c2 = sgr.recon_loss(env, x["env_gt"], x["seg"], ind.cuda(), R, C)
+    g3 = torch.autograd.grad(r2 + 10.0 * c2, [x[k] for k in SG])
+    for k, ga, gb in zip(SG, grads, g3):
+        assert rel_l2(ga, gb) < 1e-4, (k, rel_l2(ga, gb))
+
+
 def _rand_case(g):
     ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g).item())
     bn, R, C, q = ri(1, 3), ri(3, 13), ri(3, 17), (1, 2)[ri(0, 1)]
-    return dict(bn=bn, R=R, C=C, q=q, K=ri(1, 12), eh=ri(1, 9), benign=bool(ri(0, 1)))
+    wide = bool(ri(0, 1))      # the 16x32-style grid / up to 24 lobes in half of the cases (round 3: fused objective kernels exist for those too)
+    return dict(bn=bn, R=R, C=C, q=q, K=ri(1, 24 if wide else 12), eh=ri(1, 9), ew=32 if wide else 16, benign=bool(ri(0, 1)))
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2])
@@ -194,7 +238,7 @@ def test_randomised_shapes_fixed_seeds(sgr, seed):
     worst = 0.0
     for case in range(8):
         c = _rand_case(g)
-        bn, R, C, K, eh, ew = c["bn"], c["R"], c["C"], c["K"], c["eh"], 16
+        bn, R, C, K, eh, ew = c["bn"], c["R"], c["C"], c["K"], c["eh"], c["ew"]
         inp = O.synthetic_inputs(bn, R * c["q"], C * c["q"], R, C, K, eh, ew, seed=1000 * (seed + 1) + case, benign=c["benign"])
         ind = (torch.rand(bn, 1, 1, 1, generator=g) < 0.8).float()
         x = {k: v.cuda() for k, v in inp.items()}

@@ -49,7 +49,7 @@ def test_light_objective_vs_golden(sgr, golden):
     args = (layer, x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], _t(z, "in_im"), _t(z, "in_seg"),
             _t(z, "in_env_gt"), ind)
     # g2 (4x8 directions) has no fused kernel: light_objective evaluates it with the unfused HIP kernels
-    assert sgr.light_objective_supported(cfg["K"], R, C, cfg["eh"], cfg["ew"]) == (cfg["ew"] == 16 and cfg["K"] <= 12)
+    assert sgr.light_objective_supported(cfg["K"], R, C, cfg["eh"], cfg["ew"]) == (cfg["ew"] in (16, 32) and cfg["K"] <= 24)
     obj, rerr, cerr, ren, coef = sgr.light_objective(*args, 1.0, 10.0)
     r_ref, c_ref = float(z["ref32_render_err"][0]), float(z["ref32_recon_err"][0])
     assert abs(rerr.item() - r_ref) < 1e-4 * max(1.0, r_ref), (name, rerr.item(), r_ref)
@@ -63,17 +63,24 @@ def test_light_objective_vs_golden(sgr, golden):
         assert rel_l2(g.cpu(), ref64) < max(2 * e_ref, 1e-4), (name, k, rel_l2(g.cpu(), ref64), e_ref)
 
 
-@pytest.mark.parametrize("bn,imH,imW,R,C,K,benign", [
-    (2, 12, 20, 12, 20, 12, True),      # q = 1, one partial 64-pixel tile per image
-    (3, 18, 26, 9, 13, 12, False),      # q = 4, odd grid, decoder-range (stress) lobes
-    (2, 10, 14, 10, 14, 5, True),       # SGNum <= 6: the second wave of a workgroup owns no lobes
-    (1, 16, 40, 8, 20, 9, True),        # SGNum between 6 and 12
+@pytest.mark.parametrize("bn,imH,imW,R,C,K,benign,eh,ew", [
+    (2, 12, 20, 12, 20, 12, True, 8, 16),      # q = 1, one partial 64-pixel tile per image
+    (3, 18, 26, 9, 13, 12, False, 8, 16),      # q = 4, odd grid, decoder-range (stress) lobes
+    (2, 10, 14, 10, 14, 5, True, 8, 16),       # SGNum <= 6: the second wave of a workgroup owns no lobes
+    (1, 16, 40, 8, 20, 9, True, 8, 16),        # SGNum between 6 and 12
+    # round 3: the 16x32 grid (table rows as two virtual rows) and up to 24 lobes (four lane groups per pixel in the backward)
+    (2, 12, 20, 6, 10, 12, True, 16, 32),      # config-5 grid, 12 lobes: half-wave statistics kernel, NG = 2 backward on virtual rows
+    (2, 18, 26, 9, 13, 24, False, 16, 32),     # config 5's parameters: 24 lobes, 16x32, ragged 16-pixel tiles, stress lobes
+    (1, 14, 22, 7, 11, 24, True, 8, 16),       # 24 lobes on the 8x16 grid
+    (2, 10, 14, 10, 14, 17, True, 5, 32),      # a partly empty fourth lobe group, odd envHeight, q = 1
+    (1, 12, 16, 6, 8, 7, True, 3, 32),         # 16x32-style grid with few lobes
 ])
-def test_light_objective_vs_oracle(sgr, bn, imH, imW, R, C, K, benign):
+def test_light_objective_vs_oracle(sgr, bn, imH, imW, R, C, K, benign, eh, ew):
     """Values and gradients against the fp64 oracle, with env_ind == 0 images, dark ground-truth cells and
     unequal loss weights; the unfused HIP path (forwardSG + render_loss + recon_loss) must agree too."""
     from oracle import sg_oracle as O
-    eh, ew, fov, F0 = 8, 16, 57.0, 0.05
+    fov, F0 = 57.0, 0.05
+    assert sgr.light_objective_supported(K, R, C, eh, ew)
     inp = O.synthetic_inputs(bn, imH, imW, R, C, K, eh, ew, seed=77 + K, benign=benign)
     inp["env_gt"][0, :, 1:3, 2:6] = 0.0                      # dark cells drop out of the env mask
     ind = torch.ones(bn, 1, 1, 1)
