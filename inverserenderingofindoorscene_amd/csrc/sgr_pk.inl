@@ -272,6 +272,9 @@ __device__ __forceinline__ void shade_pair(const PixLocal& q, const OrthoPix& oq
 #ifndef SGR_PK_BWD_AUX
 #define SGR_PK_BWD_AUX 2   // cache policy of the packed backward's cotangent rows: 2 = non-temporal (read once)
 #endif
+#ifndef SGR_PK_BWD_FENCES
+#define SGR_PK_BWD_FENCES 2      // loop-body register fences of sg_bwd_pk_kernel: 2 = lobes, row constants, BRDF / cotangent constants; 1 = the first two
+#endif
 #ifndef SGR_PK_TJ
 #define SGR_PK_TJ 16      // directions per flushed env tile row: 16 = one table row (64-byte segments), 32 = two rows (128-byte)
 #endif
@@ -809,12 +812,16 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
       for (int ap = 0; ap < NP; ++ap) {
         fence_lobes<KPW>(P);
 #pragma unroll
-        for (int m = 0; m < KPW / 2; ++m) { SGR_FENCE2(czr[m]); SGR_FENCE2(P.lpp[m]); }
+        for (int m = 0; m < KPW / 2; ++m) { SGR_FENCE2(czr[m]); }
+#if SGR_PK_BWD_FENCES >= 2
+#pragma unroll
+        for (int m = 0; m < KPW / 2; ++m) { SGR_FENCE2(P.lpp[m]); }
         if (HAS_RENDER) {
 #pragma unroll
           for (int c = 0; c < 3; ++c) SGR_FENCE2(gds[c]);
           if (ORTHO) { SGR_FENCE2(oq.vB); SGR_FENCE2(oq.ff); SGR_FENCE2(oq.vvk); SGR_FENCE2(orow.nwc); SGR_FENCE2(orow.cvc); }
         }
+#endif
         const f32x4 cs = cpt[aoff + ap];
         const f32x2 ca = {cs[0], cs[1]}, sa = {cs[2], cs[3]};
         f32x2 g[2][3];            // [sign][colour], the azimuth pair (2 ap, 2 ap + 1) of this virtual row

@@ -6,6 +6,9 @@ knobs (read once per process, hence the subprocesses), must pass the same golden
   SGR_FWD_MODE/SGR_BWD_MODE=half3 the same built for 3 waves/SIMD (round 1's defaults; the packed-fp32 kernels are round 2's)
   SGR_FWD_MODE=full               one-pixel-per-lane forward also for the SG -> env call
   SGR_FWD_MODE=pk|pkhalf2|pkhalf3 packed fp32 forward: one pixel per lane / half-wave for every forward variant (the default mixes them)
+  SGR_FWD_MODE=pkhalf2w|pkhalf3w  half-wave with two table rows per env flush (round 3; 3w is the default whenever the env image is written)
+  SGR_BRDF_MODE=scalar|pk         BRDF-map adjoint with the env image given: round 1's scalar kernel / packed, one pixel per lane (default: packed half-wave)
+  SGR_TAN_HANDOFF=1               the fused forward hands the post-tan SG parameters to its backward (premap mode 2; off by default)
   SGR_GENERIC=1                   generic kernels (table-driven, any direction grid) on the reference's grid
   SGR_F1_MODE=half                half-wave statistics kernel in the fused objective's forward (objective tests)
   SGR_F1_MODE/SGR_B1_MODE=scalar  round 1's scalar objective kernels (the packed-fp32 ones are the default)
@@ -30,6 +33,9 @@ SUBSET = "golden or trainlight"
     {"SGR_FWD_MODE": "pk"},
     {"SGR_FWD_MODE": "pkhalf2"},
     {"SGR_FWD_MODE": "pkhalf3"},
+    {"SGR_FWD_MODE": "pkhalf2w"},
+    {"SGR_BRDF_MODE": "scalar"},
+    {"SGR_BRDF_MODE": "pk", "SGR_TAN_HANDOFF": "1"},
     {"SGR_GENERIC": "1"},
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 @pytest.mark.timeout(600)
