@@ -642,7 +642,9 @@ static int fused_fwd_recon_impl(const float* albedo, const float* normal, const 
   a.F0 = F0; a.premap = premap == 1 ? 1 : 0;
   // SGR_F1_MODE=half: half-wave statistics kernel (32-pixel work units); scalar: round 1's one pixel per lane; default: packed fp32
   static const int f1_mode = [] { const char* e = getenv("SGR_F1_MODE"); return !e ? 0 : (!strcmp(e, "half") ? 1 : (!strcmp(e, "scalar") ? 2 : 0)); }();
-  const bool wide = K > 12 || ew == 32;      // beyond the 12-lobe 8x16 kernels: packed half-wave statistics kernel (12 lobes per half for K > 12)
+  // SGR_F1_MODE=pkhalf: the packed half-wave statistics kernel also for 7..12 lobes on the 8x16 grid (3 waves per SIMD)
+  static const bool f1_pkhalf = [] { const char* e = getenv("SGR_F1_MODE"); return e && !strcmp(e, "pkhalf"); }();
+  const bool wide = K > 12 || ew == 32 || (f1_pkhalf && K > 6);      // beyond the 12-lobe 8x16 kernels: packed half-wave statistics kernel (12 lobes per half for K > 12)
   const bool f1_half = !wide && f1_mode == 1 && K > 6;
   const int tiles = (f1_half || wide) ? recon_tiles32(R * C) : recon_tiles(R * C);
   float* den_img = workspace;
@@ -657,7 +659,10 @@ static int fused_fwd_recon_impl(const float* albedo, const float* normal, const 
       if (p1) hipLaunchKernelGGL((fwd_pk_half_gt_kernel<1, KPW_, EW_>), grid, block, 0, st, a);               \
       else hipLaunchKernelGGL((fwd_pk_half_gt_kernel<2, KPW_, EW_>), grid, block, 0, st, a);                  \
     } while (0)
-    if (K <= 12) SGR_LAUNCH_GT(6, 32);
+    if (K <= 12 && ew == 16) {
+      if (p1) hipLaunchKernelGGL((fwd_pk_half_gt_kernel<1, 6, 16, 3>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((fwd_pk_half_gt_kernel<2, 6, 16, 3>), grid, block, 0, st, a);
+    } else if (K <= 12) SGR_LAUNCH_GT(6, 32);
     else if (ew == 16) SGR_LAUNCH_GT(12, 16);
     else SGR_LAUNCH_GT(12, 32);
 #undef SGR_LAUNCH_GT

@@ -697,8 +697,8 @@ __global__ __launch_bounds__(kWave, OCC) void fwd_pk_half_kernel(const Args a) {
   fwd_pk_half_body<POOL, WRITE_ENV, DO_RENDER, KPW, EW, RPF>(a, locate_group32(a, (int)blockIdx.x), tile);
 }
 // the statistics variant (fused light objective): render + <pred, gt>, <pred, pred>, sum gt against the streamed ground truth
-template <int POOL, int KPW, int EW>
-__global__ __launch_bounds__(kWave, 2) void fwd_pk_half_gt_kernel(const Args a) {
+template <int POOL, int KPW, int EW, int OCC = 2>
+__global__ __launch_bounds__(kWave, OCC) void fwd_pk_half_gt_kernel(const Args a) {
   __shared__ __attribute__((aligned(16))) float gtile[2 * kT32Floats];
   fwd_pk_half_body<POOL, false, true, KPW, EW, 1, true>(a, locate_group32(a, (int)blockIdx.x), nullptr, gtile, (int)blockIdx.x);
 }
