@@ -69,7 +69,7 @@ def train(bn=16, steps=10, imH=240, imW=320, R=120, C=160, K=12, eh=8, ew=16, re
     g = torch.Generator().manual_seed(seed + 1)
     params = [torch.nn.Parameter((torch.randn(s, generator=g) * 0.5).to(dev))
               for s in ((bn, K, 3, R, C), (bn, K, R, C), (bn, 3 * K, R, C))]
-    opt = torch.optim.Adam(params, lr=lr, betas=(0.5, 0.999))        # trainLight.py:178-181
+    opt = torch.optim.Adam(params, lr=lr, betas=(0.5, 0.999), fused=True)        # trainLight.py:178-181 (fused: one multi-tensor kernel)
     layer = sgr.renderingLayer(imWidth=C, imHeight=R, envWidth=ew, envHeight=eh)
     hist = []
     warmup = min(3, max(steps - 1, 0))
