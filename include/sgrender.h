@@ -250,6 +250,12 @@ int sgr_fused_bwd_recon(const float* albedo, const float* normal, const float* r
                         int bn, int K, int R, int C, int eh, int ew, int imH, int imW, float F0, int premap,
                         float offset, float rec_weight, void* stream);
 
+/* Tail of the light objective on the device: *recon_err = parts_e[0] / max(parts_e[1], 1e-5) / divisor_e (divisor 3 * eh * ew,
+ * wrapperBRDFLight.py:179-188), *objective = ren_w * *render_err + rec_w * *recon_err (trainLight.py:237).  parts_e = (numerator,
+ * env-mask sum), rank-summed by the caller when the batch is sharded. */
+int sgr_objective_finalize(const float* render_err, const float* parts_e, float ren_w, float rec_w, float divisor_e,
+                           float* objective, float* recon_err, void* stream);
+
 /* Cotangent scaling for gradients produced ahead of the backward call: x[i][0..n[i]) *= *scale / *applied in
  * place (i < count <= 4; x, n are HOST arrays of device pointers / lengths), then *applied = *scale.  Skipped on the
  * device when the two are equal (the cotangent of a scalar objective is normally 1).  No host sync. */

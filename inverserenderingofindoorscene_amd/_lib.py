@@ -52,6 +52,7 @@ SIGNATURES = {
     "sgr_render_loss_fwd": ([_P] * 10 + [_I] * 5 + [_P], c_int),
     "sgr_render_loss_bwd": ([_P] * 8 + [_I] * 3 + [_P], c_int),
     "sgr_loss_finalize": ([_P, _P, _P, _F, _P], c_int),
+    "sgr_objective_finalize": ([_P, _P, _F, _F, _F, _P, _P, _P], c_int),
     "sgr_render_loss_bwd_scaled": ([_P] * 9 + [_I] * 3 + [_P], c_int),
     "sgr_lsregress_coef": ([_P] * 4 + [_I, ctypes.c_longlong, _P], c_int),
     "sgr_lsregress_diffspec_coef": ([_P] * 5 + [_I, _I, _P], c_int),

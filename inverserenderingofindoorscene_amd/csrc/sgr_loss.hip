@@ -198,6 +198,15 @@ __global__ void loss_finalize(const float* __restrict__ parts, float* __restrict
   finalize_pair(parts[0], parts[1], divisor, loss, scale);
 }
 
+// objective = ren_w * renderErr + rec_w * reconstErr with reconstErr = num_e / max(den_e, 1e-5) / divisor_e (trainLight.py:237,
+// wrapperBRDFLight.py:179-188): the tail of sgr.light_objective in one launch instead of a dozen one-element torch kernels
+__global__ void objective_finalize(const float* __restrict__ render_err, const float* __restrict__ parts_e, float ren_w, float rec_w,
+                                   float divisor_e, float* __restrict__ objective, float* __restrict__ recon_err) {
+  const float rec = parts_e[0] / fmaxf(parts_e[1], 1e-5f) / divisor_e;
+  recon_err[0] = rec;
+  objective[0] = ren_w * render_err[0] + rec_w * rec;
+}
+
 // (Round 3 measured the four stages in ONE cooperative launch -- per-image device barriers between the passes, the batch fold by
 // the last workgroup: 68-85 us against 29 us for the four launches including their gaps.  The workgroups of an image sit on
 // different XCDs, so every barrier is a device-scope release + acquire, i.e. an L2 write-back and invalidate per workgroup and
@@ -339,6 +348,13 @@ extern "C" int sgr_loss_finalize(const float* parts, float* loss, float* scale, 
   SGR_REQUIRE(parts && loss && scale && divisor > 0.0f, "sgr_loss_finalize: bad argument");
   hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(1), 0, (hipStream_t)stream, parts, loss, scale, divisor);
   return sgr_check((int)hipGetLastError(), "sgr_loss_finalize");
+}
+
+extern "C" int sgr_objective_finalize(const float* render_err, const float* parts_e, float ren_w, float rec_w, float divisor_e,
+                                      float* objective, float* recon_err, void* stream) {
+  SGR_REQUIRE(render_err && parts_e && objective && recon_err && divisor_e > 0.0f, "sgr_objective_finalize: bad argument");
+  hipLaunchKernelGGL(objective_finalize, dim3(1), dim3(1), 0, (hipStream_t)stream, render_err, parts_e, ren_w, rec_w, divisor_e, objective, recon_err);
+  return sgr_check((int)hipGetLastError(), "sgr_objective_finalize");
 }
 
 extern "C" int sgr_lsregress_coef(const float* pred, const float* gt, float* coef, float* workspace, int bn, long long n,
