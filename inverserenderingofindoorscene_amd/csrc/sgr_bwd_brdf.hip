@@ -445,6 +445,94 @@ __global__ __launch_bounds__(kWave, 2) void brdf_bwd_pk_half_kernel(const Args a
   }
 }
 
+// no env image (the fused API with need_env = False): the radiance of the lane's half row is re-evaluated from the SG lobes -- all
+// KP lobes in every lane, the packed exponent / accumulation code of the forward kernels for ONE sign (so U_ka is not shared
+// between the half rows here: 6 packed + 2 v_exp per lobe and azimuth pair) -- and fed to the packed adjoint
+template <int POOL, int KP>
+__global__ __launch_bounds__(kWave, 2) void brdf_bwd_pk_sg_kernel(const Args a) {
+  constexpr int EW = 16, HALF = 8;
+  const int lane = threadIdx.x, half = lane >> 5;
+  const int own = 1 - half;
+  const Pix x = locate_group32(a, (int)blockIdx.x);
+  const int b = x.b, p = x.p;
+  const int RC = a.R * a.C;
+
+  LobesPk<KP> P;
+  load_lobes_pk<KP, true>(a, b, (unsigned)p, x.active, 0, P, false);
+  float pooled[7];
+  const Frame f = load_frame_pooled<POOL>(a, x, pooled);
+  const size_t o = (size_t)b * 3 * RC + p;
+  const float gD0 = a.g_diffuse[o], gD1 = a.g_diffuse[o + RC], gD2 = a.g_diffuse[o + 2 * (size_t)RC];
+  const float gs0 = a.g_spec[o], gs1 = a.g_spec[o + RC], gs2 = a.g_spec[o + 2 * (size_t)RC];
+  const float gd0 = gD0 * (pooled[0] * kInvPi), gd1 = gD1 * (pooled[1] * kInvPi), gd2 = gD2 * (pooled[2] * kInvPi);
+
+  FrameGradPk gp;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) gp.gN[i] = gp.gcx[i] = gp.gcy[i] = splat2(0.f);
+  gp.galpha2 = gp.gk = gp.gndv = splat2(0.f);
+  f32x2 ds[3] = {splat2(0.f), splat2(0.f), splat2(0.f)};
+  const SepTable rows = as_sep_table(a.rows);
+  const PairTable cpt = as_pair_table(a.cols, EW);
+  const int eh = a.eh;
+
+  for (int e = 0; e < eh; ++e) {
+    const f32x8 row = rows[e];
+    const float cr = row[1], om = row[2];
+    const f32x2 ss = splat2(own ? -row[0] : row[0]);
+    f32x2 Ck[KP / 2];
+#pragma unroll
+    for (int m = 0; m < KP / 2; ++m) Ck[m] = pfma(P.azp[m], splat2(cr), -P.lpp[m]);
+#pragma unroll 1
+    for (int ap = 0; ap < HALF / 2; ++ap) {
+      fence_lobes<KP>(P);
+#pragma unroll
+      for (int m = 0; m < KP / 2; ++m) SGR_FENCE2(Ck[m]);
+      const f32x4 cs = cpt[ap];
+      const f32x2 ca = {cs[0], cs[1]}, sa = {cs[2], cs[3]};
+      f32x2 e0 = splat2(0.f), e1 = splat2(0.f), e2 = splat2(0.f);
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        const f32x2 ck = half_of(Ck[k / 2], k & 1), w2 = half_of(P.w2p[k / 2], k & 1);
+        const f32x2 U = pfma(SGR_HI(P.axy[k]), sa, SGR_LO(P.axy[k]) * ca);
+        const f32x2 t = pfma(ss, U, ck);
+        const f32x2 ex = {fexp2(t.x), fexp2(t.y)};
+        e0 = pfma(SGR_LO(P.w01[k]), ex, e0);
+        e1 = pfma(SGR_HI(P.w01[k]), ex, e1);
+        e2 = pfma(w2, ex, e2);
+      }
+      const f32x2 Ed = splat2(om) * pfma(splat2(gd2), e2, pfma(splat2(gd1), e1, splat2(gd0) * e0));
+      const f32x2 Es = splat2(om) * pfma(splat2(gs2), e2, pfma(splat2(gs1), e1, splat2(gs0) * e0));
+      const f32x2 ndl = brdf_pair_bwd(f, ss * ca, ss * sa, cr, a.F0, Ed, Es, gp);
+      const f32x2 wt = ndl * splat2(om);
+      ds[0] = pfma(wt, e0, ds[0]); ds[1] = pfma(wt, e1, ds[1]); ds[2] = pfma(wt, e2, ds[2]);
+    }
+  }
+
+  FrameGrad g;
+  fold_frame_grad(gp, g);
+  float dsum[3] = {ds[0].x + ds[0].y, ds[1].x + ds[1].y, ds[2].x + ds[2].y};
+  auto both = [](float& v) { float d_ = v, s_ = v; swap32(d_, s_); v = d_ + s_; };
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { both(g.gN[i]); both(g.gcx[i]); both(g.gcy[i]); both(dsum[i]); }
+  both(g.galpha2); both(g.gk); both(g.gndv);
+  float gpn[3], gprho;
+  frame_bwd(pooled[3], pooled[4], pooled[5], pooled[6], f, g, gpn, gprho);
+  if (x.active && half == 0) {
+    const unsigned off = pooled_offset<POOL>(p, a.C, a.imW);
+    const size_t plane = (size_t)a.imH * a.imW;
+    float* ga = a.g_albedo + (size_t)b * 3 * plane;
+    float* gn = a.g_normal + (size_t)b * 3 * plane;
+    float* gr = a.g_rough + (size_t)b * plane;
+    scatter_pooled<POOL>(ga, off, a.imW, gD0 * kInvPi * dsum[0]);
+    scatter_pooled<POOL>(ga + plane, off, a.imW, gD1 * kInvPi * dsum[1]);
+    scatter_pooled<POOL>(ga + 2 * plane, off, a.imW, gD2 * kInvPi * dsum[2]);
+    scatter_pooled<POOL>(gn, off, a.imW, gpn[0]);
+    scatter_pooled<POOL>(gn + plane, off, a.imW, gpn[1]);
+    scatter_pooled<POOL>(gn + 2 * plane, off, a.imW, gpn[2]);
+    scatter_pooled<POOL>(gr, off, a.imW, gprho);
+  }
+}
+
 template <int KP, int POOL, bool FROM_SG>
 static int brdf_launch_vec(const Args& a, hipStream_t st) {
   const dim3 grid = wave_grid(a.bn, a.R, a.C), block(kWave);
@@ -464,6 +552,15 @@ static int brdf_launch(const Args& a, hipStream_t st) {
     else if (mode == 2) hipLaunchKernelGGL((brdf_bwd_pk_kernel<POOL>), wave_grid(a.bn, a.R, a.C), dim3(kWave), 0, st, a);
     else hipLaunchKernelGGL((brdf_bwd_pk_half_kernel<POOL>), dim3((unsigned)(a.bn * ((a.R * a.C + kPx - 1) / kPx))), dim3(kWave), 0, st, a);
     return (int)hipGetLastError();
+  }
+  if (a.K > 0 && a.K <= 12 && a.ew == 16 && !sgr_generic_forced()) {
+    static const bool scalar = [] { const char* e = getenv("SGR_BRDF_MODE"); return e && !strcmp(e, "scalar"); }();
+    if (!scalar) {
+      const dim3 grid((unsigned)(a.bn * ((a.R * a.C + kPx - 1) / kPx))), block(kWave);
+      if (a.K <= 6) hipLaunchKernelGGL((brdf_bwd_pk_sg_kernel<POOL, 6>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((brdf_bwd_pk_sg_kernel<POOL, 12>), grid, block, 0, st, a);
+      return (int)hipGetLastError();
+    }
   }
   if (a.K == 0) return brdf_launch_vec<1, POOL, false>(a, st);
   if (a.K <= 4) return brdf_launch_vec<4, POOL, true>(a, st);

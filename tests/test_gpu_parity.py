@@ -141,6 +141,24 @@ def test_dropin_two_call_backward_vs_golden(sgr, golden):
     _check_grads(name, z, cfg, dict(zip(NAMES, grads)))
 
 
+def test_brdf_grads_without_env_image(sgr, golden):
+    """need_env=False: the BRDF-map adjoint re-evaluates the radiance from the SG lobes (brdf_bwd_pk_sg_kernel on the 8x16 grid)
+    instead of reading the env image -- same gradients as the env-given kernel, and against the fixture like it."""
+    name, z, cfg = golden
+    layer = sgr.renderingLayer(imWidth=cfg["C"], imHeight=cfg["R"], fov=cfg["fov"], F0=cfg["F0"],
+                               envWidth=cfg["ew"], envHeight=cfg["eh"])
+    _, cd, cs = _cotangents(z)
+    out = []
+    for need_env in (False, True):
+        x = _dev_inputs(z, grad=NAMES)
+        env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=need_env)
+        out.append(torch.autograd.grad((d * cd).sum() + (s * cs).sum(), [x[k] for k in NAMES]))
+    mask = torch.from_numpy(_nondegenerate_mask(z, cfg)).cuda()
+    for k, a, b in zip(NAMES, out[0], out[1]):
+        m = mask.expand_as(a) if k == "normal" else torch.ones_like(a, dtype=torch.bool)
+        assert rel_l2(a[m], b[m]) < 2e-5, (name, k, rel_l2(a[m], b[m]))
+
+
 def test_sg_only_grads_like_trainlight(sgr, golden):
     """trainLight mode: only the SG parameters need gradients, no env cotangent."""
     name, z, cfg = golden
