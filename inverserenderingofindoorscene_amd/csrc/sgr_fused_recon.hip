@@ -587,17 +587,18 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
 struct RescaleArgs { float* x[4]; long long n[4]; };
 __global__ __launch_bounds__(256) void rescale_kernel(RescaleArgs r, const float* __restrict__ s, const float* __restrict__ applied) {
   const float f = s[0] / applied[0];
-  if (f == 1.0f) return;
+  if (f == 1.0f) return;                 // the usual case: a handful of workgroups look and leave (grid-stride: the grid is small)
   float* __restrict__ x = r.x[blockIdx.y];
   const long long n = r.n[blockIdx.y];
-  const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i0 >= n) return;
-  if (i0 + 3 < n) {
-    f32x4 v = *reinterpret_cast<f32x4*>(x + i0);
-    v *= f;
-    *reinterpret_cast<f32x4*>(x + i0) = v;
-  } else {
-    for (long long i = i0; i < n; ++i) x[i] *= f;
+  const long long stride = (long long)gridDim.x * 256 * 4;
+  for (long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += stride) {
+    if (i0 + 3 < n) {
+      f32x4 v = *reinterpret_cast<f32x4*>(x + i0);
+      v *= f;
+      *reinterpret_cast<f32x4*>(x + i0) = v;
+    } else {
+      for (long long i = i0; i < n; ++i) x[i] *= f;
+    }
   }
 }
 __global__ void set_scalar_kernel(float* dst, const float* src) { dst[0] = src[0]; }
@@ -775,7 +776,8 @@ extern "C" int sgr_rescale_inplace(float* const* x, const long long* n, int coun
       r.x[i] = x[i]; r.n[i] = n[i];
       nmax = n[i] > nmax ? n[i] : nmax;
     }
-    hipLaunchKernelGGL(rescale_kernel, dim3((unsigned)((nmax + 1023) / 1024), (unsigned)count), dim3(256), 0, st, r, scale, applied);
+    const long long blocks = (nmax + 1023) / 1024;
+    hipLaunchKernelGGL(rescale_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024), (unsigned)count), dim3(256), 0, st, r, scale, applied);
   }
   hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, st, applied, scale);
   return sgr_check((int)hipGetLastError(), "sgr_rescale_inplace");
