@@ -346,7 +346,8 @@ def valu_roofline(tkey, patterns, live_ms):
 
 
 def config3_legs(pkg, layer, x, ind, bn, R, C, K, steps, barrier) -> dict:
-    """BASELINE config 3 at config-2 shapes: decoder-output tensors as parameters, sgr.light_heads, sgr.light_objective,
+    """BASELINE config 3 at config-2 shapes: decoder-output tensors as parameters, sgr.light_objective with the decoders' output
+    activations as the prologue of its kernels (and, for comparison, sgr.light_heads as a standalone pass each way),
     backward, Adam (trainLight.py:178-181: lr 1e-4 scaled, betas (0.5, 0.999)).  Eager, and the whole step replayed from one
     HIP graph (fused + capturable Adam: the optimizer's ~30 foreach launches become one kernel, the ~25 small launches of
     the step lose their gaps)."""
@@ -354,19 +355,24 @@ def config3_legs(pkg, layer, x, ind, bn, R, C, K, steps, barrier) -> dict:
     g = torch.Generator().manual_seed(7)
     shapes = ((bn, 3 * K, R, C), (bn, K, R, C), (bn, 3 * K, R, C))
     out = {}
-    for mode in ("eager", "hipgraph"):
+    for mode in ("eager", "eager_standalone_heads", "hipgraph"):
         params = [torch.nn.Parameter((torch.randn(s, generator=g) * 0.5).to(dev)) for s in shapes]
         opt = torch.optim.Adam(params, lr=1e-3, betas=(0.5, 0.999), fused=True, capturable=(mode == "hipgraph"))
+        prologue = mode != "eager_standalone_heads"
 
         def one():
             opt.zero_grad(set_to_none=True)
-            axis, lam, w, _ = pkg.light_heads(params[0], params[1], params[2])
-            total = pkg.light_objective(layer, x["albedo"], x["normal"], x["rough"], axis, lam, w, x["im"], x["seg"], x["env_gt"], ind, 1.0, 10.0)[0]
+            if prologue:      # the decoders' output activations run inside the objective's two heavy kernels (premap 3)
+                total = pkg.light_objective(layer, x["albedo"], x["normal"], x["rough"], params[0], params[1], params[2], x["im"], x["seg"],
+                                            x["env_gt"], ind, 1.0, 10.0, decoder_outputs=True)[0]
+            else:             # round 2's route: a standalone pass each way
+                axis, lam, w, _ = pkg.light_heads(params[0], params[1], params[2])
+                total = pkg.light_objective(layer, x["albedo"], x["normal"], x["rough"], axis, lam, w, x["im"], x["seg"], x["env_gt"], ind, 1.0, 10.0)[0]
             total.backward()
             opt.step()
             return total
 
-        if mode == "eager":
+        if mode != "hipgraph":
             for _ in range(3):
                 one()
             barrier()
@@ -374,7 +380,7 @@ def config3_legs(pkg, layer, x, ind, bn, R, C, K, steps, barrier) -> dict:
             for _ in range(steps):
                 one()
             barrier()
-            out["ms_per_step_config3"] = round((time.perf_counter() - t0) / steps * 1e3, 4)
+            out["ms_per_step_config3" if prologue else "ms_per_step_config3_standalone_heads"] = round((time.perf_counter() - t0) / steps * 1e3, 4)
         else:
             try:
                 side = torch.cuda.Stream(device=dev)
@@ -398,7 +404,7 @@ def config3_legs(pkg, layer, x, ind, bn, R, C, K, steps, barrier) -> dict:
             except Exception as exc:
                 out["ms_per_step_config3_hipgraph"] = None
                 out["hipgraph_error"] = str(exc)[:160]
-    out["step"] = ("light_heads -> light_objective (fused) -> backward -> Adam(fused) over 3 decoder-output tensors "
+    out["step"] = ("light_objective(decoder_outputs=True: heads as the kernels' prologue) -> backward -> Adam(fused) over 3 decoder-output tensors "
                    f"({sum(torch.Size(s).numel() for s in shapes) * 4 / 1e6:.0f} MB), batch {bn}")
     return out
 

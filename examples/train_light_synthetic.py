@@ -7,7 +7,8 @@ its step (trainLight.py:203-244 -> wrapperBRDFLight.py:158-207) around synthetic
   * "frozen BRDF net outputs": albedo / normal / rough maps (no grad, like trainLight.py:121-144);
   * the light network is replaced by three learnable tensors pushed through decoderLight's output
     activations (models.py:336-346): 1.01*tanh -> unit axes, 0.5*(x+1) clamped to [0,1] for lamb/weight
-    (sgr.light_heads, one HIP pass each way; --torch-heads for the op-by-op torch version);
+    -- by default inside the objective's two heavy kernels (light_objective(decoder_outputs=True), SURVEY.md 8f rank 2);
+    with --unfused as sgr.light_heads, one HIP pass each way; --torch-heads for the op-by-op torch version;
   * step = zero_grad -> objective -> backward -> Adam, the objective being either
       fused (default): sgr.light_objective -- render loss + 10 x log-L2 env reconstruction loss in two heavy
                        kernel passes, the predicted env image never written, or
@@ -79,11 +80,18 @@ def train(bn=16, steps=10, imH=240, imW=320, R=120, C=160, K=12, eh=8, ew=16, re
             torch.cuda.synchronize()
             t0 = time.perf_counter()
         opt.zero_grad()
-        if hip_heads:
+        prologue = hip_heads and fused and sgr.light_objective_supported(K, R, C, eh, ew)
+        if prologue:                   # default: the decoders' output activations run inside the objective's kernels
+            total, render_err, recon_err, _, _ = sgr.light_objective(layer, batch["albedo"], batch["normal"], batch["rough"], params[0],
+                                                                     params[1], params[2], batch["im"], batch["seg"], batch["env_gt"],
+                                                                     batch["env_ind"], renW, recW, decoder_outputs=True)
+        elif hip_heads:
             axis, lam, w, _ = sgr.light_heads(params[0].view(bn, 3 * K, R, C), params[1], params[2])
         else:
             axis, lam, w = decoder_heads(*params)
-        if fused and sgr.light_objective_supported(K, R, C, eh, ew):
+        if prologue:
+            pass
+        elif fused and sgr.light_objective_supported(K, R, C, eh, ew):
             total, render_err, recon_err, _, _ = sgr.light_objective(layer, batch["albedo"], batch["normal"], batch["rough"], axis, lam, w,
                                                                      batch["im"], batch["seg"], batch["env_gt"], batch["env_ind"],
                                                                      renW, recW)

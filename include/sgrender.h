@@ -20,6 +20,11 @@
  *     (output2env.fromSGtoIm); 2 (backward entry points) = they are the post-tan values a forward call returned
  *     (`lamb_tan` / `weight_tan`), and the gradients are still those w.r.t. the RAW inputs -- the backward then
  *     applies the chain rule d tan = 0.999 pi/2 (1 + y^2) from y alone instead of re-evaluating 4K tangents per cell.
+ *     3 (sgr_fused_fwd, sgr_fused_bwd_sg, sgr_fused_fwd_recon(_tan), sgr_fused_bwd_recon; where sgr_heads_prologue_supported
+ *     says so) = `axis` / `lamb` / `weight` are the light decoders' LAST-CONVOLUTION outputs: the output activations of
+ *     models.py:336-346 (1.01 tanh -> unit axis / clamp(0.5 (. + 1), 0, 1)) run as the
+ *     kernels' prologue, then the tan pre-map; the backward entry points return the gradients w.r.t. those raw outputs
+ *     (the heads' chain rule is their epilogue).  Same shapes; no intermediate tensors.
  *
  * Shapes:  bn images; K = SGNum lobes per cell (<= SGR_MAX_LOBES); env grid R x C
  *   (envRow x envCol == the renderingLayer ctor's imHeight x imWidth); J = eh*ew
@@ -33,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SGR_ABI_VERSION 2
+#define SGR_ABI_VERSION 3
 #define SGR_MAX_LOBES 32
 
 #define SGR_OK 0
@@ -157,6 +162,16 @@ int sgr_render_loss_fwd(const float* diffuse, const float* spec, const float* im
                         float* im_small, float* seg_small, float* rendered, float* coef, float* parts,
                         float* workspace, int bn, int R, int C, int imH, int imW, void* stream);
 
+/* The same three passes, with the loss value formed by the third one when the batch is not sharded (no separate
+ * sgr_loss_finalize launch):  *loss = parts[0] / max(parts[1], 1e-5) / divisor,  *scale = d loss / d parts[0]
+ * (wrapperBRDFLight.py:192,205-207: divisor 3).  loss and scale may both be NULL (= sgr_render_loss_fwd: all-reduce
+ * parts over the ranks, then sgr_loss_finalize).  Three launches; the batch totals are folded by the last workgroup of
+ * the third pass to arrive, in a fixed order (bit-reproducible). */
+int sgr_render_loss_fwd_total(const float* diffuse, const float* spec, const float* im, const float* seg,
+                              float* im_small, float* seg_small, float* rendered, float* coef, float* parts,
+                              float* loss /* [1], nullable */, float* scale /* [1], nullable */, float divisor,
+                              float* workspace, int bn, int R, int C, int imH, int imW, void* stream);
+
 /* d parts[0] / d{diffuse, spec} times *g_num (a device scalar); coefficients are constants as in
  * the reference (detached, models.py:54,76; wrapperBRDFLight.py:197-201). */
 int sgr_render_loss_bwd(const float* g_num, const float* diffuse, const float* spec,
@@ -210,6 +225,10 @@ int sgr_recon_loss_fwd(const float* env, const float* env_gt, const float* seg_s
 int sgr_recon_loss_bwd(const float* g_num, const float* env, const float* env_gt, const float* mask,
                        const float* coef, float* g_env,
                        int bn, int R, int C, int eh, int ew, float offset, void* stream);
+
+/* Whether premap = 3 (decoder heads as a prologue, see Conventions) is available for a configuration: envWidth 16 or 32,
+ * 6 < SGNum <= 24, the default kernels (no SGR_*_MODE override). */
+int sgr_heads_prologue_supported(int K, int R, int C, int eh, int ew);
 
 /* ---- trainLight objective without the env image (fully fused) --------------
  * wrapperBRDFLight.py:172-207 in two heavy passes; neither the predicted env image (:177) nor its

@@ -16,7 +16,7 @@ from ctypes import c_char_p, c_float, c_int, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SGR_LIB", os.path.join(_HERE, "libsgrender.so"))
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class SgrenderUnavailable(RuntimeError):
@@ -50,6 +50,7 @@ SIGNATURES = {
     "sgr_render_bwd_brdf": ([_P] * 14 + [_I] * 8 + [_F, _I, _P], c_int),
     "sgr_loss_workspace_floats": ([_I], c_int),
     "sgr_render_loss_fwd": ([_P] * 10 + [_I] * 5 + [_P], c_int),
+    "sgr_render_loss_fwd_total": ([_P] * 11 + [_F, _P] + [_I] * 5 + [_P], c_int),
     "sgr_render_loss_bwd": ([_P] * 8 + [_I] * 3 + [_P], c_int),
     "sgr_loss_finalize": ([_P, _P, _P, _F, _P], c_int),
     "sgr_objective_finalize": ([_P, _P, _F, _F, _F, _P, _P, _P], c_int),
@@ -61,6 +62,7 @@ SIGNATURES = {
     "sgr_recon_loss_fwd": ([_P] * 8 + [_I] * 5 + [_F, _P], c_int),
     "sgr_recon_loss_bwd": ([_P] * 6 + [_I] * 5 + [_F, _P], c_int),
     "sgr_fused_recon_supported": ([_I] * 5, c_int),
+    "sgr_heads_prologue_supported": ([_I] * 5, c_int),
     "sgr_fused_recon_workspace_floats": ([_I, _I, _I], c_int),
     "sgr_fused_fwd_recon": ([_P] * 17 + [_I] * 8 + [_F, _I, _P], c_int),
     "sgr_fused_fwd_recon_tan": ([_P] * 19 + [_I] * 8 + [_F, _I, _P], c_int),

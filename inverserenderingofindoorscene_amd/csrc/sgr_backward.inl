@@ -242,19 +242,23 @@ static int sgbwd_half_launch(const Args& a, hipStream_t st) {
   return (int)hipGetLastError();
 }
 // packed-fp32 half-wave backward (envWidth 16 or 32; one workgroup per 32 pixels and group of 12 lobes), sgr_pk.inl
-template <bool HAS_GENV, bool HAS_RENDER, int EW>
+template <bool HAS_GENV, bool HAS_RENDER, int EW, bool HEADS = false>
 static int sgbwd_pk_launch_ew(const Args& a, hipStream_t st) {
   const int ng = (a.K + 11) / 12;
   const unsigned tiles = (unsigned)(a.bn * ((a.R * a.C + kPx - 1) / kPx));
   const dim3 grid(ng == 1 ? tiles : ((tiles + 7) / 8) * 8 * (unsigned)ng), block(kWave);
   if (!HAS_RENDER || (a.imH == a.R && a.imW == a.C))
-    hipLaunchKernelGGL((sg_bwd_pk_kernel<1, HAS_GENV, HAS_RENDER, EW>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((sg_bwd_pk_kernel<1, HAS_GENV, HAS_RENDER, EW, HEADS>), grid, block, 0, st, a);
   else
-    hipLaunchKernelGGL((sg_bwd_pk_kernel<2, HAS_GENV, HAS_RENDER, EW>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((sg_bwd_pk_kernel<2, HAS_GENV, HAS_RENDER, EW, HEADS>), grid, block, 0, st, a);
   return (int)hipGetLastError();
 }
 template <bool HAS_GENV, bool HAS_RENDER>
 static int sgbwd_pk_launch(const Args& a, hipStream_t st) {
+  if constexpr (HAS_RENDER) {      // premap == 3: the same kernels built with the decoder heads as prologue / epilogue (bwd_heads_ok holds)
+    if (a.premap == 3)
+      return a.ew == 16 ? sgbwd_pk_launch_ew<HAS_GENV, HAS_RENDER, 16, true>(a, st) : sgbwd_pk_launch_ew<HAS_GENV, HAS_RENDER, 32, true>(a, st);
+  }
   return a.ew == 16 ? sgbwd_pk_launch_ew<HAS_GENV, HAS_RENDER, 16>(a, st) : sgbwd_pk_launch_ew<HAS_GENV, HAS_RENDER, 32>(a, st);
 }
 static inline int bwd_mode() {     // 4 packed half-wave (default), 0 split (two waves), 2 / 3 scalar half-wave kernel built for that many waves per SIMD
@@ -286,6 +290,11 @@ static int sgbwd_launch(const Args& a, hipStream_t st) {
     return a.ew == 16 ? sgbwd_fast_launch_pool<16, HAS_GENV, HAS_RENDER>(a, st) : sgbwd_fast_launch_pool<32, HAS_GENV, HAS_RENDER>(a, st);
   if (!HAS_RENDER || (a.imH == a.R && a.imW == a.C)) return sgbwd_launch_k<1, HAS_GENV, HAS_RENDER>(a, st);
   return sgbwd_launch_k<2, HAS_GENV, HAS_RENDER>(a, st);
+}
+
+// premap == 3: see fwd_heads_ok (sgr_forward.inl)
+static inline bool bwd_heads_ok(const Args& a) {
+  return fast_ok(a) && !sgr_generic_forced() && bwd_mode() == 4 && a.K > 6 && a.K <= 24;
 }
 
 static inline int check_pool_b(int R, int C, int imH, int imW, const char* who) {

@@ -593,6 +593,7 @@ extern "C" int sgr_render_bwd_brdf(const float* g_diffuse, const float* g_spec, 
   a.bn = bn; a.K = env ? 0 : K; a.R = R; a.C = C; a.J = eh * ew; a.Jpad = sgr_dirs_padded(a.J); a.imH = imH; a.imW = imW;
   a.rows = reinterpret_cast<const float*>(a.dirs) + 4 * (size_t)a.Jpad;      // separable form of the table (include/sgrender.h)
   a.cols = a.rows + 8 * (size_t)((eh + 1) / 2 * 2);
+  SGR_REQUIRE(premap >= 0 && premap <= 2, "sgr_render_bwd_brdf: premap must be 0, 1 or 2");
   a.F0 = F0; a.premap = premap == 1 ? 1 : 0; a.eh = eh; a.ew = ew;      // 2 = post-tan SG inputs: nothing to pre-map, no SG chain rule here
   const hipStream_t st = (hipStream_t)stream;
   return sgr_check(imH == R ? brdf_launch<1>(a, st) : brdf_launch<2>(a, st), "sgr_render_bwd_brdf");

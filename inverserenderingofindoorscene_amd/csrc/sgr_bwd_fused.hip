@@ -11,7 +11,7 @@ extern "C" int sgr_fused_bwd_sg(const float* g_env, const float* g_diffuse, cons
   SGR_REQUIRE(g_diffuse && g_spec && albedo && normal && rough && axis && lamb && weight && dirs && view && g_axis &&
                   g_lamb && g_weight, "sgr_fused_bwd_sg: NULL tensor");
   SGR_REQUIRE(bn > 0 && K > 0 && R > 0 && C > 0 && eh > 0 && ew > 0, "sgr_fused_bwd_sg: non-positive size");
-  SGR_REQUIRE(premap >= 0 && premap <= 2, "sgr_fused_bwd_sg: premap must be 0, 1 or 2");
+  SGR_REQUIRE(premap >= 0 && premap <= 3, "sgr_fused_bwd_sg: premap must be 0..3");
   if (int rc = check_pool_b(R, C, imH, imW, "sgr_fused_bwd_sg: BRDF-map / env-grid ratio must be 1 or 2 (pool first)")) return rc;
   Args a{};
   a.g_env = g_env; a.g_diffuse = g_diffuse; a.g_spec = g_spec;
@@ -20,6 +20,7 @@ extern "C" int sgr_fused_bwd_sg(const float* g_env, const float* g_diffuse, cons
   a.g_axis = g_axis; a.g_lamb = g_lamb; a.g_weight = g_weight;
   set_dims_b(a, bn, K, R, C, eh, ew, imH, imW);
   a.F0 = F0; a.premap = premap;
+  SGR_SUPPORTED(premap != 3 || bwd_heads_ok(a), "sgr_fused_bwd_sg: premap 3 (decoder heads as a prologue) needs envWidth 16 or 32 and 6 < SGNum <= 24 (sgr_heads_prologue_supported)");
   const hipStream_t st = (hipStream_t)stream;
   return sgr_check(g_env ? sgbwd_launch<true, true>(a, st) : sgbwd_launch<false, true>(a, st), "sgr_fused_bwd_sg");
 }

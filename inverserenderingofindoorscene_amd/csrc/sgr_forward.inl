@@ -175,33 +175,33 @@ static int fwd_half_launch(const Args& a, hipStream_t st) {
   return (int)hipGetLastError();
 }
 // packed-fp32 forward (envWidth 16, SGNum <= 12): one pixel per lane, arithmetic in azimuth pairs (sgr_pk.inl)
-template <int KP, bool WRITE_ENV, bool DO_RENDER>
+template <int KP, bool WRITE_ENV, bool DO_RENDER, bool HEADS = false>
 static int fwd_pk_launch(const Args& a, hipStream_t st) {
   const dim3 grid = wave_grid(a.bn, a.R, a.C), block(kWave);
   if (!DO_RENDER || (a.imH == a.R && a.imW == a.C))
-    hipLaunchKernelGGL((fwd_pk_kernel<KP, 1, WRITE_ENV, DO_RENDER>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((fwd_pk_kernel<KP, 1, WRITE_ENV, DO_RENDER, false, HEADS>), grid, block, 0, st, a);
   else
-    hipLaunchKernelGGL((fwd_pk_kernel<KP, 2, WRITE_ENV, DO_RENDER>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((fwd_pk_kernel<KP, 2, WRITE_ENV, DO_RENDER, false, HEADS>), grid, block, 0, st, a);
   return (int)hipGetLastError();
 }
 // packed half-wave forward (envWidth 16, 6 < SGNum <= 12), OCC resident waves per SIMD
-template <bool WRITE_ENV, bool DO_RENDER, int OCC, int EW = 16, int RPF = 1>
+template <bool WRITE_ENV, bool DO_RENDER, int OCC, int EW = 16, int RPF = 1, bool HEADS = false>
 static int fwd_pk_half_launch(const Args& a, hipStream_t st) {
   const dim3 grid((unsigned)(a.bn * ((a.R * a.C + kPx - 1) / kPx))), block(kWave);
   if (!DO_RENDER || (a.imH == a.R && a.imW == a.C))
-    hipLaunchKernelGGL((fwd_pk_half_kernel<1, WRITE_ENV, DO_RENDER, OCC, 6, EW, RPF>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((fwd_pk_half_kernel<1, WRITE_ENV, DO_RENDER, OCC, 6, EW, RPF, HEADS>), grid, block, 0, st, a);
   else
-    hipLaunchKernelGGL((fwd_pk_half_kernel<2, WRITE_ENV, DO_RENDER, OCC, 6, EW, RPF>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((fwd_pk_half_kernel<2, WRITE_ENV, DO_RENDER, OCC, 6, EW, RPF, HEADS>), grid, block, 0, st, a);
   return (int)hipGetLastError();
 }
 // packed half-wave forward with 12 lobes per half: 12 < SGNum <= 24, envWidth 16 or 32 (config 5)
-template <bool WRITE_ENV, bool DO_RENDER, int EW>
+template <bool WRITE_ENV, bool DO_RENDER, int EW, bool HEADS = false>
 static int fwd_pk_half24_launch(const Args& a, hipStream_t st) {
   const dim3 grid((unsigned)(a.bn * ((a.R * a.C + kPx - 1) / kPx))), block(kWave);
   if (!DO_RENDER || (a.imH == a.R && a.imW == a.C))
-    hipLaunchKernelGGL((fwd_pk_half_kernel<1, WRITE_ENV, DO_RENDER, 2, 12, EW>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((fwd_pk_half_kernel<1, WRITE_ENV, DO_RENDER, 2, 12, EW, 1, HEADS>), grid, block, 0, st, a);
   else
-    hipLaunchKernelGGL((fwd_pk_half_kernel<2, WRITE_ENV, DO_RENDER, 2, 12, EW>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((fwd_pk_half_kernel<2, WRITE_ENV, DO_RENDER, 2, 12, EW, 1, HEADS>), grid, block, 0, st, a);
   return (int)hipGetLastError();
 }
 static inline int fwd_mode() {     // 4 packed (default; 7: one pixel per lane always, 5 / 6: half-wave always), 0 scalar one pixel per lane, 2 / 3 scalar half-wave kernel, -1 round-1 default
@@ -226,6 +226,15 @@ static int fwd_fast_launch(const Args& a, hipStream_t st) {
   // measured at config 2, one pixel per lane / half-wave: in the bench loop (working set cycling through HBM) env + render
   // 239 / 206 us, render only 163 / 172 us; relaunched on the same buffers (tools/kbench, inputs partly cache-resident)
   // env + render 214-223 / 209-219 us, env only 178 / 149 us  ->  half-wave whenever the env image is written
+  if constexpr (DO_RENDER) {
+    // premap == 3 (decoder heads as the prologue; fwd_heads_ok holds): the default kernel of each shape, built with HEADS
+    if (a.premap == 3) {
+      if (a.K > 12) return a.ew == 16 ? fwd_pk_half24_launch<WRITE_ENV, DO_RENDER, 16, true>(a, st) : fwd_pk_half24_launch<WRITE_ENV, DO_RENDER, 32, true>(a, st);
+      if (a.ew == 32) return fwd_pk_half_launch<WRITE_ENV, DO_RENDER, 3, 32, 1, true>(a, st);
+      if constexpr (WRITE_ENV) return fwd_pk_half_launch<WRITE_ENV, DO_RENDER, 3, 16, 2, true>(a, st);
+      return fwd_pk_launch<12, WRITE_ENV, DO_RENDER, true>(a, st);
+    }
+  }
   if (fwd_mode() >= 4 && a.K > 12 && a.K <= 24)      // 24 lobes: 12 per half-wave, packed (config 5: 1.32 -> ms with the scalar 24-lobe kernel)
     return a.ew == 16 ? fwd_pk_half24_launch<WRITE_ENV, DO_RENDER, 16>(a, st) : fwd_pk_half24_launch<WRITE_ENV, DO_RENDER, 32>(a, st);
   if (fwd_mode() >= 4 && a.ew == 32 && a.K > 6 && a.K <= 12)      // 16x32 grid, up to 12 lobes: six per half-wave, packed
@@ -281,6 +290,12 @@ static int fwd_launch(const Args& a, hipStream_t st) {
   if (FROM_SG && fast_ok(a) && a.K <= 24 && !sgr_generic_forced()) return fwd_fast_launch<WRITE_ENV, DO_RENDER>(a, st);
   if (!DO_RENDER || (a.imH == a.R && a.imW == a.C)) return fwd_launch_k<1, FROM_SG, WRITE_ENV, DO_RENDER>(a, st);
   return fwd_launch_k<2, FROM_SG, WRITE_ENV, DO_RENDER>(a, st);
+}
+
+// premap == 3 (the decoder heads as a prologue) is implemented in the packed kernels' lobe loader (sgr_pk.inl) only: the shapes
+// the default dispatch above sends there
+static inline bool fwd_heads_ok(const Args& a) {
+  return fast_ok(a) && !sgr_generic_forced() && fwd_mode() == 4 && a.K > 6 && a.K <= 24;
 }
 
 static inline int check_pool(int R, int C, int imH, int imW, const char* who) {

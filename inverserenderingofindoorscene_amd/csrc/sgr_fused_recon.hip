@@ -315,7 +315,7 @@ __device__ __forceinline__ void tile16_dma_issue_vrow(float* tile, __amdgpu_buff
 }
 template <> __device__ __forceinline__ void wait_vmcnt<3>() { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
 
-template <int POOL, int EW = 16, int NG = 2>
+template <int POOL, int EW = 16, int NG = 2, bool HEADS = false>
 __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a) {
   constexpr int HALF = 8, NP = 4, KPW = 6, Q = EW / 16, PXW = kWave / NG;       // PXW pixels per wave
   constexpr int kTile = 3 * PXW * 16;                                           // floats per ground-truth virtual-row tile
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
   f32x2 lossp = splat2(0.0f);
 
   LobesPk<KPW> P;      // axes pre-multiplied by lp = lam * log2e (floored), as in sg_bwd_pk_kernel
-  load_lobes_pk<KPW, true>(a, b, (unsigned)p, x.active, grp * KPW, P, false);
+  load_lobes_pk<KPW, true, HEADS>(a, b, (unsigned)p, x.active, grp * KPW, P, false);
   f32x2 gw0[KPW], gw1[KPW], gw2[KPW], gl[KPW], gz[KPW], gx[KPW], gy[KPW];
 #pragma unroll
   for (int k = 0; k < KPW; ++k) gw0[k] = gw1[k] = gw2[k] = gl[k] = gz[k] = gx[k] = gy[k] = splat2(0.f);
@@ -565,15 +565,21 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
         const float w0 = P.w01[k].x, w1 = P.w01[k].y, w2 = (k & 1) ? P.w2p[k / 2].y : P.w2p[k / 2].x;
         const float lam = fabsf(lpk) <= kLpFloor ? 0.0f : lpk * kLn2;      // the floor stands for lam == 0
         float glk = (gl[k].x + gl[k].y) * frcp(lpk), q0 = gw0[k].x + gw0[k].y, q1 = gw1[k].x + gw1[k].y, q2 = gw2[k].x + gw2[k].y;
-        if (a.premap) {
+        if (HEADS || a.premap) {
           glk *= premap_grad(lam);
           q0 *= premap_grad(w0); q1 *= premap_grad(w1); q2 *= premap_grad(w2);
         }
+        float gax = lam * (gx[k].x + gx[k].y), gay = lam * (gy[k].x + gy[k].y), gaz = lam * (gz[k].x + gz[k].y);
+        if (HEADS)      // decoder heads as a prologue: their chain rule as the epilogue
+          heads_bwd_lobe(reinterpret_cast<const char*>(a.axis + (size_t)b * K * 3 * RC) + (size_t)k * 3 * RC * 4,
+                         reinterpret_cast<const char*>(a.lamb + (size_t)b * K * RC) + (size_t)k * RC * 4,
+                         reinterpret_cast<const char*>(a.weight + (size_t)b * K * 3 * RC) + (size_t)k * 3 * RC * 4, o3_own, o1_own,
+                         (size_t)RC * 4, gax, gay, gaz, glk, q0, q1, q2);
         char* pa = g_axis_b + (size_t)k * 3 * RC * 4;
         char* pw = g_weight_b + (size_t)k * 3 * RC * 4;
-        *reinterpret_cast<float*>(pa + o3_own) = lam * (gx[k].x + gx[k].y);
-        *reinterpret_cast<float*>(pa + (size_t)RC * 4 + o3_own) = lam * (gy[k].x + gy[k].y);
-        *reinterpret_cast<float*>(pa + (size_t)RC * 8 + o3_own) = lam * (gz[k].x + gz[k].y);
+        *reinterpret_cast<float*>(pa + o3_own) = gax;
+        *reinterpret_cast<float*>(pa + (size_t)RC * 4 + o3_own) = gay;
+        *reinterpret_cast<float*>(pa + (size_t)RC * 8 + o3_own) = gaz;
         *reinterpret_cast<float*>(g_lamb_b + (size_t)k * RC * 4 + o1_own) = glk;
         *reinterpret_cast<float*>(pw + o3_own) = q0;
         *reinterpret_cast<float*>(pw + (size_t)RC * 4 + o3_own) = q1;
@@ -640,7 +646,9 @@ static int fused_fwd_recon_impl(const float* albedo, const float* normal, const 
   a.env_gt = env_gt; a.seg_small = seg_small; a.env_ind = env_ind; a.mask = mask;
   a.lamb_tan = lamb_tan; a.weight_tan = weight_tan;
   set_dims(a, bn, K, R, C, eh, ew, imH, imW);
-  a.F0 = F0; a.premap = premap == 1 ? 1 : 0;
+  a.F0 = F0; a.premap = premap == 1 ? 1 : (premap == 3 ? 3 : 0);
+  SGR_REQUIRE(premap >= 0 && premap <= 3, "sgr_fused_fwd_recon: premap must be 0..3");
+  SGR_SUPPORTED(premap != 3 || (K > 6 && getenv("SGR_F1_MODE") == nullptr), "sgr_fused_fwd_recon: premap 3 (decoder heads as a prologue) needs 6 < SGNum <= 24 and the default kernels");
   // SGR_F1_MODE=half: half-wave statistics kernel (32-pixel work units); scalar: round 1's one pixel per lane; default: packed fp32
   static const int f1_mode = [] { const char* e = getenv("SGR_F1_MODE"); return !e ? 0 : (!strcmp(e, "half") ? 1 : (!strcmp(e, "scalar") ? 2 : 0)); }();
   // SGR_F1_MODE=pkhalf: the packed half-wave statistics kernel also for 7..12 lobes on the 8x16 grid (3 waves per SIMD)
@@ -653,19 +661,23 @@ static int fused_fwd_recon_impl(const float* albedo, const float* normal, const 
   a.ws = ws0;
   const hipStream_t st = (hipStream_t)stream;
   const bool p1 = (imH == R && imW == C);
+  const bool heads = premap == 3;
   if (wide) {
     const dim3 grid((unsigned)(bn * tiles)), block(kWave);
-#define SGR_LAUNCH_GT(KPW_, EW_)                                                                              \
+#define SGR_LAUNCH_GT(KPW_, EW_, OCC_)                                                                        \
     do {                                                                                                      \
-      if (p1) hipLaunchKernelGGL((fwd_pk_half_gt_kernel<1, KPW_, EW_>), grid, block, 0, st, a);               \
-      else hipLaunchKernelGGL((fwd_pk_half_gt_kernel<2, KPW_, EW_>), grid, block, 0, st, a);                  \
+      if (heads) {                                                                                            \
+        if (p1) hipLaunchKernelGGL((fwd_pk_half_gt_kernel<1, KPW_, EW_, OCC_, true>), grid, block, 0, st, a);  \
+        else hipLaunchKernelGGL((fwd_pk_half_gt_kernel<2, KPW_, EW_, OCC_, true>), grid, block, 0, st, a);     \
+      } else {                                                                                                \
+        if (p1) hipLaunchKernelGGL((fwd_pk_half_gt_kernel<1, KPW_, EW_, OCC_>), grid, block, 0, st, a);        \
+        else hipLaunchKernelGGL((fwd_pk_half_gt_kernel<2, KPW_, EW_, OCC_>), grid, block, 0, st, a);           \
+      }                                                                                                       \
     } while (0)
-    if (K <= 12 && ew == 16) {
-      if (p1) hipLaunchKernelGGL((fwd_pk_half_gt_kernel<1, 6, 16, 3>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((fwd_pk_half_gt_kernel<2, 6, 16, 3>), grid, block, 0, st, a);
-    } else if (K <= 12) SGR_LAUNCH_GT(6, 32);
-    else if (ew == 16) SGR_LAUNCH_GT(12, 16);
-    else SGR_LAUNCH_GT(12, 32);
+    if (K <= 12 && ew == 16) SGR_LAUNCH_GT(6, 16, 3);
+    else if (K <= 12) SGR_LAUNCH_GT(6, 32, 2);
+    else if (ew == 16) SGR_LAUNCH_GT(12, 16, 2);
+    else SGR_LAUNCH_GT(12, 32, 2);
 #undef SGR_LAUNCH_GT
   } else if (f1_half) {
     const dim3 grid((unsigned)(bn * tiles)), block(kWave);
@@ -673,7 +685,10 @@ static int fused_fwd_recon_impl(const float* albedo, const float* normal, const 
     else hipLaunchKernelGGL((fwd_half_kernel<2, false, true, 2, true>), grid, block, 0, st, a);
   } else {
     const dim3 grid = wave_grid(bn, R, C), block(kWave);
-    if (f1_mode == 0 && K <= 6) {
+    if (heads) {      // 6 < K <= 12, envWidth 16 (checked above)
+      if (p1) hipLaunchKernelGGL((fwd_pk_kernel<12, 1, false, true, true, true>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((fwd_pk_kernel<12, 2, false, true, true, true>), grid, block, 0, st, a);
+    } else if (f1_mode == 0 && K <= 6) {
       if (p1) hipLaunchKernelGGL((fwd_pk_kernel<6, 1, false, true, true>), grid, block, 0, st, a);
       else hipLaunchKernelGGL((fwd_pk_kernel<6, 2, false, true, true>), grid, block, 0, st, a);
     } else if (f1_mode == 0) {
@@ -721,7 +736,8 @@ extern "C" int sgr_fused_bwd_recon(const float* albedo, const float* normal, con
                   g_axis && g_lamb && g_weight && parts && workspace,
               "sgr_fused_bwd_recon: NULL tensor");
   SGR_REQUIRE(bn > 0 && K > 0 && R > 0 && C > 0 && eh > 0 && ew > 0, "sgr_fused_bwd_recon: non-positive size");
-  SGR_REQUIRE(premap >= 0 && premap <= 2, "sgr_fused_bwd_recon: premap must be 0, 1 or 2");
+  SGR_REQUIRE(premap >= 0 && premap <= 3, "sgr_fused_bwd_recon: premap must be 0..3");
+  SGR_SUPPORTED(premap != 3 || (K > 6 && getenv("SGR_B1_MODE") == nullptr), "sgr_fused_bwd_recon: premap 3 (decoder heads as a prologue) needs 6 < SGNum <= 24 and the default kernels");
   SGR_SUPPORTED(fused_recon_ok(K, R, C, eh, ew), "sgr_fused_bwd_recon: needs envWidth 16 or 32 and SGNum <= 24 (use the unfused calls)");
   if (int rc = check_pool(R, C, imH, imW, "sgr_fused_bwd_recon: BRDF-map / env-grid ratio must be 1 or 2 (pool first)")) return rc;
   Args a{};
@@ -748,8 +764,13 @@ extern "C" int sgr_fused_bwd_recon(const float* albedo, const float* normal, con
   } else {
 #define SGR_LAUNCH_BR(EW_, NG_)                                                                              \
     do {                                                                                                     \
-      if (p1) hipLaunchKernelGGL((sg_bwd_recon_pk_kernel<1, EW_, NG_>), grid, block, 0, st, a);              \
-      else hipLaunchKernelGGL((sg_bwd_recon_pk_kernel<2, EW_, NG_>), grid, block, 0, st, a);                 \
+      if (premap == 3) {                                                                                     \
+        if (p1) hipLaunchKernelGGL((sg_bwd_recon_pk_kernel<1, EW_, NG_, true>), grid, block, 0, st, a);      \
+        else hipLaunchKernelGGL((sg_bwd_recon_pk_kernel<2, EW_, NG_, true>), grid, block, 0, st, a);         \
+      } else {                                                                                               \
+        if (p1) hipLaunchKernelGGL((sg_bwd_recon_pk_kernel<1, EW_, NG_>), grid, block, 0, st, a);            \
+        else hipLaunchKernelGGL((sg_bwd_recon_pk_kernel<2, EW_, NG_>), grid, block, 0, st, a);               \
+      }                                                                                                      \
     } while (0)
     if (!four && ew == 16) SGR_LAUNCH_BR(16, 2);
     else if (!four) SGR_LAUNCH_BR(32, 2);

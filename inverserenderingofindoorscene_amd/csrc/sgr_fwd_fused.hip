@@ -15,7 +15,9 @@ static int fused_fwd_impl(const char* who, const float* albedo, const float* nor
   a.dirs = reinterpret_cast<const float4*>(dirs); a.view = view; a.env_out = env; a.diffuse = diffuse; a.spec = spec;
   a.lamb_tan = lamb_tan; a.weight_tan = weight_tan;
   set_dims(a, bn, K, R, C, eh, ew, imH, imW);
-  a.F0 = F0; a.premap = premap == 1 ? 1 : 0;      // 2 (post-tan inputs, a backward-only distinction) is 0 here
+  a.F0 = F0; a.premap = premap == 1 ? 1 : (premap == 3 ? 3 : 0);      // 2 (post-tan inputs, a backward-only distinction) is 0 here
+  SGR_REQUIRE(premap >= 0 && premap <= 3, "sgr_fused_fwd: premap must be 0..3");
+  SGR_SUPPORTED(premap != 3 || fwd_heads_ok(a), "sgr_fused_fwd: premap 3 (decoder heads as a prologue) needs envWidth 16 or 32 and 6 < SGNum <= 24 (sgr_heads_prologue_supported)");
   const hipStream_t st = (hipStream_t)stream;
   return sgr_check(env ? fwd_launch<true, true, true>(a, st) : fwd_launch<true, false, true>(a, st), who);
 }
@@ -45,3 +47,12 @@ extern "C" int sgr_debug_trace_fwd(void* device_buffer) {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(sgr::g_trace), &device_buffer, sizeof(void*));
 }
 #endif
+
+// Whether premap = 3 (axis / lamb / weight are the light decoders' last-convolution outputs; the heads of models.py:336-346 run as
+// the prologue of the fused kernels and their chain rule as the epilogue of the backward kernels) is available for a configuration
+extern "C" int sgr_heads_prologue_supported(int K, int R, int C, int eh, int ew) {
+  Args a{};
+  set_dims(a, 1, K, R, C, eh, ew, R, C);
+  static const bool recon_default = [] { return getenv("SGR_F1_MODE") == nullptr && getenv("SGR_B1_MODE") == nullptr && getenv("SGR_BWD_MODE") == nullptr; }();
+  return (K > 0 && R > 0 && C > 0 && eh > 0 && ew > 0 && fwd_heads_ok(a) && recon_default) ? 1 : 0;
+}

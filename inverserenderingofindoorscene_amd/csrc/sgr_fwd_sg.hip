@@ -8,6 +8,7 @@ extern "C" int sgr_sg_to_env_fwd(const float* axis, const float* lamb, const flo
   SGR_REQUIRE(axis && lamb && weight && dirs && env, "sgr_sg_to_env_fwd: NULL tensor");
   SGR_REQUIRE(bn > 0 && K > 0 && R > 0 && C > 0 && eh > 0 && ew > 0, "sgr_sg_to_env_fwd: non-positive size");
   SGR_SUPPORTED(K <= SGR_MAX_LOBES, "sgr_sg_to_env_fwd: SGNum > 32 is not supported");
+  SGR_REQUIRE(premap >= 0 && premap <= 2, "sgr_sg_to_env_fwd: premap must be 0, 1 or 2");
   Args a{};
   a.axis = axis; a.lamb = lamb; a.weight = weight; a.dirs = reinterpret_cast<const float4*>(dirs);
   a.env_out = env; a.lamb_tan = lamb_tan; a.weight_tan = weight_tan;
@@ -22,6 +23,7 @@ extern "C" int sgr_sg_shading(const float* axis, const float* lamb, const float*
   SGR_REQUIRE(axis && lamb && weight && dirs && shading, "sgr_sg_shading: NULL tensor");
   SGR_REQUIRE(bn > 0 && K > 0 && R > 0 && C > 0 && eh > 0 && ew > 0, "sgr_sg_shading: non-positive size");
   SGR_SUPPORTED(K <= 24 && (ew == 16 || ew == 32), "sgr_sg_shading: needs envWidth 16 or 32 and SGNum <= 24");
+  SGR_REQUIRE(premap >= 0 && premap <= 2, "sgr_sg_shading: premap must be 0, 1 or 2");
   Args a{};
   a.axis = axis; a.lamb = lamb; a.weight = weight; a.dirs = reinterpret_cast<const float4*>(dirs); a.diffuse = shading;
   set_dims(a, bn, K, R, C, eh, ew, R, C);

@@ -15,6 +15,9 @@ namespace sgr {
 
 constexpr int kLossThreads = 256;
 constexpr int kSplit = 16;           // blocks per image
+#ifndef SGR_LOSS_FENCE
+#define SGR_LOSS_FENCE 0               // 1: __threadfence() around the ticket of loss_stage_c instead of the write-through store + s_waitcnt
+#endif
 
 template <int N>
 __device__ __forceinline__ void block_reduce(float (&v)[N], float* lds /* [4*N] */) {
@@ -36,7 +39,9 @@ __device__ __forceinline__ void block_reduce(float (&v)[N], float* lds /* [4*N] 
   __syncthreads();
 }
 
-// fold the kSplit partials of image b (N values each) in double, fixed order
+// fold the kSplit partials of image b (N values each) in double, fixed order.  (Measured in round 3: 64 blocks per image with
+// a wave-butterfly fold are 2 us SLOWER over the three passes than 16 with this serial one -- the passes are not short of
+// parallelism; what they cost is 13 us of data movement plus three dependent launches at 5-6 us each.)
 template <int N>
 __device__ __forceinline__ void fold(const float* __restrict__ ws, int b, double (&out)[N]) {
 #pragma unroll
@@ -75,10 +80,11 @@ template <int POOL>
 __global__ __launch_bounds__(kLossThreads) void loss_stage_a(const float* __restrict__ diffuse, const float* __restrict__ spec,
                                                               const float* __restrict__ im, const float* __restrict__ seg,
                                                               float* __restrict__ im_s, float* __restrict__ seg_s,
-                                                              float* __restrict__ wsA /* [bn,kSplit,6] */, int R, int C, int imH,
-                                                              int imW) {
+                                                              float* __restrict__ wsA /* [bn,kSplit,6] */, unsigned* __restrict__ ticket,
+                                                              int R, int C, int imH, int imW) {
   __shared__ float lds[4 * 6];
   const int b = blockIdx.y, RC = R * C, n = 3 * RC;
+  if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) ticket[0] = 0u;      // stage C's arrival counter (two kernel boundaries ahead of its use)
   float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const size_t plane = (size_t)imH * imW;
   for (int i = blockIdx.x * kLossThreads + threadIdx.x; i < n; i += kSplit * kLossThreads) {
@@ -127,13 +133,25 @@ __global__ __launch_bounds__(kLossThreads) void loss_stage_b(const float* __rest
   }
 }
 
+// ---- loss value and gradient scale from the (rank-summed) totals: wrapperBRDFLight.py:192,205-207 --------
+//   loss = num / max(den, 1e-5) / divisor,   scale = d loss / d num      (two separate outputs: the host layer returns the
+//   first and saves the second for the backward pass, and they must not share a buffer / version counter)
+__device__ __forceinline__ void finalize_pair(const float num, const float den_raw, float divisor, float* loss, float* scale) {
+  const float den = fmaxf(den_raw, 1e-5f);
+  loss[0] = num / den / divisor;
+  scale[0] = 1.0f / den / divisor;
+}
 // ---- stage C: final coefficients, rendered image, masked squared error -------------------------
 __global__ __launch_bounds__(kLossThreads) void loss_stage_c(const float* __restrict__ diffuse, const float* __restrict__ spec,
                                                               const float* __restrict__ im_s, const float* __restrict__ seg_s,
                                                               const float* __restrict__ wsA, const float* __restrict__ wsB,
                                                               float* __restrict__ coef /* [bn,2] */, float* __restrict__ rendered,
-                                                              float* __restrict__ wsC /* [bn,kSplit] */, int RC) {
+                                                              float* __restrict__ wsC /* [bn,kSplit] */, int RC, unsigned* __restrict__ ticket,
+                                                              float* __restrict__ parts, float* __restrict__ loss, float* __restrict__ scale,
+                                                              float divisor) {
   __shared__ float lds[4];
+  __shared__ double fold_lds[kLossThreads * 2];
+  __shared__ unsigned last;
   const int b = blockIdx.y, n = 3 * RC;
   double sA[6], sB[2];
   fold<6>(wsA, b, sA);
@@ -157,43 +175,48 @@ __global__ __launch_bounds__(kLossThreads) void loss_stage_c(const float* __rest
     acc[0] = fmaf(e * e, seg_s[(size_t)b * RC + p], acc[0]);
   }
   block_reduce<1>(acc, lds);
-  if (threadIdx.x == 0) wsC[(size_t)b * kSplit + blockIdx.x] = acc[0];
-}
-
-// ---- stage D: batch totals [num, den_raw] (this rank's shard) ----------------------------------
-__global__ __launch_bounds__(kLossThreads) void loss_stage_d(const float* __restrict__ wsA, const float* __restrict__ wsC,
-                                                              float* __restrict__ parts, int bn) {
-  // deterministic: thread t adds entries t, t+256, ... in double, then a fixed LDS tree
-  __shared__ double lds[kLossThreads * 2];
-  double num = 0.0, den = 0.0;
-  for (int i = threadIdx.x; i < bn * kSplit; i += kLossThreads) {
-    num += (double)wsC[i];
-    den += (double)wsA[(size_t)i * 6 + 5];
+  // The batch totals [num, den_raw] of this rank's shard, by whichever workgroup arrives last (no fourth launch): every
+  // workgroup publishes its partial at agent scope, then draws a ticket; the holder of the last ticket reads all partials
+  // back -- in index order, in double, through a fixed LDS tree: the result does not depend on which workgroup that is.
+  const int nparts = (int)(gridDim.x * gridDim.y);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&wsC[(size_t)b * kSplit + blockIdx.x], acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if SGR_LOSS_FENCE
+    __threadfence();
+#else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the write-through store has reached the coherence point before the ticket is drawn
+#endif
+    last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nparts - 1) ? 1u : 0u;
   }
-  lds[threadIdx.x * 2] = num;
-  lds[threadIdx.x * 2 + 1] = den;
+  __syncthreads();
+  if (!last) return;
+#if SGR_LOSS_FENCE
+  __threadfence();
+#endif
+  double num = 0.0, den = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += kLossThreads) {
+    num += (double)__hip_atomic_load(&wsC[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    den += (double)wsA[(size_t)i * 6 + 5];                 // stage A's: a kernel boundary away
+  }
+  fold_lds[threadIdx.x * 2] = num;
+  fold_lds[threadIdx.x * 2 + 1] = den;
   __syncthreads();
   for (int s = kLossThreads / 2; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s) {
-      lds[threadIdx.x * 2] += lds[(threadIdx.x + s) * 2];
-      lds[threadIdx.x * 2 + 1] += lds[(threadIdx.x + s) * 2 + 1];
+      fold_lds[threadIdx.x * 2] += fold_lds[(threadIdx.x + s) * 2];
+      fold_lds[threadIdx.x * 2 + 1] += fold_lds[(threadIdx.x + s) * 2 + 1];
     }
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    parts[0] = (float)lds[0];
-    parts[1] = (float)lds[1];
+    const float fnum = (float)fold_lds[0], fden = (float)fold_lds[1];
+    parts[0] = fnum;
+    parts[1] = fden;
+    if (loss) finalize_pair(fnum, fden, divisor, loss, scale);
   }
 }
 
-// ---- loss value and gradient scale from the (rank-summed) totals: wrapperBRDFLight.py:192,205-207 --------
-//   loss = num / max(den, 1e-5) / divisor,   scale = d loss / d num      (two separate outputs: the host layer returns the
-//   first and saves the second for the backward pass, and they must not share a buffer / version counter)
-__device__ __forceinline__ void finalize_pair(const float num, const float den_raw, float divisor, float* loss, float* scale) {
-  const float den = fmaxf(den_raw, 1e-5f);
-  loss[0] = num / den / divisor;
-  scale[0] = 1.0f / den / divisor;
-}
+// ---- loss value and gradient scale after an all-reduce of the totals (sharded batches) ----
 __global__ void loss_finalize(const float* __restrict__ parts, float* __restrict__ loss, float* __restrict__ scale, float divisor) {
   finalize_pair(parts[0], parts[1], divisor, loss, scale);
 }
@@ -300,13 +323,15 @@ __global__ void diffspec_finish(const float* __restrict__ wsA, const float* __re
 
 using namespace sgr;
 
-extern "C" int sgr_loss_workspace_floats(int bn) { return bn * kSplit * (6 + 2 + 1); }
+extern "C" int sgr_loss_workspace_floats(int bn) { return bn * kSplit * (6 + 2 + 1) + 1; }      // + the arrival counter
 
-extern "C" int sgr_render_loss_fwd(const float* diffuse, const float* spec, const float* im, const float* seg,
-                                   float* im_small, float* seg_small, float* rendered, float* coef, float* parts,
-                                   float* workspace, int bn, int R, int C, int imH, int imW, void* stream) {
+extern "C" int sgr_render_loss_fwd_total(const float* diffuse, const float* spec, const float* im, const float* seg,
+                                         float* im_small, float* seg_small, float* rendered, float* coef, float* parts,
+                                         float* loss, float* scale, float divisor, float* workspace, int bn, int R, int C,
+                                         int imH, int imW, void* stream) {
   SGR_REQUIRE(diffuse && spec && im && seg && im_small && seg_small && rendered && coef && parts && workspace,
               "sgr_render_loss_fwd: NULL tensor");
+  SGR_REQUIRE((loss == nullptr) == (scale == nullptr) && (!loss || divisor > 0.0f), "sgr_render_loss_fwd: loss / scale / divisor");
   SGR_REQUIRE(bn > 0 && R > 0 && C > 0, "sgr_render_loss_fwd: non-positive size");
   const bool ok = (imH == R && imW == C) || (imH == 2 * R && imW == 2 * C);
   SGR_SUPPORTED(ok, "sgr_render_loss_fwd: image / env-grid ratio must be 1 or 2 (pool first)");
@@ -314,16 +339,24 @@ extern "C" int sgr_render_loss_fwd(const float* diffuse, const float* spec, cons
   float* wsA = workspace;
   float* wsB = wsA + (size_t)bn * kSplit * 6;
   float* wsC = wsB + (size_t)bn * kSplit * 2;
+  unsigned* ticket = reinterpret_cast<unsigned*>(wsC + (size_t)bn * kSplit);
   const dim3 grid(kSplit, bn), block(kLossThreads);
   const int RC = R * C;
   if (imH == R)
-    hipLaunchKernelGGL((loss_stage_a<1>), grid, block, 0, st, diffuse, spec, im, seg, im_small, seg_small, wsA, R, C, imH, imW);
+    hipLaunchKernelGGL((loss_stage_a<1>), grid, block, 0, st, diffuse, spec, im, seg, im_small, seg_small, wsA, ticket, R, C, imH, imW);
   else
-    hipLaunchKernelGGL((loss_stage_a<2>), grid, block, 0, st, diffuse, spec, im, seg, im_small, seg_small, wsA, R, C, imH, imW);
+    hipLaunchKernelGGL((loss_stage_a<2>), grid, block, 0, st, diffuse, spec, im, seg, im_small, seg_small, wsA, ticket, R, C, imH, imW);
   hipLaunchKernelGGL(loss_stage_b, grid, block, 0, st, diffuse, spec, im_small, wsA, wsB, 3 * RC);
-  hipLaunchKernelGGL(loss_stage_c, grid, block, 0, st, diffuse, spec, im_small, seg_small, wsA, wsB, coef, rendered, wsC, RC);
-  hipLaunchKernelGGL(loss_stage_d, dim3(1), dim3(kLossThreads), 0, st, wsA, wsC, parts, bn);
+  hipLaunchKernelGGL(loss_stage_c, grid, block, 0, st, diffuse, spec, im_small, seg_small, wsA, wsB, coef, rendered, wsC, RC, ticket, parts,
+                     loss, scale, divisor);
   return sgr_check((int)hipGetLastError(), "sgr_render_loss_fwd");
+}
+
+extern "C" int sgr_render_loss_fwd(const float* diffuse, const float* spec, const float* im, const float* seg,
+                                   float* im_small, float* seg_small, float* rendered, float* coef, float* parts,
+                                   float* workspace, int bn, int R, int C, int imH, int imW, void* stream) {
+  return sgr_render_loss_fwd_total(diffuse, spec, im, seg, im_small, seg_small, rendered, coef, parts, nullptr, nullptr, 0.0f, workspace,
+                                   bn, R, C, imH, imW, stream);
 }
 
 extern "C" int sgr_render_loss_bwd_scaled(const float* g_loss, const float* g_scale, const float* diffuse, const float* spec,

@@ -121,6 +121,69 @@ __device__ __forceinline__ void premap2x2(f32x2& u, f32x2& v) {
   v = f32x2{v0 ? -frcp(tv.x) : tv.x, v1 ? -frcp(tv.y) : tv.y};
 }
 
+// ---- the light decoders' output activations as a prologue (premap == 3; models.py:336-346) ----
+//   axis = normalize3(1.01 tanh x),   lamb, weight = clamp(0.5 (1.01 tanh x + 1), 0, 1)   -> then the tan pre-map as for premap == 1
+// tanh two at a time as 1 - 2 / (e^{2x} + 1): accurate to ~1e-7 ABSOLUTE for every x (e^{2x} = inf and 0 give +-1), which is all
+// the normalisation and the affine map in front of a [0, 1] clamp can see; the standalone pass (sgr_heads.hip, bit-pinned
+// against the reference's clamp decisions) adds a polynomial below |x| = 0.625 for relative accuracy.  7 instructions per pair.
+__device__ __forceinline__ f32x2 tanh2_abs(f32x2 x) {
+  const f32x2 y = x * splat2(2.8853900817779268f);
+  const f32x2 d = f32x2{fexp2(y.x), fexp2(y.y)} + splat2(1.0f);
+  return pfma(splat2(-2.0f), f32x2{frcp(d.x), frcp(d.y)}, splat2(1.0f));
+}
+// 0.5 (1.01 t + 1) with torch's op-by-op rounding (the clamp kinks sit on these bits), two at a time
+__device__ __forceinline__ f32x2 unit_pre2(f32x2 t) {
+#pragma clang fp contract(off)
+  f32x2 u = t * splat2(1.01f);
+  u = u + splat2(1.0f);
+  return u * splat2(0.5f);
+}
+// two lobes (14 raw decoder outputs) -> unit axes and [0, 1] sharpness / intensity, in place
+__device__ __forceinline__ void heads_two_lobes(float (&ax)[2], float (&ay)[2], float (&az)[2], float (&lp)[2], float (&w0)[2], float (&w1)[2],
+                                                float (&w2)[2]) {
+  const f32x2 a0 = tanh2_abs(f32x2{ax[0], ay[0]}) * splat2(1.01f), a1 = tanh2_abs(f32x2{ax[1], ay[1]}) * splat2(1.01f);
+  const f32x2 az2 = tanh2_abs(f32x2{az[0], az[1]}) * splat2(1.01f);
+  const f32x2 tl = tanh2_abs(f32x2{lp[0], lp[1]});
+  const f32x2 t0 = tanh2_abs(f32x2{w0[0], w1[0]}), t1 = tanh2_abs(f32x2{w0[1], w1[1]}), t2 = tanh2_abs(f32x2{w2[0], w2[1]});
+  // a / max(|a|, 1e-6) as a * min(rsq(|a|^2), 1e6)   (|a| = 0: 0 * 1e6 = 0, like 0 / 1e-6)
+  const f32x2 n2 = pfma(az2, az2, pfma(f32x2{a0.y, a1.y}, f32x2{a0.y, a1.y}, f32x2{a0.x, a1.x} * f32x2{a0.x, a1.x}));
+  const f32x2 inv = {fminf(frsq(n2.x), 1e6f), fminf(frsq(n2.y), 1e6f)};
+  const f32x2 y0 = a0 * SGR_LO(inv), y1 = a1 * SGR_HI(inv), yz = az2 * inv;
+  ax[0] = y0.x; ay[0] = y0.y; ax[1] = y1.x; ay[1] = y1.y; az[0] = yz.x; az[1] = yz.y;
+  const f32x2 ul = unit_pre2(tl), u0 = unit_pre2(t0), u1 = unit_pre2(t1), u2 = unit_pre2(t2);
+  lp[0] = clamp01(ul.x); lp[1] = clamp01(ul.y);
+  w0[0] = clamp01(u0.x); w1[0] = clamp01(u0.y); w0[1] = clamp01(u1.x); w1[1] = clamp01(u1.y);
+  w2[0] = clamp01(u2.x); w2[1] = clamp01(u2.y);
+}
+// The heads' chain rule for one lobe (the backward kernels' epilogue): cotangents w.r.t. the unit axis and the [0, 1] sharpness /
+// intensity in, cotangents w.r.t. the seven raw decoder outputs out.  The raw values are read again here (xa / xl / xw: the lobe's
+// planes, wave-uniform; o3 / o1: the lane's byte offsets; rc4 = 4 R C) -- 28 bytes per lobe against seven live registers per lobe
+// across the whole kernel.  Gates and formulas as heads_bwd_kernel (sgr_heads.hip): the min-clamp of the norm blocks the radial
+// term below 1e-6, the [0, 1] clamp passes the cotangent on 0 <= pre <= 1 inclusive (torch).
+__device__ __forceinline__ void heads_bwd_lobe(const char* xa, const char* xl, const char* xw, unsigned o3, unsigned o1, size_t rc4, float& gx,
+                                               float& gy, float& gz, float& gl, float& q0, float& q1, float& q2) {
+  const float x0 = *reinterpret_cast<const float*>(xa + o3), x1 = *reinterpret_cast<const float*>(xa + rc4 + o3);
+  const float x2 = *reinterpret_cast<const float*>(xa + 2 * rc4 + o3), x3 = *reinterpret_cast<const float*>(xl + o1);
+  const float x4 = *reinterpret_cast<const float*>(xw + o3), x5 = *reinterpret_cast<const float*>(xw + rc4 + o3);
+  const float x6 = *reinterpret_cast<const float*>(xw + 2 * rc4 + o3);
+  const f32x2 t01 = tanh2_abs(f32x2{x0, x1}), t23 = tanh2_abs(f32x2{x2, x3}), t45 = tanh2_abs(f32x2{x4, x5}), t66 = tanh2_abs(f32x2{x6, x6});
+  const f32x2 one = splat2(1.0f);
+  const f32x2 s01 = pfma(-t01, t01, one), s23 = pfma(-t23, t23, one), s45 = pfma(-t45, t45, one), s66 = pfma(-t66, t66, one);   // 1 - tanh^2
+  const float a0 = 1.01f * t01.x, a1 = 1.01f * t01.y, a2 = 1.01f * t23.x;
+  const float n2 = fmaf(a2, a2, fmaf(a1, a1, a0 * a0));
+  const bool live = n2 >= 1e-12f;                                         // |a| >= 1e-6
+  const float inv = live ? frsq_nr(n2) : 1e6f;
+  const float dot = live ? fmaf(a2, gz, fmaf(a1, gy, a0 * gx)) * (inv * inv) : 0.0f;
+  gx = (gx - a0 * dot) * inv * (1.01f * s01.x);
+  gy = (gy - a1 * dot) * inv * (1.01f * s01.y);
+  gz = (gz - a2 * dot) * inv * (1.01f * s23.x);
+  const f32x2 p3 = unit_pre2(f32x2{t23.y, t66.x}), p45 = unit_pre2(t45);
+  gl = (p3.x >= 0.0f && p3.x <= 1.0f) ? gl * (0.505f * s23.y) : 0.0f;
+  q0 = (p45.x >= 0.0f && p45.x <= 1.0f) ? q0 * (0.505f * s45.x) : 0.0f;
+  q1 = (p45.y >= 0.0f && p45.y <= 1.0f) ? q1 * (0.505f * s45.y) : 0.0f;
+  q2 = (p3.y >= 0.0f && p3.y <= 1.0f) ? q2 * (0.505f * s66.x) : 0.0f;
+}
+
 // |lp| below this floor stands for lam == 0 (see LobesPk): 2^-40 -- exp2(2^-40 t) is exactly 1 for the |t| <= 2 of the
 // layer, like exp2(0 t), and sums of T (lp t) stay twenty orders of magnitude above the denormal range even for the
 // 1e-9-sized cotangents of a normalised training loss (1e-30, the first choice, did not: ADVICE round 2)
@@ -130,12 +193,15 @@ constexpr float kLpFloor = 9.094947017729282e-13f;
 // of every lobe is in flight before the pre-map consumes any.  `kg` = first lobe (may differ between the two halves of
 // a wave, so the lobe planes are addressed by 32-bit per-lane offsets into the image's SG block); lobes past K re-read
 // lobe K-1 and get zero weights.
-// a.premap: 1 = lamb / weight are the decoders' raw outputs (pre-mapped here); 0 and 2 = they are post-tan already (2: the
+// a.premap: 1 = lamb / weight are the decoders' outputs in [0, 1] (pre-mapped here); 0 and 2 = they are post-tan already (2: the
 // backward still applies the pre-map's chain rule, see sg_bwd_pk_kernel).  The post-tan values go to a.lamb_tan /
 // a.weight_tan when those are given (an output of output2env.output2env, models.py:396-404, and what the backward
 // kernels read instead of re-evaluating 24 tangents per lane) -- in a loop of their own after the last pre-map, so that
 // the pre-map chains of all lobes interleave freely.
-template <int KP, bool FOLD>
+// HEADS (premap == 3 at the C ABI): axis / lamb / weight are the decoders' last-convolution outputs -- heads_two_lobes, then the
+// pre-map.  A template parameter, not a branch on a.premap: as a run-time branch the extra code cost the default kernels 1 % (layer)
+// to 5 % (objective backward) through register allocation alone (measured, round 3).
+template <int KP, bool FOLD, bool HEADS = false>
 __device__ __forceinline__ void load_lobes_pk(const Args& a, int b, unsigned up, bool active, int kg, LobesPk<KP>& P, bool write_tan) {
   static_assert(KP % 2 == 0, "lobes are packed in pairs");
   const int RC = a.R * a.C, K = a.K;
@@ -165,7 +231,21 @@ __device__ __forceinline__ void load_lobes_pk(const Args& a, int b, unsigned up,
     w1[k] = *reinterpret_cast<const float*>(pw + (size_t)RC * 4 + v3);
     w2[k] = *reinterpret_cast<const float*>(pw + (size_t)RC * 8 + v3);
   }
-  if (a.premap == 1) {
+  if (HEADS) {
+#pragma unroll
+    for (int m = 0; m < KP / 2; ++m) {
+      float hx[2] = {ax[2 * m], ax[2 * m + 1]}, hy[2] = {ay[2 * m], ay[2 * m + 1]}, hz[2] = {az[2 * m], az[2 * m + 1]};
+      float hl[2] = {lp[2 * m], lp[2 * m + 1]}, h0[2] = {w0[2 * m], w0[2 * m + 1]}, h1[2] = {w1[2 * m], w1[2 * m + 1]};
+      float h2[2] = {w2[2 * m], w2[2 * m + 1]};
+      heads_two_lobes(hx, hy, hz, hl, h0, h1, h2);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ax[2 * m + i] = hx[i]; ay[2 * m + i] = hy[i]; az[2 * m + i] = hz[i]; lp[2 * m + i] = hl[i];
+        w0[2 * m + i] = h0[i]; w1[2 * m + i] = h1[i]; w2[2 * m + i] = h2[i];
+      }
+    }
+  }
+  if (HEADS || a.premap == 1) {
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
       f32x2 r0 = {lp[k], w0[k]}, r1 = {w1[k], w2[k]};
@@ -284,7 +364,7 @@ __device__ __forceinline__ void shade_pair(const PixLocal& q, const OrthoPix& oq
 // LSregress scale (wrapperBRDFLight.py:172-176, models.py:7-21).  Per-wave partials land in a.ws[blockIdx.x * 3 + {0,1,2}].
 // `unit` = index of the 64-pixel group in the launch's (image, tile) order; `tile` / `gtile` = the workgroup's LDS (env tile
 // of Tile<TJ>::kFloats floats when WRITE_ENV, ground-truth row tile of DmaTile<16>::kFloats floats when HAS_GT)
-template <int KP, int POOL, bool WRITE_ENV, bool DO_RENDER, bool HAS_GT>
+template <int KP, int POOL, bool WRITE_ENV, bool DO_RENDER, bool HAS_GT, bool HEADS = false>
 __device__ __forceinline__ void fwd_pk_body(const Args& a, int unit, float* tile, float* gtile) {
   static_assert(!(HAS_GT && WRITE_ENV), "the statistics variant does not write the env image");
   constexpr int EW = 16, TJ = SGR_PK_TJ, HALF = 8, NQ = 2, RPT = TJ / EW;
@@ -295,7 +375,7 @@ __device__ __forceinline__ void fwd_pk_body(const Args& a, int unit, float* tile
   const int RC = a.R * a.C;
 
   LobesPk<KP> P;
-  load_lobes_pk<KP, true>(a, b, (unsigned)p, x.active, 0, P, true);      // post-tan copies leave when a.lamb_tan / a.weight_tan are given
+  load_lobes_pk<KP, true, HEADS>(a, b, (unsigned)p, x.active, 0, P, true);      // post-tan copies leave when a.lamb_tan / a.weight_tan are given
 
   PixLocal q;
   OrthoPix oq;
@@ -445,11 +525,11 @@ __device__ __forceinline__ void fwd_pk_body(const Args& a, int unit, float* tile
   }
   SGR_TRACE_END
 }
-template <int KP, int POOL, bool WRITE_ENV, bool DO_RENDER, bool HAS_GT = false>
+template <int KP, int POOL, bool WRITE_ENV, bool DO_RENDER, bool HAS_GT = false, bool HEADS = false>
 __global__ __launch_bounds__(kWave, 2) void fwd_pk_kernel(const Args a) {
   __shared__ __attribute__((aligned(16))) float tile[WRITE_ENV ? Tile<SGR_PK_TJ>::kFloats : 4];
   __shared__ __attribute__((aligned(16))) float gtile[HAS_GT ? DmaTile<16>::kFloats : 4];
-  fwd_pk_body<KP, POOL, WRITE_ENV, DO_RENDER, HAS_GT>(a, (int)blockIdx.x, tile, gtile);
+  fwd_pk_body<KP, POOL, WRITE_ENV, DO_RENDER, HAS_GT, HEADS>(a, (int)blockIdx.x, tile, gtile);
 }
 
 
@@ -501,7 +581,7 @@ __device__ __forceinline__ void tile32_dma_issue_vrow(float* tile, __amdgpu_buff
 // tile32_dma_issue_vrow; on the 8x16 grid a virtual row is a table row), double-buffered, and each half accumulates
 // <pred, gt>, <pred, pred>, sum gt over the half rows whose totals it holds; `gtile` = 2 x kT32Floats floats of LDS, `unit` =
 // the 32-pixel group's slot in a.ws.
-template <int POOL, bool WRITE_ENV, bool DO_RENDER, int KPW, int EW, int RPF = 1, bool HAS_GT = false>
+template <int POOL, bool WRITE_ENV, bool DO_RENDER, int KPW, int EW, int RPF = 1, bool HAS_GT = false, bool HEADS = false>
 __device__ __forceinline__ void fwd_pk_half_body(const Args& a, const Pix x, float* tile, float* gtile = nullptr, int unit = 0) {
   static_assert(!(HAS_GT && WRITE_ENV), "the statistics variant does not write the env image");
   constexpr int HALF = EW / 2, NQ = HALF / 4, TD = EW * RPF, Q = EW / 16;
@@ -513,7 +593,7 @@ __device__ __forceinline__ void fwd_pk_half_body(const Args& a, const Pix x, flo
   const int b = x.b, p = x.p;
 
   LobesPk<KPW> P;      // this half's lobes, folded (axis pre-multiplied by lam * log2e)
-  load_lobes_pk<KPW, true>(a, b, (unsigned)p, x.active, half * KPW, P, true);
+  load_lobes_pk<KPW, true, HEADS>(a, b, (unsigned)p, x.active, half * KPW, P, true);
 
   PixLocal q;
   OrthoPix oq;
@@ -691,16 +771,16 @@ __device__ __forceinline__ void fwd_pk_half_body(const Args& a, const Pix x, flo
   }
   SGR_TRACE_END
 }
-template <int POOL, bool WRITE_ENV, bool DO_RENDER, int OCC, int KPW = 6, int EW = 16, int RPF = 1>
+template <int POOL, bool WRITE_ENV, bool DO_RENDER, int OCC, int KPW = 6, int EW = 16, int RPF = 1, bool HEADS = false>
 __global__ __launch_bounds__(kWave, OCC) void fwd_pk_half_kernel(const Args a) {
   __shared__ __attribute__((aligned(16))) float tile[WRITE_ENV ? T32Out<EW * RPF>::kFloats : 4];
-  fwd_pk_half_body<POOL, WRITE_ENV, DO_RENDER, KPW, EW, RPF>(a, locate_group32(a, (int)blockIdx.x), tile);
+  fwd_pk_half_body<POOL, WRITE_ENV, DO_RENDER, KPW, EW, RPF, false, HEADS>(a, locate_group32(a, (int)blockIdx.x), tile);
 }
 // the statistics variant (fused light objective): render + <pred, gt>, <pred, pred>, sum gt against the streamed ground truth
-template <int POOL, int KPW, int EW, int OCC = 2>
+template <int POOL, int KPW, int EW, int OCC = 2, bool HEADS = false>
 __global__ __launch_bounds__(kWave, OCC) void fwd_pk_half_gt_kernel(const Args a) {
   __shared__ __attribute__((aligned(16))) float gtile[2 * kT32Floats];
-  fwd_pk_half_body<POOL, false, true, KPW, EW, 1, true>(a, locate_group32(a, (int)blockIdx.x), nullptr, gtile, (int)blockIdx.x);
+  fwd_pk_half_body<POOL, false, true, KPW, EW, 1, true, HEADS>(a, locate_group32(a, (int)blockIdx.x), nullptr, gtile, (int)blockIdx.x);
 }
 
 
@@ -726,7 +806,7 @@ __device__ __forceinline__ void tile32_read_two_pairs2(const float* tile, int pl
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int POOL, bool HAS_GENV, bool HAS_RENDER, int EW = 16>
+template <int POOL, bool HAS_GENV, bool HAS_RENDER, int EW = 16, bool HEADS = false>
 __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
   constexpr int HALF = 8, NP = 4, KPW = 6, Q = EW / 16;
   // env cotangent rows: a ring of three one-row LDS-DMA buffers (18 KB).  Rows are requested two at a time, back to back
@@ -775,7 +855,7 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
   // packed FMAs, and the sharpness gradient is accumulated as sum T t' = lp sum T t and divided by lp at the end -- two
   // packed multiplies fewer per lobe and azimuth pair
   LobesPk<KPW> P;
-  load_lobes_pk<KPW, true>(a, b, (unsigned)p, x.active, grp * 2 * KPW + half * KPW, P, false);
+  load_lobes_pk<KPW, true, HEADS>(a, b, (unsigned)p, x.active, grp * 2 * KPW + half * KPW, P, false);
 
   f32x2 gw0[KPW], gw1[KPW], gw2[KPW], gl[KPW], gz[KPW], gx[KPW], gy[KPW];
 #pragma unroll
@@ -899,15 +979,21 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
         const float w0 = P.w01[k].x, w1 = P.w01[k].y, w2 = (k & 1) ? P.w2p[k / 2].y : P.w2p[k / 2].x;
         const float lam = fabsf(lpk) <= kLpFloor ? 0.0f : lpk * kLn2;      // the floor stands for lam == 0
         float glk = (gl[k].x + gl[k].y) * frcp(lpk), q0 = gw0[k].x + gw0[k].y, q1 = gw1[k].x + gw1[k].y, q2 = gw2[k].x + gw2[k].y;
-        if (a.premap) {
+        if (HEADS || a.premap) {
           glk *= premap_grad(lam);
           q0 *= premap_grad(w0); q1 *= premap_grad(w1); q2 *= premap_grad(w2);
         }
+        float gax = lam * (gx[k].x + gx[k].y), gay = lam * (gy[k].x + gy[k].y), gaz = lam * (gz[k].x + gz[k].y);
+        if (HEADS)
+          heads_bwd_lobe(reinterpret_cast<const char*>(a.axis + (size_t)b * K * 3 * RC) + (size_t)ks * 3 * RC * 4,
+                         reinterpret_cast<const char*>(a.lamb + (size_t)b * K * RC) + (size_t)ks * RC * 4,
+                         reinterpret_cast<const char*>(a.weight + (size_t)b * K * 3 * RC) + (size_t)ks * 3 * RC * 4, o3_own, o1_own,
+                         (size_t)RC * 4, gax, gay, gaz, glk, q0, q1, q2);
         char* pa = g_axis_b + (size_t)ks * 3 * RC * 4;
         char* pw = g_weight_b + (size_t)ks * 3 * RC * 4;
-        *reinterpret_cast<float*>(pa + o3_own) = lam * (gx[k].x + gx[k].y);
-        *reinterpret_cast<float*>(pa + (size_t)RC * 4 + o3_own) = lam * (gy[k].x + gy[k].y);
-        *reinterpret_cast<float*>(pa + (size_t)RC * 8 + o3_own) = lam * (gz[k].x + gz[k].y);
+        *reinterpret_cast<float*>(pa + o3_own) = gax;
+        *reinterpret_cast<float*>(pa + (size_t)RC * 4 + o3_own) = gay;
+        *reinterpret_cast<float*>(pa + (size_t)RC * 8 + o3_own) = gaz;
         *reinterpret_cast<float*>(g_lamb_b + (size_t)ks * RC * 4 + o1_own) = glk;
         *reinterpret_cast<float*>(pw + o3_own) = q0;
         *reinterpret_cast<float*>(pw + (size_t)RC * 4 + o3_own) = q1;

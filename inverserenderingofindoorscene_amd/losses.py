@@ -126,7 +126,7 @@ def _sharded(group) -> bool:
 
 class _RenderLoss(torch.autograd.Function):
     """``(renderErr, rendered)``: sgr_render_loss_fwd -> [all-reduce of the two totals] -> sgr_loss_finalize, and
-    sgr_render_loss_bwd_scaled.  Six small launches per step and no elementwise torch glue: this sits between the two heavy
+    sgr_render_loss_bwd_scaled.  Four small launches per step (five + the collective when sharded) and no elementwise torch glue: this sits between the two heavy
     kernels of every training step, where a dozen 5-us launches are worth a tenth of the step."""
 
     @staticmethod
@@ -148,11 +148,15 @@ class _RenderLoss(torch.autograd.Function):
         scale = torch.empty(1, device=dev, dtype=torch.float32)      # (separate buffers: no shared version counter)
         ws = _workspace(bn, dev)
         with torch.cuda.device(dev):
-            _lib.call("sgr_render_loss_fwd", _ptr(d), _ptr(s), _ptr(im_c), _ptr(seg_c), _ptr(im_s), _ptr(seg_s),
-                      _ptr(rendered), _ptr(coef), _ptr(parts), _ptr(ws), bn, R, C, imH, imW, _stream(dev))
             if _sharded(group):
+                _lib.call("sgr_render_loss_fwd", _ptr(d), _ptr(s), _ptr(im_c), _ptr(seg_c), _ptr(im_s), _ptr(seg_s),
+                          _ptr(rendered), _ptr(coef), _ptr(parts), _ptr(ws), bn, R, C, imH, imW, _stream(dev))
                 dist.all_reduce(parts, op=dist.ReduceOp.SUM, group=group)      # [num, den] of the global batch (RCCL over xGMI)
-            _lib.call("sgr_loss_finalize", _ptr(parts), _ptr(loss), _ptr(scale), 3.0, _stream(dev))
+                _lib.call("sgr_loss_finalize", _ptr(parts), _ptr(loss), _ptr(scale), 3.0, _stream(dev))
+            else:                                                             # the third pass forms the loss value itself
+                _lib.call("sgr_render_loss_fwd_total", _ptr(d), _ptr(s), _ptr(im_c), _ptr(seg_c), _ptr(im_s), _ptr(seg_s),
+                          _ptr(rendered), _ptr(coef), _ptr(parts), _ptr(loss), _ptr(scale), 3.0, _ptr(ws), bn, R, C, imH, imW,
+                          _stream(dev))
         ctx.save_for_backward(d, s, im_s, seg_s, coef, scale)
         ctx.mark_non_differentiable(rendered)
         return loss, rendered
@@ -299,7 +303,7 @@ class _LightObjective(torch.autograd.Function):
     gradients are produced here and handed out (times the incoming cotangent) in ``backward``."""
 
     @staticmethod
-    def forward(ctx, albedo, normal, rough, axis, lamb, weight, im, seg, env_gt, env_ind, layer_cfg, ren_w, rec_w, offset, group):
+    def forward(ctx, albedo, normal, rough, axis, lamb, weight, im, seg, env_gt, env_ind, layer_cfg, ren_w, rec_w, offset, group, heads=False):
         dev = _require_hip(albedo, normal, rough, axis, lamb, weight, im, seg, env_gt, env_ind)
         eh, ew, fov, F0, cam = layer_cfg
         albedo_c, normal_c, rough_c = albedo.contiguous(), normal.contiguous(), rough.contiguous()
@@ -325,7 +329,8 @@ class _LightObjective(torch.autograd.Function):
         ws = torch.empty(lib.sgr_fused_recon_workspace_floats(bn, R, C), **f32)
         ws_r = _workspace(bn, dev)
         g_axis, g_lamb, g_weight = torch.empty_like(axis_c), torch.empty_like(lamb_c), torch.empty_like(weight_c)
-        handoff = _ops.tan_handoff()
+        handoff = _ops.tan_handoff() and not heads
+        pm = 3 if heads else 1      # 3: axis / lamb / weight are the decoders' last-convolution outputs (heads as the kernels' prologue)
         # post-tan values: written by the forward pass, read by the backward pass (premap mode 2)
         lam_t, w_t = (torch.empty_like(lamb_c), torch.empty_like(weight_c)) if handoff else (lamb_c, weight_c)
         d, v = _dirs(dev, eh, ew), _view(dev, R, C, fov, cam)
@@ -340,26 +345,27 @@ class _LightObjective(torch.autograd.Function):
                 seg_small = F.avg_pool2d(seg_c, 2)
             _lib.call("sgr_fused_fwd_recon_tan", *sg_args, _ptr(gt), _ptr(seg_small), _ptr(ind), _ptr(lam_t) if handoff else None,
                       _ptr(w_t) if handoff else None, _ptr(diffuse),
-                      _ptr(spec), _ptr(mask), _ptr(coef), _ptr(parts_f), _ptr(ws), bn, K, R, C, eh, ew, h, w, float(F0), 1, st)
-            _lib.call("sgr_render_loss_fwd", _ptr(diffuse), _ptr(spec), _ptr(im_c), _ptr(seg_c), _ptr(im_s), _ptr(seg_s),
-                      _ptr(rendered), _ptr(coef_ds), _ptr(parts_r), _ptr(ws_r), bn, R, C, imH, imW, st)
+                      _ptr(spec), _ptr(mask), _ptr(coef), _ptr(parts_f), _ptr(ws), bn, K, R, C, eh, ew, h, w, float(F0), pm, st)
+            sharded = _sharded(group)
+            render_err, scale_r = torch.empty((), **f32), torch.empty(1, **f32)
+            _lib.call("sgr_render_loss_fwd_total", _ptr(diffuse), _ptr(spec), _ptr(im_c), _ptr(seg_c), _ptr(im_s), _ptr(seg_s),
+                      _ptr(rendered), _ptr(coef_ds), _ptr(parts_r), None if sharded else _ptr(render_err), None if sharded else _ptr(scale_r),
+                      3.0, _ptr(ws_r), bn, R, C, imH, imW, st)
             # everything between the heavy kernels stays on the device and in two one-thread launches (a dozen one-element
             # torch kernels before round 3: 0.05 ms of a 0.86 ms training step)
-            render_err, scale_r = torch.empty((), **f32), torch.empty(1, **f32)
             recon_err, objective = torch.empty((), **f32), torch.empty((), **f32)
-            sharded = _sharded(group)
             den_e_c = None
             if sharded:
                 v1 = torch.stack([parts_r[0], parts_r[1], parts_f[1]])      # [num_r, den_r, den_e]: one all-reduce before the backward pass
                 dist.all_reduce(v1, op=dist.ReduceOp.SUM, group=group)
                 parts_r, den_e_c = v1[:2], v1[2:3]
-            _lib.call("sgr_loss_finalize", _ptr(parts_r), _ptr(render_err), _ptr(scale_r), 3.0, st)
+                _lib.call("sgr_loss_finalize", _ptr(parts_r), _ptr(render_err), _ptr(scale_r), 3.0, st)
             g_d, g_s = torch.empty_like(diffuse), torch.empty_like(spec)
             _lib.call("sgr_render_loss_bwd_scaled", _ptr(_const_scalar(dev, float(ren_w))), _ptr(scale_r), _ptr(diffuse), _ptr(spec), _ptr(im_s),
                       _ptr(seg_s), _ptr(coef_ds), _ptr(g_d), _ptr(g_s), bn, R, C, st)
             _lib.call("sgr_fused_bwd_recon", *sg_args_tan, _ptr(gt), _ptr(mask), _ptr(coef), _ptr(den_e_c), _ptr(g_d), _ptr(g_s),
                       _ptr(g_axis), _ptr(g_lamb), _ptr(g_weight), _ptr(parts_b), _ptr(ws),
-                      bn, K, R, C, eh, ew, h, w, float(F0), 2 if handoff else 1, float(offset), float(rec_w), st)
+                      bn, K, R, C, eh, ew, h, w, float(F0), 2 if handoff else pm, float(offset), float(rec_w), st)
             if sharded:
                 num_e = parts_b[0:1].clone()
                 dist.all_reduce(num_e, op=dist.ReduceOp.SUM, group=group)      # the second and last collective: the reconstruction numerator
@@ -389,14 +395,14 @@ class _LightObjective(torch.autograd.Function):
                 raise RuntimeError("sgrender: light_objective was first back-propagated with a zero cotangent; its stored "
                                    "gradients are gone -- re-evaluate the objective instead of reusing the graph")
             f = g_obj.detach() / applied[0]
-            return tuple([None] * 3 + [g * f if ctx.needs_input_grad[3 + i] else None for i, g in enumerate(gs)] + [None] * 9)
+            return tuple([None] * 3 + [g * f if ctx.needs_input_grad[3 + i] else None for i, g in enumerate(gs)] + [None] * 10)
         ctx.handed_out = True
         ptrs = (ctypes.c_void_p * 3)(*[g.data_ptr() for g in gs])
         lens = (ctypes.c_longlong * 3)(*[g.numel() for g in gs])
         scale = g_obj.detach().to(torch.float32).reshape(1).contiguous()
         with torch.cuda.device(dev):
             _lib.call("sgr_rescale_inplace", ctypes.addressof(ptrs), ctypes.addressof(lens), 3, _ptr(scale), _ptr(applied), _stream(dev))
-        outs = [None] * 15
+        outs = [None] * 16
         for i, g in ((3, g_axis), (4, g_lamb), (5, g_weight)):
             if ctx.needs_input_grad[i]:
                 outs[i] = g
@@ -405,7 +411,7 @@ class _LightObjective(torch.autograd.Function):
 
 def light_objective(renderLayer, albedoPred, normalPred, roughPred, axisPred, lambPred, weightPred, imBatch, segBRDFBatch,
                     envmapsBatch, envmapsIndBatch, renderWeight: float = 1.0, reconWeight: float = 10.0, offset: float = 1.0,
-                    group=None):
+                    group=None, decoder_outputs: bool = False):
     """The cascade-0 light objective ``renderWeight * renderErr + reconWeight * reconstErr`` of
     wrapperBRDFLight.py:167-207 / trainLight.py:237 in two heavy kernel passes, without ever writing the
     predicted env image or its gradient.
@@ -417,12 +423,31 @@ def light_objective(renderLayer, albedoPred, normalPred, roughPred, axisPred, la
     Configurations without a fused kernel (envWidth other than 16 / 32 or SGNum > 24, see :func:`light_objective_supported`)
     are evaluated by the unfused HIP kernels (forwardSG + render_loss + recon_loss) with the same return values.
 
+    ``decoder_outputs=True``: ``axisPred [bn,3K,R,C] (or [bn,K,3,R,C]), lambPred, weightPred`` are the three light decoders'
+    LAST-CONVOLUTION outputs instead -- their output activations (models.py:336-346: ``1.01 tanh`` -> unit axis /
+    ``clamp(0.5 (. + 1), 0, 1)``) run as the prologue of the two heavy kernels and their chain rule as the epilogue of the
+    backward one (SURVEY.md section 8f rank 2 as written), so the activated SG parameters and their gradients never exist in
+    HBM; the gradients come back w.r.t. the raw outputs.  Where the fused kernels do not cover the configuration
+    (``sgr_heads_prologue_supported``: SGNum <= 6 or > 24, other direction grids) the same result comes from
+    :func:`light_heads` followed by the plain objective.
+
     Returns ``(objective, renderErr, reconstErr, renderedImPred, envScale)``; the two error terms are reported
     values (no gradient), ``envScale [bn]`` is the LSregress coefficient (``envmapsPredScaledImage =
     envScale * envmapsPredImage`` if the caller materialises the env for logging).  Under batch sharding the
     mask sums are all-reduced before the backward pass and the numerators after it (two collectives of two
     floats each)."""
     impl = getattr(renderLayer, "impl", renderLayer)
+    heads = False
+    if decoder_outputs:
+        if axisPred.dim() == 4 and axisPred.shape[1] % 3 == 0:
+            axisPred = axisPred.reshape(axisPred.shape[0], axisPred.shape[1] // 3, 3, axisPred.shape[2], axisPred.shape[3])
+        k_, r_, c_ = axisPred.shape[1], axisPred.shape[-2], axisPred.shape[-1]
+        if light_objective_supported(k_, r_, c_, impl.envHeight, impl.envWidth) and \
+                _lib.load().sgr_heads_prologue_supported(int(k_), int(r_), int(c_), int(impl.envHeight), int(impl.envWidth)):
+            heads = True
+        else:
+            from .layers import light_heads
+            axisPred, lambPred, weightPred, _ = light_heads(axisPred.reshape(axisPred.shape[0], -1, r_, c_), lambPred, weightPred)
     bn, K, R, C = _check_sg(axisPred, lambPred, weightPred, None)
     impl._check_grid(R, C)
     if not light_objective_supported(K, R, C, impl.envHeight, impl.envWidth):
@@ -442,4 +467,4 @@ def light_objective(renderLayer, albedoPred, normalPred, roughPred, axisPred, la
         seg = F.adaptive_avg_pool2d(seg, (R, C))
     cfg = (impl.envHeight, impl.envWidth, impl.fov_deg, impl.F0, impl._cam)
     return _LightObjective.apply(a, n, r, axisPred, lambPred, weightPred, im, seg, envmapsBatch, envmapsIndBatch, cfg,
-                                 float(renderWeight), float(reconWeight), float(offset), group)
+                                 float(renderWeight), float(reconWeight), float(offset), group, heads)

@@ -76,3 +76,79 @@ def test_light_heads_rejects_bad_shapes(sgr):
         sgr.light_heads(torch.zeros(1, 35, 4, 4, device="cuda"), torch.zeros(1, 12, 4, 4, device="cuda"), torch.zeros(1, 36, 4, 4, device="cuda"))
     with pytest.raises(RuntimeError):
         sgr.light_heads(torch.zeros(1, 36, 4, 4), torch.zeros(1, 12, 4, 4), torch.zeros(1, 36, 4, 4))
+
+
+@pytest.mark.parametrize("bn,imH,imW,R,C,K,eh,ew,need_env", [
+    (2, 18, 26, 9, 13, 12, 8, 16, True),       # config 2's kernels (half-wave forward with the env image, packed backward)
+    (1, 12, 20, 12, 20, 9, 8, 16, False),      # render only: one pixel per lane
+    (1, 18, 26, 9, 13, 24, 16, 32, True),      # config 5's kernels
+])
+def test_fused_layer_with_heads_prologue_through_the_c_abi(sgr, bn, imH, imW, R, C, K, eh, ew, need_env):
+    """``premap = 3`` at the C ABI (sgr_fused_fwd / sgr_fused_bwd_sg): the decoders' last-convolution outputs go in, the heads run as
+    the kernels' prologue and their chain rule as the backward's epilogue -- against the two-step route (sgr.light_heads, then the
+    layer with premap = 1) with autograd doing the chain rule, within twice the fp32 oracle's own noise."""
+    from conftest import tol2
+    from inverserenderingofindoorscene_amd import _lib
+    from inverserenderingofindoorscene_amd.ops import _dirs, _ptr, _stream, _view
+    from oracle import sg_oracle as O
+    fov, F0 = 57.0, 0.05
+    assert _lib.load().sgr_heads_prologue_supported(K, R, C, eh, ew) == 1
+    inp = O.synthetic_inputs(bn, imH, imW, R, C, K, eh, ew, seed=500 + K, benign=True)
+    g = torch.Generator().manual_seed(17 + K)
+    xs = [1.3 * torch.randn(bn, 3 * K, R, C, generator=g), 1.3 * torch.randn(bn, K, R, C, generator=g),
+          1.3 * torch.randn(bn, 3 * K, R, C, generator=g)]
+    cts = [1e-3 * torch.randn(bn, 3, R, C, eh, ew, generator=g), torch.randn(bn, 3, R, C, generator=g), torch.randn(bn, 3, R, C, generator=g)]
+
+    def oracle(dtype):
+        x = [t.to(dtype).clone().requires_grad_(True) for t in xs]
+        a, l, w, _ = O.light_heads(*x)
+        env, d, s = O.render_from_sg(inp["albedo"].to(dtype), inp["normal"].to(dtype), inp["rough"].to(dtype), a, l, w, eh, ew, fov, F0)
+        outs, ct = ([env, d, s], cts) if need_env else ([d, s], cts[1:])
+        return [env, d, s], torch.autograd.grad(outs, x, grad_outputs=[c.to(dtype) for c in ct])
+    (env64, d64, s64), g64 = oracle(torch.float64)
+    (env32, d32, s32), g32 = oracle(torch.float32)
+
+    dev = torch.device("cuda")
+    alb, nrm, rgh = (inp[k].cuda() for k in ("albedo", "normal", "rough"))
+    xa, xl, xw = (t.cuda() for t in xs)
+    env = torch.empty(bn, 3, R, C, eh, ew, device=dev) if need_env else None
+    dif, spc = torch.empty(bn, 3, R, C, device=dev), torch.empty(bn, 3, R, C, device=dev)
+    d_tab, v_tab = _dirs(dev, eh, ew), _view(dev, R, C, fov, (0.0, 0.0, 0.0))
+    _lib.call("sgr_fused_fwd", _ptr(alb), _ptr(nrm), _ptr(rgh), _ptr(xa), _ptr(xl), _ptr(xw), _ptr(d_tab), _ptr(v_tab), _ptr(env), _ptr(dif),
+              _ptr(spc), bn, K, R, C, eh, ew, imH, imW, F0, 3, _stream(dev))
+    if need_env:
+        assert rel_l2(env.cpu(), env64) < tol2(rel_l2(env32, env64))
+    assert rel_l2(dif.cpu(), d64) < tol2(rel_l2(d32, d64)) and rel_l2(spc.cpu(), s64) < tol2(rel_l2(s32, s64))
+    gxa, gxl, gxw = torch.empty_like(xa), torch.empty_like(xl), torch.empty_like(xw)
+    ct_dev = [c.cuda() for c in cts]
+    _lib.call("sgr_fused_bwd_sg", _ptr(ct_dev[0]) if need_env else None, _ptr(ct_dev[1]), _ptr(ct_dev[2]), _ptr(alb), _ptr(nrm), _ptr(rgh),
+              _ptr(xa), _ptr(xl), _ptr(xw), _ptr(d_tab), _ptr(v_tab), _ptr(gxa), _ptr(gxl), _ptr(gxw), bn, K, R, C, eh, ew, imH, imW, F0, 3,
+              _stream(dev))
+    # two-step route: standalone heads, then the layer on the activated SG parameters
+    x2 = [t.clone().requires_grad_(True) for t in (xa, xl, xw)]
+    a, l, w, _ = sgr.light_heads(*x2)
+    layer = sgr.renderingLayer(imWidth=C, imHeight=R, fov=fov, F0=F0, envWidth=ew, envHeight=eh)
+    env2, d2, s2 = layer.forwardSG(alb, nrm, rgh, a, l, w, need_env=need_env)
+    outs, ct = ([env2, d2, s2], ct_dev) if need_env else ([d2, s2], ct_dev[1:])
+    g2 = torch.autograd.grad(outs, x2, grad_outputs=ct)
+    for name, gp, gs, a64, a32 in zip(("x_axis", "x_lamb", "x_weight"), (gxa, gxl, gxw), g2, g64, g32):
+        e_ref = rel_l2(a32, a64)
+        assert rel_l2(gp.cpu(), a64) < tol2(e_ref), (name, rel_l2(gp.cpu(), a64), e_ref)
+        assert rel_l2(gp, gs) < tol2(e_ref), (name, rel_l2(gp, gs), e_ref)
+
+
+def test_heads_prologue_is_refused_where_no_kernel_has_it(sgr):
+    from inverserenderingofindoorscene_amd import _lib
+    lib = _lib.load()
+    assert lib.sgr_heads_prologue_supported(5, 8, 8, 8, 16) == 0        # SGNum <= 6
+    assert lib.sgr_heads_prologue_supported(12, 8, 8, 4, 8) == 0        # a direction grid without packed kernels
+    assert lib.sgr_heads_prologue_supported(12, 120, 160, 8, 16) == 1 and lib.sgr_heads_prologue_supported(24, 240, 320, 16, 32) == 1
+    dev = torch.device("cuda")
+    t = torch.zeros(1, 5, 3, 8, 8, device=dev)
+    from inverserenderingofindoorscene_amd.ops import _dirs, _ptr, _stream, _view
+    with pytest.raises(Exception):
+        _lib.call("sgr_fused_fwd", _ptr(torch.zeros(1, 3, 8, 8, device=dev)), _ptr(torch.zeros(1, 3, 8, 8, device=dev)),
+                  _ptr(torch.zeros(1, 1, 8, 8, device=dev)), _ptr(t), _ptr(torch.zeros(1, 5, 8, 8, device=dev)),
+                  _ptr(torch.zeros(1, 15, 8, 8, device=dev)), _ptr(_dirs(dev, 8, 16)), _ptr(_view(dev, 8, 8, 57.0, (0.0, 0.0, 0.0))), None,
+                  _ptr(torch.zeros(1, 3, 8, 8, device=dev)), _ptr(torch.zeros(1, 3, 8, 8, device=dev)), 1, 5, 8, 8, 8, 16, 8, 8, 0.05, 3,
+                  _stream(dev))

@@ -176,3 +176,103 @@ def test_light_objective_rejects_brdf_gradients(sgr):
                               inp["im"], inp["seg"], inp["env_gt"], torch.ones(1, 1, 1, 1, device="cuda"))[0]
     with pytest.raises(NotImplementedError):
         obj.backward()
+
+
+# --------------------------------------------------------------------------- #
+# decoder heads as the kernels' prologue (SURVEY.md section 8f rank 2 as written; premap = 3)
+# --------------------------------------------------------------------------- #
+def _decoder_outputs(bn, K, R, C, seed):
+    """Last-convolution outputs of the three light decoders: N(0, 1.2) with saturated entries either side (the 1.01 tanh
+    then leaves [-1, 1] and both ends of the [0, 1] clamp are live)."""
+    g = torch.Generator().manual_seed(seed)
+    xa = 1.2 * torch.randn(bn, 3 * K, R, C, generator=g)
+    xl = 1.2 * torch.randn(bn, K, R, C, generator=g)
+    xw = 1.2 * torch.randn(bn, 3 * K, R, C, generator=g)
+    for x in (xa, xl, xw):
+        flat = x.view(-1)
+        idx = torch.randperm(flat.numel(), generator=g)[: max(4, flat.numel() // 50)]
+        flat[idx] = torch.where(torch.rand(idx.numel(), generator=g) < 0.5, 6.0, -6.0) + 0.3 * torch.randn(idx.numel(), generator=g)
+    return xa, xl, xw
+
+
+@pytest.mark.parametrize("bn,imH,imW,R,C,K,eh,ew", [
+    (2, 12, 20, 12, 20, 12, 8, 16),            # config 2's kernels, q = 1, partial tile
+    (2, 18, 26, 9, 13, 12, 8, 16),             # q = 4
+    (1, 16, 40, 8, 20, 9, 8, 16),              # lobe slots past K in the second half-wave
+    (2, 18, 26, 9, 13, 24, 16, 32),            # config 5's kernels (12 lobes per half-wave forward, four lane groups backward)
+    (1, 12, 16, 6, 8, 7, 3, 32),
+    (2, 10, 14, 10, 14, 5, 8, 16),             # no prologue for SGNum <= 6: light_heads + the plain objective, same answers
+])
+def test_light_objective_from_decoder_outputs(sgr, bn, imH, imW, R, C, K, eh, ew):
+    """``light_objective(decoder_outputs=True)``: values and gradients w.r.t. the decoders' last-convolution outputs against
+    the fp64 oracle (heads of models.py:336-346 + wrapperBRDFLight.py:167-207) within twice the fp32 oracle's own noise, and
+    against the two-step HIP route (standalone heads pass, then the objective)."""
+    from conftest import tol2
+    from oracle import sg_oracle as O
+    fov, F0, ren_w, rec_w = 57.0, 0.05, 1.0, 10.0
+    inp = O.synthetic_inputs(bn, imH, imW, R, C, K, eh, ew, seed=300 + K, benign=True)
+    xs = _decoder_outputs(bn, K, R, C, seed=900 + K)
+    ind = torch.ones(bn, 1, 1, 1)
+
+    def oracle(dtype):
+        x = [t.to(dtype).clone().requires_grad_(True) for t in xs]
+        a, l, w, _ = O.light_heads(*x)
+        o = {k: v.to(dtype) for k, v in inp.items()}
+        env, d, s = O.render_from_sg(o["albedo"], o["normal"], o["rough"], a, l, w, eh, ew, fov, F0)
+        rerr = O.render_loss(d, s, o["im"], o["seg"], R, C)[0]
+        cerr = O.recon_loss(env, o["env_gt"], o["seg"], ind.to(dtype), R, C, 1.0)[0]
+        tot = ren_w * rerr + rec_w * cerr
+        return tot.item(), rerr.item(), cerr.item(), torch.autograd.grad(tot, x)
+    tot64, r64, c64, g64 = oracle(torch.float64)
+    _, _, _, g32 = oracle(torch.float32)
+
+    dev = {k: v.cuda() for k, v in inp.items()}
+    layer = sgr.renderingLayer(imWidth=C, imHeight=R, fov=fov, F0=F0, envWidth=ew, envHeight=eh)
+    supported = bool(sgr._lib.load().sgr_heads_prologue_supported(K, R, C, eh, ew))
+    assert supported == (K > 6)
+
+    def run(prologue):
+        x = [t.cuda().requires_grad_(True) for t in xs]
+        if prologue:
+            out = sgr.light_objective(layer, dev["albedo"], dev["normal"], dev["rough"], x[0], x[1], x[2], dev["im"], dev["seg"],
+                                      dev["env_gt"], ind.cuda(), ren_w, rec_w, decoder_outputs=True)
+        else:
+            a, l, w, _ = sgr.light_heads(*x)
+            out = sgr.light_objective(layer, dev["albedo"], dev["normal"], dev["rough"], a, l, w, dev["im"], dev["seg"], dev["env_gt"],
+                                      ind.cuda(), ren_w, rec_w)
+        return out, torch.autograd.grad(out[0], x)
+    (o_p, g_p), (o_s, g_s) = run(True), run(False)
+    assert abs(o_p[1].item() - r64) < 1e-4 * max(1.0, r64) and abs(o_p[2].item() - c64) < 1e-4 * max(1.0, c64)
+    assert abs(o_p[0].item() - tot64) < 1e-4 * max(1.0, tot64)
+    for name, gp, gs, a64, a32 in zip(("x_axis", "x_lamb", "x_weight"), g_p, g_s, g64, g32):
+        e_ref = rel_l2(a32, a64)
+        assert rel_l2(gp.cpu(), a64) < tol2(e_ref), (name, rel_l2(gp.cpu(), a64), e_ref)
+        # the two HIP routes differ by the rounding of tanh alone, which the tan pre-map amplifies near w = 1 like any fp32 noise
+        assert rel_l2(gp, gs) < tol2(e_ref), (name, rel_l2(gp, gs), e_ref)
+        assert torch.isfinite(gp).all()
+
+
+def test_light_objective_from_decoder_outputs_full_size(sgr):
+    """BASELINE config 2 shapes (4 images): the prologue route equals the standalone-heads route, and is bit-reproducible."""
+    from oracle import sg_oracle as O
+    bn, imH, imW, R, C, K, eh, ew = 4, 240, 320, 120, 160, 12, 8, 16
+    inp = {k: v.cuda() for k, v in O.synthetic_inputs(bn, imH, imW, R, C, K, eh, ew, seed=20203).items()}
+    xs = [t.cuda() for t in _decoder_outputs(bn, K, R, C, seed=41)]
+    ind = torch.ones(bn, 1, 1, 1, device="cuda")
+    layer = sgr.renderingLayer(imWidth=C, imHeight=R, fov=57, F0=0.05, envWidth=ew, envHeight=eh)
+
+    def run(prologue):
+        x = [t.clone().requires_grad_(True) for t in xs]
+        if prologue:
+            out = sgr.light_objective(layer, inp["albedo"], inp["normal"], inp["rough"], x[0], x[1], x[2], inp["im"], inp["seg"],
+                                      inp["env_gt"], ind, 1.0, 10.0, decoder_outputs=True)
+        else:
+            a, l, w, _ = sgr.light_heads(*x)
+            out = sgr.light_objective(layer, inp["albedo"], inp["normal"], inp["rough"], a, l, w, inp["im"], inp["seg"], inp["env_gt"], ind,
+                                      1.0, 10.0)
+        return out, torch.autograd.grad(out[0], x)
+    (o1, g1), (o2, g2), (o3, g3) = run(True), run(True), run(False)
+    assert torch.equal(o1[0], o2[0]) and all(torch.equal(a, b) for a, b in zip(g1, g2))
+    assert abs(o1[1].item() - o3[1].item()) < 2e-5 * max(1.0, o3[1].item()) and abs(o1[2].item() - o3[2].item()) < 2e-5 * max(1.0, o3[2].item())
+    for name, ga, gb in zip(("x_axis", "x_lamb", "x_weight"), g1, g3):
+        assert rel_l2(ga, gb) < 1e-4, (name, rel_l2(ga, gb))

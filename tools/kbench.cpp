@@ -44,7 +44,7 @@ int main(int argc, char** argv) {
 #define SYM(name) auto name##_p = (decltype(&name))dlsym(lib, #name); if (!name##_p) { printf("missing %s\n", #name); return 1; }
   SYM(sgr_fill_direction_table) SYM(sgr_fill_view_vectors) SYM(sgr_dirs_floats)
   SYM(sgr_sg_to_env_fwd) SYM(sgr_render_env_fwd) SYM(sgr_fused_fwd) SYM(sgr_sg_to_env_bwd) SYM(sgr_fused_bwd_sg)
-  SYM(sgr_render_env_bwd_env) SYM(sgr_render_bwd_brdf) SYM(sgr_render_loss_fwd) SYM(sgr_render_loss_bwd) SYM(sgr_loss_workspace_floats)
+  SYM(sgr_render_env_bwd_env) SYM(sgr_render_bwd_brdf) SYM(sgr_render_loss_fwd) SYM(sgr_render_loss_fwd_total) SYM(sgr_render_loss_bwd) SYM(sgr_loss_workspace_floats)
   SYM(sgr_fused_fwd_recon) SYM(sgr_fused_bwd_recon) SYM(sgr_fused_recon_workspace_floats) SYM(sgr_recon_loss_fwd) SYM(sgr_recon_loss_bwd) SYM(sgr_recon_workspace_floats)
   // round-3 entry points (absent from older builds of the library: their lines are skipped then)
   auto sgr_fused_fwd_tan_p = (decltype(&sgr_fused_fwd_tan))dlsym(lib, "sgr_fused_fwd_tan");
@@ -124,7 +124,8 @@ int main(int argc, char** argv) {
   bench("sgr_render_env_bwd_env", Bbrdf + Bout + Benv, [&] { return sgr_render_env_bwd_env_p(g_d, g_s, albedo, normal, rough, dirs, view, env, bn, R, C, eh, ew, imH, imW, F0d, st); });
   bench("sgr_render_bwd_brdf (env given)", 2 * Bbrdf + Bout + Benv, [&] { return sgr_render_bwd_brdf_p(g_d, g_s, albedo, normal, rough, g_env, (float*)nullptr, (float*)nullptr, (float*)nullptr, dirs, view, g_alb, g_nrm, g_rgh, bn, K, R, C, eh, ew, imH, imW, F0d, 1, st); });
   bench("sgr_render_bwd_brdf (from SG)", 2 * Bbrdf + Bout + Bsg, [&] { return sgr_render_bwd_brdf_p(g_d, g_s, albedo, normal, rough, (float*)nullptr, axis, lamb, weight, dirs, view, g_alb, g_nrm, g_rgh, bn, K, R, C, eh, ew, imH, imW, F0d, 1, st); });
-  bench("sgr_render_loss_fwd (4 kernels)", 3 * 4 * q + 4 * q + 24 + 12 + 4 + 12 + 36, [&] { return sgr_render_loss_fwd_p(diffuse, spec, im, seg, im_s, seg_s, rendered, coef, parts, ws, bn, R, C, imH, imW, st); });
+  float* lossv = dev_empty(2);
+  bench("sgr_render_loss_fwd_total (3 k.)", 3 * 4 * q + 4 * q + 24 + 12 + 4 + 12 + 36, [&] { return sgr_render_loss_fwd_total_p(diffuse, spec, im, seg, im_s, seg_s, rendered, coef, parts, lossv, lossv + 1, 3.0f, ws, bn, R, C, imH, imW, st); });
   bench("sgr_render_loss_bwd", 24 + 12 + 4 + 24, [&] { return sgr_render_loss_bwd_p(g_num, diffuse, spec, im_s, seg_s, coef, g_d, g_s, bn, R, C, st); });
   // env reconstruction: unfused passes over the materialised env image vs the fused objective
   float* env_gt = dev_rand(P * 3 * J, 0, 2, 13); float* ind = dev_rand(bn, 1, 1, 14);
@@ -138,5 +139,19 @@ int main(int argc, char** argv) {
     bench("sgr_fused_bwd_recon (premap 2)", Bbrdf + Bsg + Bout + Benv + Bsg, [&] { return sgr_fused_bwd_recon_p(albedo, normal, rough, axis, lam_t, w_t, dirs, view, env_gt, mask, rcoef, (float*)nullptr, g_d, g_s, g_axis, g_lamb, g_weight, rparts, fws, bn, K, R, C, eh, ew, imH, imW, F0d, 2, 1.0f, 10.0f, st); });
   }
   bench("sgr_fused_bwd_recon", Bbrdf + Bsg + Bout + Benv + Bsg, [&] { return sgr_fused_bwd_recon_p(albedo, normal, rough, axis, lamb, weight, dirs, view, env_gt, mask, rcoef, (float*)nullptr, g_d, g_s, g_axis, g_lamb, g_weight, rparts, fws, bn, K, R, C, eh, ew, imH, imW, F0d, 1, 1.0f, 10.0f, st); });
+  // decoder heads: standalone passes vs the prologue / epilogue of the fused kernels (premap 3)
+  auto heads_fwd_p = (decltype(&sgr_light_heads_fwd))dlsym(lib, "sgr_light_heads_fwd");
+  auto heads_bwd_p = (decltype(&sgr_light_heads_bwd))dlsym(lib, "sgr_light_heads_bwd");
+  auto heads_ok_p = (decltype(&sgr_heads_prologue_supported))dlsym(lib, "sgr_heads_prologue_supported");
+  if (heads_fwd_p && heads_bwd_p && heads_ok_p && heads_ok_p(K, R, C, eh, ew)) {
+    float* xa = dev_rand(P * K * 3, -2, 2, 21); float* xl = dev_rand(P * K, -2, 2, 22); float* xw = dev_rand(P * K * 3, -2, 2, 23);
+    float* ha = dev_empty(P * K * 3); float* hl = dev_empty(P * K); float* hw = dev_empty(P * K * 3);
+    bench("sgr_light_heads_fwd", 2 * Bsg, [&] { return heads_fwd_p(xa, xl, xw, ha, hl, hw, (float*)nullptr, bn, K, R, C, st); });
+    bench("sgr_light_heads_bwd", 3 * Bsg, [&] { return heads_bwd_p(xa, xl, xw, g_axis, g_lamb, g_weight, (const float*)nullptr, ha, hl, hw, bn, K, R, C, st); });
+    bench("sgr_fused_fwd (env, premap 3)", Bbrdf + Bsg + Benv + Bout, [&] { return sgr_fused_fwd_p(albedo, normal, rough, xa, xl, xw, dirs, view, env, diffuse, spec, bn, K, R, C, eh, ew, imH, imW, F0d, 3, st); });
+    bench("sgr_fused_bwd_sg (premap 3)", Bbrdf + 2 * Bsg + Bout + Benv + Bsg, [&] { return sgr_fused_bwd_sg_p(g_env, g_d, g_s, albedo, normal, rough, xa, xl, xw, dirs, view, g_axis, g_lamb, g_weight, bn, K, R, C, eh, ew, imH, imW, F0d, 3, st); });
+    bench("sgr_fused_fwd_recon (premap 3)", Bbrdf + Bsg + Benv + Bout, [&] { return sgr_fused_fwd_recon_p(albedo, normal, rough, xa, xl, xw, dirs, view, env_gt, seg_s, ind, diffuse, spec, mask, rcoef, rparts, fws, bn, K, R, C, eh, ew, imH, imW, F0d, 3, st); });
+    bench("sgr_fused_bwd_recon (premap 3)", Bbrdf + 2 * Bsg + Bout + Benv + Bsg, [&] { return sgr_fused_bwd_recon_p(albedo, normal, rough, xa, xl, xw, dirs, view, env_gt, mask, rcoef, (float*)nullptr, g_d, g_s, g_axis, g_lamb, g_weight, rparts, fws, bn, K, R, C, eh, ew, imH, imW, F0d, 3, 1.0f, 10.0f, st); });
+  }
   return 0;
 }
