@@ -653,7 +653,10 @@ static int fused_fwd_recon_impl(const float* albedo, const float* normal, const 
   static const int f1_mode = [] { const char* e = getenv("SGR_F1_MODE"); return !e ? 0 : (!strcmp(e, "half") ? 1 : (!strcmp(e, "scalar") ? 2 : 0)); }();
   // SGR_F1_MODE=pkhalf: the packed half-wave statistics kernel also for 7..12 lobes on the 8x16 grid (3 waves per SIMD)
   static const bool f1_pkhalf = [] { const char* e = getenv("SGR_F1_MODE"); return e && !strcmp(e, "pkhalf"); }();
-  const bool wide = K > 12 || ew == 32 || (f1_pkhalf && K > 6);      // beyond the 12-lobe 8x16 kernels: packed half-wave statistics kernel (12 lobes per half for K > 12)
+  // premap == 3 (decoder heads as the prologue): always the half-wave kernel -- at three waves per SIMD the 42 tanh per lane
+  // disappear behind the other waves' row loops (165 us with or without them at config 2), where the one-pixel-per-lane
+  // kernel's 84 per lane at two waves per SIMD cost 22-32 us
+  const bool wide = K > 12 || ew == 32 || (f1_pkhalf && K > 6) || premap == 3;      // beyond the 12-lobe 8x16 kernels: packed half-wave statistics kernel (12 lobes per half for K > 12)
   const bool f1_half = !wide && f1_mode == 1 && K > 6;
   const int tiles = (f1_half || wide) ? recon_tiles32(R * C) : recon_tiles(R * C);
   float* den_img = workspace;
@@ -685,10 +688,7 @@ static int fused_fwd_recon_impl(const float* albedo, const float* normal, const 
     else hipLaunchKernelGGL((fwd_half_kernel<2, false, true, 2, true>), grid, block, 0, st, a);
   } else {
     const dim3 grid = wave_grid(bn, R, C), block(kWave);
-    if (heads) {      // 6 < K <= 12, envWidth 16 (checked above)
-      if (p1) hipLaunchKernelGGL((fwd_pk_kernel<12, 1, false, true, true, true>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((fwd_pk_kernel<12, 2, false, true, true, true>), grid, block, 0, st, a);
-    } else if (f1_mode == 0 && K <= 6) {
+    if (f1_mode == 0 && K <= 6) {
       if (p1) hipLaunchKernelGGL((fwd_pk_kernel<6, 1, false, true, true>), grid, block, 0, st, a);
       else hipLaunchKernelGGL((fwd_pk_kernel<6, 2, false, true, true>), grid, block, 0, st, a);
     } else if (f1_mode == 0) {
