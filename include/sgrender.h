@@ -239,7 +239,7 @@ int sgr_fused_recon_workspace_floats(int bn, int R, int C);
 
 /* Forward: sgr_fused_fwd without the env output, plus the statistics of sgr_recon_loss_fwd stage 0 taken on
  * the fly against env_gt:  diffuse, spec [bn,3,R,C];  mask [bn,R*C];  coef [bn] (LSregress scale, models.py:7-21);
- * parts = (0, sum mask) for this rank's shard. */
+ * parts (nullable) = (0, sum mask) for this rank's shard: what a sharded caller all-reduces before the backward pass. */
 int sgr_fused_fwd_recon(const float* albedo, const float* normal, const float* rough, const float* axis,
                         const float* lamb, const float* weight, const float* dirs, const float* view,
                         const float* env_gt, const float* seg_small, const float* env_ind,
@@ -269,6 +269,19 @@ int sgr_fused_bwd_recon(const float* albedo, const float* normal, const float* r
                         int bn, int K, int R, int C, int eh, int ew, int imH, int imW, float F0, int premap,
                         float offset, float rec_weight, void* stream);
 
+/* sgr_fused_bwd_recon for an unsharded batch (den = this shard's own mask sum), with the objective's scalar tail taken in the same
+ * fold (no sgr_objective_finalize launch):  *recon_err = num / max(den, 1e-5) / (3 eh ew),
+ * *objective = ren_weight * *render_err + rec_weight * *recon_err  (trainLight.py:237).  applied2 (nullable): slot 0 of
+ * sgr_rescale_inplace_flip's pair is set to 1 (the gradients are those of the objective itself). */
+int sgr_fused_bwd_recon_total(const float* albedo, const float* normal, const float* rough, const float* axis,
+                              const float* lamb, const float* weight, const float* dirs, const float* view,
+                              const float* env_gt, const float* mask, const float* coef,
+                              const float* g_diffuse, const float* g_spec,
+                              float* g_axis, float* g_lamb, float* g_weight, float* parts, float* workspace,
+                              int bn, int K, int R, int C, int eh, int ew, int imH, int imW, float F0, int premap,
+                              float offset, float rec_weight, const float* render_err, float ren_weight,
+                              float* objective, float* recon_err, float* applied2, void* stream);
+
 /* Tail of the light objective on the device: *recon_err = parts_e[0] / max(parts_e[1], 1e-5) / divisor_e (divisor 3 * eh * ew,
  * wrapperBRDFLight.py:179-188), *objective = ren_w * *render_err + rec_w * *recon_err (trainLight.py:237).  parts_e = (numerator,
  * env-mask sum), rank-summed by the caller when the batch is sharded. */
@@ -279,6 +292,11 @@ int sgr_objective_finalize(const float* render_err, const float* parts_e, float 
  * place (i < count <= 4; x, n are HOST arrays of device pointers / lengths), then *applied = *scale.  Skipped on the
  * device when the two are equal (the cotangent of a scalar objective is normally 1).  No host sync. */
 int sgr_rescale_inplace(float* const* x, const long long* n, int count, const float* scale, float* applied, void* stream);
+
+/* The same in ONE launch (1 <= count <= 4): `applied2` holds two slots, the factor currently applied in applied2[parity]; on
+ * return the new one (*scale) is in applied2[1 - parity] -- the caller flips its parity after every call. */
+int sgr_rescale_inplace_flip(float* const* x, const long long* n, int count, const float* scale, float* applied2, int parity,
+                             void* stream);
 
 /* ---- light-decoder output heads --------------------------------------------
  * The activations at the end of models.decoderLight.forward (models.py:336-346) for the three decoders

@@ -69,7 +69,9 @@ SIGNATURES = {
     "sgr_light_heads_fwd": ([_P] * 7 + [_I] * 4 + [_P], c_int),
     "sgr_light_heads_bwd": ([_P] * 10 + [_I] * 4 + [_P], c_int),
     "sgr_rescale_inplace": ([_P, _P, _I, _P, _P, _P], c_int),
+    "sgr_rescale_inplace_flip": ([_P, _P, _I, _P, _P, _I, _P], c_int),
     "sgr_fused_bwd_recon": ([_P] * 19 + [_I] * 8 + [_F, _I, _F, _F, _P], c_int),
+    "sgr_fused_bwd_recon_total": ([_P] * 18 + [_I] * 8 + [_F, _I, _F, _F, _P, _F, _P, _P, _P, _P], c_int),
     "sgr_glue_workspace_floats": ([_I], c_int),
     "sgr_light_albedo_scale": ([_P] * 7 + [ctypes.c_longlong, ctypes.c_longlong, _P], c_int),
     "sgr_light_input_fwd": ([_P] * 9 + [_I] * 5 + [_P], c_int),

@@ -608,6 +608,25 @@ __global__ __launch_bounds__(256) void rescale_kernel(RescaleArgs r, const float
   }
 }
 __global__ void set_scalar_kernel(float* dst, const float* src) { dst[0] = src[0]; }
+// the same in one launch: `applied` is a pair of slots, read at [parity] by every workgroup and written at [1 - parity] by the first
+// one (no workgroup reads the slot that is written); the caller flips the parity after each call
+__global__ __launch_bounds__(256) void rescale_flip_kernel(RescaleArgs r, const float* __restrict__ s, float* __restrict__ applied2, int parity) {
+  const float sv = s[0], f = sv / applied2[parity];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) applied2[1 - parity] = sv;
+  if (f == 1.0f) return;
+  float* __restrict__ x = r.x[blockIdx.y];
+  const long long n = r.n[blockIdx.y];
+  const long long stride = (long long)gridDim.x * 256 * 4;
+  for (long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += stride) {
+    if (i0 + 3 < n) {
+      f32x4 v = *reinterpret_cast<f32x4*>(x + i0);
+      v *= f;
+      *reinterpret_cast<f32x4*>(x + i0) = v;
+    } else {
+      for (long long i = i0; i < n; ++i) x[i] *= f;
+    }
+  }
+}
 
 }  // namespace sgr
 
@@ -635,7 +654,7 @@ static int fused_fwd_recon_impl(const float* albedo, const float* normal, const 
                                float* spec, float* mask, float* coef, float* parts, float* workspace, int bn, int K, int R, int C,
                                int eh, int ew, int imH, int imW, float F0, int premap, void* stream) {
   SGR_REQUIRE(albedo && normal && rough && axis && lamb && weight && dirs && view && env_gt && seg_small && env_ind && diffuse &&
-                  spec && mask && coef && parts && workspace,
+                  spec && mask && coef && workspace,
               "sgr_fused_fwd_recon: NULL tensor");
   SGR_REQUIRE(bn > 0 && K > 0 && R > 0 && C > 0 && eh > 0 && ew > 0, "sgr_fused_fwd_recon: non-positive size");
   SGR_SUPPORTED(fused_recon_ok(K, R, C, eh, ew), "sgr_fused_fwd_recon: needs envWidth 16 or 32 and SGNum <= 24 (use the unfused calls)");
@@ -703,7 +722,8 @@ static int fused_fwd_recon_impl(const float* albedo, const float* normal, const 
     }
   }
   hipLaunchKernelGGL(recon_fold0, dim3(bn), dim3(kRThreads), 0, st, ws0, coef, den_img, tiles);
-  hipLaunchKernelGGL(recon_fold1, dim3(1), dim3(kRThreads), 0, st, ws0, den_img, parts, bn, 0);   // parts = (0, local sum of the env mask)
+  if (parts)      // (0, local sum of the env mask): what a sharded caller all-reduces before the backward pass; nobody else needs it
+    hipLaunchKernelGGL(recon_fold1, dim3(1), dim3(kRThreads), 0, st, ws0, den_img, parts, bn, 0, ObjectiveTail{});
   return sgr_check((int)hipGetLastError(), "sgr_fused_fwd_recon");
 }
 
@@ -726,12 +746,12 @@ extern "C" int sgr_fused_fwd_recon_tan(const float* albedo, const float* normal,
                               diffuse, spec, mask, coef, parts, workspace, bn, K, R, C, eh, ew, imH, imW, F0, premap, stream);
 }
 
-extern "C" int sgr_fused_bwd_recon(const float* albedo, const float* normal, const float* rough, const float* axis, const float* lamb,
-                                   const float* weight, const float* dirs, const float* view, const float* env_gt, const float* mask,
-                                   const float* coef, const float* den_global, const float* g_diffuse, const float* g_spec,
-                                   float* g_axis, float* g_lamb, float* g_weight, float* parts, float* workspace, int bn, int K, int R,
-                                   int C, int eh, int ew, int imH, int imW, float F0, int premap, float offset, float rec_weight,
-                                   void* stream) {
+static int fused_bwd_recon_impl(const float* albedo, const float* normal, const float* rough, const float* axis, const float* lamb,
+                               const float* weight, const float* dirs, const float* view, const float* env_gt, const float* mask,
+                               const float* coef, const float* den_global, const float* g_diffuse, const float* g_spec,
+                               float* g_axis, float* g_lamb, float* g_weight, float* parts, float* workspace, int bn, int K, int R,
+                               int C, int eh, int ew, int imH, int imW, float F0, int premap, float offset, float rec_weight,
+                               ObjectiveTail tail, void* stream) {
   SGR_REQUIRE(albedo && normal && rough && axis && lamb && weight && dirs && view && env_gt && mask && coef && g_diffuse && g_spec &&
                   g_axis && g_lamb && g_weight && parts && workspace,
               "sgr_fused_bwd_recon: NULL tensor");
@@ -778,8 +798,32 @@ extern "C" int sgr_fused_bwd_recon(const float* albedo, const float* normal, con
     else SGR_LAUNCH_BR(32, 4);
 #undef SGR_LAUNCH_BR
   }
-  hipLaunchKernelGGL(recon_fold1, dim3(1), dim3(kRThreads), 0, st, ws1, den_img, parts, bn, tiles);     // parts = (loss numerator, local sum of the env mask)
+  hipLaunchKernelGGL(recon_fold1, dim3(1), dim3(kRThreads), 0, st, ws1, den_img, parts, bn, tiles, tail);     // parts = (loss numerator, local sum of the env mask)
   return sgr_check((int)hipGetLastError(), "sgr_fused_bwd_recon");
+}
+
+extern "C" int sgr_fused_bwd_recon(const float* albedo, const float* normal, const float* rough, const float* axis, const float* lamb,
+                                   const float* weight, const float* dirs, const float* view, const float* env_gt, const float* mask,
+                                   const float* coef, const float* den_global, const float* g_diffuse, const float* g_spec,
+                                   float* g_axis, float* g_lamb, float* g_weight, float* parts, float* workspace, int bn, int K, int R,
+                                   int C, int eh, int ew, int imH, int imW, float F0, int premap, float offset, float rec_weight,
+                                   void* stream) {
+  return fused_bwd_recon_impl(albedo, normal, rough, axis, lamb, weight, dirs, view, env_gt, mask, coef, den_global, g_diffuse, g_spec, g_axis,
+                              g_lamb, g_weight, parts, workspace, bn, K, R, C, eh, ew, imH, imW, F0, premap, offset, rec_weight, ObjectiveTail{},
+                              stream);
+}
+
+// one rank: the objective's scalar tail (sgr_objective_finalize) comes out of the same fold
+extern "C" int sgr_fused_bwd_recon_total(const float* albedo, const float* normal, const float* rough, const float* axis, const float* lamb,
+                                         const float* weight, const float* dirs, const float* view, const float* env_gt, const float* mask,
+                                         const float* coef, const float* g_diffuse, const float* g_spec, float* g_axis, float* g_lamb,
+                                         float* g_weight, float* parts, float* workspace, int bn, int K, int R, int C, int eh, int ew, int imH,
+                                         int imW, float F0, int premap, float offset, float rec_weight, const float* render_err, float ren_weight,
+                                         float* objective, float* recon_err, float* applied2, void* stream) {
+  SGR_REQUIRE(render_err && objective && recon_err, "sgr_fused_bwd_recon_total: NULL scalar");
+  ObjectiveTail tail{render_err, ren_weight, rec_weight, 3.0f * (float)(eh * ew), objective, recon_err, applied2};
+  return fused_bwd_recon_impl(albedo, normal, rough, axis, lamb, weight, dirs, view, env_gt, mask, coef, nullptr, g_diffuse, g_spec, g_axis,
+                              g_lamb, g_weight, parts, workspace, bn, K, R, C, eh, ew, imH, imW, F0, premap, offset, rec_weight, tail, stream);
 }
 
 // Cotangent scaling for gradients that were produced ahead of the backward call (sgr.light_objective):
@@ -802,4 +846,23 @@ extern "C" int sgr_rescale_inplace(float* const* x, const long long* n, int coun
   }
   hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, st, applied, scale);
   return sgr_check((int)hipGetLastError(), "sgr_rescale_inplace");
+}
+
+// sgr_rescale_inplace in ONE launch: applied2 = two slots, the current factor in applied2[parity]; on return the new one is in
+// applied2[1 - parity] (the caller flips its parity).  count in 1..4.
+extern "C" int sgr_rescale_inplace_flip(float* const* x, const long long* n, int count, const float* scale, float* applied2, int parity,
+                                        void* stream) {
+  SGR_REQUIRE(x && n && scale && applied2 && count >= 1 && (parity == 0 || parity == 1), "sgr_rescale_inplace_flip: bad argument");
+  SGR_SUPPORTED(count <= 4, "sgr_rescale_inplace_flip: at most 4 tensors per call");
+  RescaleArgs r{};
+  long long nmax = 0;
+  for (int i = 0; i < count; ++i) {
+    SGR_REQUIRE(x[i] && n[i] > 0, "sgr_rescale_inplace_flip: empty tensor");
+    r.x[i] = x[i]; r.n[i] = n[i];
+    nmax = n[i] > nmax ? n[i] : nmax;
+  }
+  const long long blocks = (nmax + 1023) / 1024;
+  hipLaunchKernelGGL(rescale_flip_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024), (unsigned)count), dim3(256), 0, (hipStream_t)stream, r,
+                     scale, applied2, parity);
+  return sgr_check((int)hipGetLastError(), "sgr_rescale_inplace_flip");
 }

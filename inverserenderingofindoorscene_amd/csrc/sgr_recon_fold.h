@@ -42,16 +42,27 @@ static __global__ __launch_bounds__(kRThreads) void recon_fold0(const float* __r
   }
 }
 
+// The tail of the light objective when the batch is not sharded (otherwise sgr_objective_finalize after the all-reduce):
+//   reconstErr = num / max(den, 1e-5) / divisor (wrapperBRDFLight.py:179-188), objective = ren_w renderErr + rec_w reconstErr (trainLight.py:237)
+struct ObjectiveTail { const float* render_err; float ren_w, rec_w, divisor_e; float* objective; float* recon_err; float* one; };
+
 static __global__ __launch_bounds__(kRThreads) void recon_fold1(const float* __restrict__ ws, const float* __restrict__ den_img,
-                                                          float* __restrict__ parts, int bn, int nblk) {
+                                                          float* __restrict__ parts, int bn, int nblk, ObjectiveTail tail) {
   __shared__ double lds[kRThreads * 2];
   double v[2] = {0.0, 0.0};
   for (int i = threadIdx.x; i < bn * nblk; i += kRThreads) v[0] += (double)ws[i];
   for (int i = threadIdx.x; i < bn; i += kRThreads) v[1] += (double)den_img[i];
   block_sum_double<2>(v, lds);
   if (threadIdx.x == 0) {
-    parts[0] = (float)v[0];
-    parts[1] = (float)v[1];
+    const float num = (float)v[0], den = (float)v[1];
+    parts[0] = num;
+    parts[1] = den;
+    if (tail.objective) {
+      const float rec = num / fmaxf(den, 1e-5f) / tail.divisor_e;
+      tail.recon_err[0] = rec;
+      tail.objective[0] = tail.ren_w * tail.render_err[0] + tail.rec_w * rec;
+      if (tail.one) tail.one[0] = 1.0f;      // the factor the gradients are scaled by so far (sgr_rescale_inplace_flip's slot 0)
+    }
   }
 }
 

@@ -338,6 +338,7 @@ class _LightObjective(torch.autograd.Function):
         sg_args = (_ptr(albedo_c), _ptr(normal_c), _ptr(rough_c), _ptr(axis_c), _ptr(lamb_c), _ptr(weight_c), _ptr(d), _ptr(v))
         sg_args_tan = (_ptr(albedo_c), _ptr(normal_c), _ptr(rough_c), _ptr(axis_c), _ptr(lam_t), _ptr(w_t), _ptr(d), _ptr(v))
         with torch.cuda.device(dev):
+            sharded = _sharded(group)
             # the pooled object mask is an output of the render-loss pass; the env mask needs it first
             if (imH, imW) == (R, C):
                 seg_small = seg_c
@@ -345,14 +346,14 @@ class _LightObjective(torch.autograd.Function):
                 seg_small = F.avg_pool2d(seg_c, 2)
             _lib.call("sgr_fused_fwd_recon_tan", *sg_args, _ptr(gt), _ptr(seg_small), _ptr(ind), _ptr(lam_t) if handoff else None,
                       _ptr(w_t) if handoff else None, _ptr(diffuse),
-                      _ptr(spec), _ptr(mask), _ptr(coef), _ptr(parts_f), _ptr(ws), bn, K, R, C, eh, ew, h, w, float(F0), pm, st)
-            sharded = _sharded(group)
+                      _ptr(spec), _ptr(mask), _ptr(coef), _ptr(parts_f) if sharded else None, _ptr(ws), bn, K, R, C, eh, ew, h, w, float(F0), pm, st)
             render_err, scale_r = torch.empty((), **f32), torch.empty(1, **f32)
             _lib.call("sgr_render_loss_fwd_total", _ptr(diffuse), _ptr(spec), _ptr(im_c), _ptr(seg_c), _ptr(im_s), _ptr(seg_s),
                       _ptr(rendered), _ptr(coef_ds), _ptr(parts_r), None if sharded else _ptr(render_err), None if sharded else _ptr(scale_r),
                       3.0, _ptr(ws_r), bn, R, C, imH, imW, st)
-            # everything between the heavy kernels stays on the device and in two one-thread launches (a dozen one-element
-            # torch kernels before round 3: 0.05 ms of a 0.86 ms training step)
+            # everything between the heavy kernels stays on the device: one rank -- the scalar tails ride in the folds of the passes
+            # that produce their inputs (ten launches per objective, eight of them small); sharded -- two one-thread launches
+            # around the collectives (a dozen one-element torch kernels before round 3: 0.05 ms of a 0.86 ms training step)
             recon_err, objective = torch.empty((), **f32), torch.empty((), **f32)
             den_e_c = None
             if sharded:
@@ -363,16 +364,24 @@ class _LightObjective(torch.autograd.Function):
             g_d, g_s = torch.empty_like(diffuse), torch.empty_like(spec)
             _lib.call("sgr_render_loss_bwd_scaled", _ptr(_const_scalar(dev, float(ren_w))), _ptr(scale_r), _ptr(diffuse), _ptr(spec), _ptr(im_s),
                       _ptr(seg_s), _ptr(coef_ds), _ptr(g_d), _ptr(g_s), bn, R, C, st)
-            _lib.call("sgr_fused_bwd_recon", *sg_args_tan, _ptr(gt), _ptr(mask), _ptr(coef), _ptr(den_e_c), _ptr(g_d), _ptr(g_s),
-                      _ptr(g_axis), _ptr(g_lamb), _ptr(g_weight), _ptr(parts_b), _ptr(ws),
-                      bn, K, R, C, eh, ew, h, w, float(F0), 2 if handoff else pm, float(offset), float(rec_w), st)
+            # `applied`: two slots, the cotangent the stored gradients are currently scaled by in applied[ctx.parity] (see backward)
             if sharded:
+                _lib.call("sgr_fused_bwd_recon", *sg_args_tan, _ptr(gt), _ptr(mask), _ptr(coef), _ptr(den_e_c), _ptr(g_d), _ptr(g_s),
+                          _ptr(g_axis), _ptr(g_lamb), _ptr(g_weight), _ptr(parts_b), _ptr(ws),
+                          bn, K, R, C, eh, ew, h, w, float(F0), 2 if handoff else pm, float(offset), float(rec_w), st)
                 num_e = parts_b[0:1].clone()
                 dist.all_reduce(num_e, op=dist.ReduceOp.SUM, group=group)      # the second and last collective: the reconstruction numerator
                 parts_b = torch.cat([num_e, den_e_c])
-            _lib.call("sgr_objective_finalize", _ptr(render_err), _ptr(parts_b), float(ren_w), float(rec_w), 3.0 * eh * ew,
-                      _ptr(objective), _ptr(recon_err), st)
-        applied = torch.ones(1, **f32)            # the cotangent the stored gradients are currently scaled by
+                _lib.call("sgr_objective_finalize", _ptr(render_err), _ptr(parts_b), float(ren_w), float(rec_w), 3.0 * eh * ew,
+                          _ptr(objective), _ptr(recon_err), st)
+                applied = torch.ones(2, **f32)
+            else:
+                applied = torch.empty(2, **f32)
+                _lib.call("sgr_fused_bwd_recon_total", *sg_args_tan, _ptr(gt), _ptr(mask), _ptr(coef), _ptr(g_d), _ptr(g_s),
+                          _ptr(g_axis), _ptr(g_lamb), _ptr(g_weight), _ptr(parts_b), _ptr(ws),
+                          bn, K, R, C, eh, ew, h, w, float(F0), 2 if handoff else pm, float(offset), float(rec_w), _ptr(render_err),
+                          float(ren_w), _ptr(objective), _ptr(recon_err), _ptr(applied), st)
+        ctx.parity = 0
         ctx.save_for_backward(g_axis, g_lamb, g_weight, applied)
         ctx.mark_non_differentiable(render_err, recon_err, rendered, coef)
         return objective, render_err, recon_err, rendered, coef
@@ -391,17 +400,19 @@ class _LightObjective(torch.autograd.Function):
             # may be somebody's .grad by now -- leave them alone.  If the first backward came with a zero cotangent the
             # stored gradients were scaled to zero in place and cannot be recovered: say so instead of returning inf/NaN
             # (rare path, so the host sync is acceptable)
-            if float(applied[0].item()) == 0.0:
+            if float(applied[ctx.parity].item()) == 0.0:
                 raise RuntimeError("sgrender: light_objective was first back-propagated with a zero cotangent; its stored "
                                    "gradients are gone -- re-evaluate the objective instead of reusing the graph")
-            f = g_obj.detach() / applied[0]
+            f = g_obj.detach() / applied[ctx.parity]
             return tuple([None] * 3 + [g * f if ctx.needs_input_grad[3 + i] else None for i, g in enumerate(gs)] + [None] * 10)
         ctx.handed_out = True
         ptrs = (ctypes.c_void_p * 3)(*[g.data_ptr() for g in gs])
         lens = (ctypes.c_longlong * 3)(*[g.numel() for g in gs])
         scale = g_obj.detach().to(torch.float32).reshape(1).contiguous()
         with torch.cuda.device(dev):
-            _lib.call("sgr_rescale_inplace", ctypes.addressof(ptrs), ctypes.addressof(lens), 3, _ptr(scale), _ptr(applied), _stream(dev))
+            _lib.call("sgr_rescale_inplace_flip", ctypes.addressof(ptrs), ctypes.addressof(lens), 3, _ptr(scale), _ptr(applied), ctx.parity,
+                      _stream(dev))
+        ctx.parity = 1 - ctx.parity
         outs = [None] * 16
         for i, g in ((3, g_axis), (4, g_lamb), (5, g_weight)):
             if ctx.needs_input_grad[i]:
