@@ -159,10 +159,13 @@ class _RenderLoss(torch.autograd.Function):
                           _stream(dev))
         ctx.save_for_backward(d, s, im_s, seg_s, coef, scale)
         ctx.mark_non_differentiable(rendered)
+        ctx.set_materialize_grads(False)      # no zero image for the unused cotangent of `rendered` on every backward
         return loss, rendered
 
     @staticmethod
     def backward(ctx, g_loss, _g_ren):
+        if g_loss is None:
+            return (None,) * 7
         d, s, im_s, seg_s, coef, scale = ctx.saved_tensors
         dev = d.device
         bn, _, R, C = d.shape
@@ -243,10 +246,13 @@ class _ReconLossParts(torch.autograd.Function):
         ctx.offset = float(offset)
         num, den = parts[0], parts[1]
         ctx.mark_non_differentiable(den, coef)
+        ctx.set_materialize_grads(False)
         return num, den, coef
 
     @staticmethod
     def backward(ctx, g_num, _g_den, _g_coef):
+        if g_num is None:
+            return (None,) * 5
         e, g, mask, coef = ctx.saved_tensors
         dev = e.device
         bn, _, R, C, eh, ew = e.shape
@@ -384,10 +390,13 @@ class _LightObjective(torch.autograd.Function):
         ctx.parity = 0
         ctx.save_for_backward(g_axis, g_lamb, g_weight, applied)
         ctx.mark_non_differentiable(render_err, recon_err, rendered, coef)
+        ctx.set_materialize_grads(False)      # otherwise every backward zero-fills cotangents for the four reported outputs (one of them an image)
         return objective, render_err, recon_err, rendered, coef
 
     @staticmethod
     def backward(ctx, g_obj, *_unused):
+        if g_obj is None:
+            return (None,) * 16
         g_axis, g_lamb, g_weight, applied = ctx.saved_tensors
         if any(ctx.needs_input_grad[:3]) or any(ctx.needs_input_grad[6:10]):
             raise NotImplementedError("sgrender: light_objective differentiates w.r.t. the SG parameters only "
