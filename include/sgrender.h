@@ -256,6 +256,16 @@ int sgr_fused_fwd_recon_tan(const float* albedo, const float* normal, const floa
                             int bn, int K, int R, int C, int eh, int ew, int imH, int imW, float F0, int premap,
                             void* stream);
 
+/* sgr_fused_fwd_recon_tan with the object mask at its own resolution: seg [bn,1,segH,segW], (segH, segW) = (R, C) or (2R, 2C);
+ * the latter is pooled 2x2 by the kernel (wrapperBRDFLight.py:171: adaptive_avg_pool2d's sum order), no separate pooling pass. */
+int sgr_fused_fwd_recon_seg(const float* albedo, const float* normal, const float* rough, const float* axis,
+                            const float* lamb, const float* weight, const float* dirs, const float* view,
+                            const float* env_gt, const float* seg, int segH, int segW, const float* env_ind,
+                            float* lamb_tan /* nullable */, float* weight_tan /* nullable */,
+                            float* diffuse, float* spec, float* mask, float* coef, float* parts /* nullable */, float* workspace,
+                            int bn, int K, int R, int C, int eh, int ew, int imH, int imW, float F0, int premap,
+                            void* stream);
+
 /* Backward of  objective = (render terms, through g_diffuse / g_spec) + rec_weight * reconstErr,
  *   reconstErr = num / max(den, 1e-5) / 3 / (eh*ew),  num = sum mask (log(coef env + offset) - log(env_gt + offset))^2,
  * w.r.t. the SG parameters, with env recomputed in registers.  den = *den_global when given (the mask sum

@@ -66,6 +66,7 @@ SIGNATURES = {
     "sgr_fused_recon_workspace_floats": ([_I, _I, _I], c_int),
     "sgr_fused_fwd_recon": ([_P] * 17 + [_I] * 8 + [_F, _I, _P], c_int),
     "sgr_fused_fwd_recon_tan": ([_P] * 19 + [_I] * 8 + [_F, _I, _P], c_int),
+    "sgr_fused_fwd_recon_seg": ([_P] * 10 + [_I, _I] + [_P] * 9 + [_I] * 8 + [_F, _I, _P], c_int),
     "sgr_light_heads_fwd": ([_P] * 7 + [_I] * 4 + [_P], c_int),
     "sgr_light_heads_bwd": ([_P] * 10 + [_I] * 4 + [_P], c_int),
     "sgr_rescale_inplace": ([_P, _P, _I, _P, _P, _P], c_int),

@@ -442,7 +442,8 @@ struct Args {
   const float* g_spec;    // [bn,3,R,C]
   // env reconstruction (fused objective): ground-truth env, pooled env mask inputs, per-image scale
   const float* env_gt;    // [bn,3,R,C,J]
-  const float* seg_small; // [bn,R,C]
+  const float* seg_small; // [bn,R,C], or [bn,2R,2C] when seg_pool2 (pooled 2x2 on the fly, wrapperBRDFLight.py:171)
+  int seg_pool2;
   const float* env_ind;   // [bn]
   const float* coef;      // [bn]      LSregress scale (constant in backward)
   const float* mask_in;   // [bn,R,C]  env mask from the forward pass
@@ -469,6 +470,20 @@ struct Args {
   float F0;
   int premap;
 };
+
+// pooled object mask of env cell p of image b (the seg_small factor of the env mask, wrapperBRDFLight.py:171-174): read, or the
+// 2x2 average of the full-resolution mask in adaptive_avg_pool2d's summation order (bit-identical to pooling first)
+__device__ __forceinline__ float seg_small_at(const Args& a, int b, int p) {
+  const int RC = a.R * a.C;
+  if (a.seg_pool2) {
+    const int r = p / a.C, c = p - r * a.C, W = 2 * a.C;
+    const float* pl = a.seg_small + (size_t)b * 4 * RC + (size_t)(2 * r) * W + 2 * c;
+    const float2 t = *reinterpret_cast<const float2*>(pl), u = *reinterpret_cast<const float2*>(pl + W);
+    return (((t.x + t.y) + u.x) + u.y) * 0.25f;
+  }
+  return (a.seg_small + (size_t)b * RC)[(unsigned)p];
+}
+
 
 // Which pixel does this lane own?  One wave = 64 consecutive cells of one image.
 struct Pix {

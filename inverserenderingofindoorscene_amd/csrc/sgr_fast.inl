@@ -292,7 +292,7 @@ __global__ __launch_bounds__(kWave, 2) void fwd_fast_kernel(const Args a) {
   if (HAS_GT) {
     // env mask of the pixel (wrapperBRDFLight.py:172-174) and the wave's share of the per-image sums
     const float not_dark = (s_g / (3.0f * (float)a.J)) > 0.001f ? 1.0f : 0.0f;
-    const float m = x.active ? (a.seg_small + (size_t)b * RC)[(unsigned)p] * a.env_ind[b] * not_dark : 0.0f;
+    const float m = x.active ? seg_small_at(a, b, p) * a.env_ind[b] * not_dark : 0.0f;
     if (x.active) (a.mask + (size_t)b * RC)[(unsigned)p] = m;
     float r0 = m * m * s_pg, r1 = m * m * s_pp, r2 = m;
   #pragma unroll
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(kWave, OCC) void fwd_half_kernel(const Args a) {
       v[i] = d_ + s_;
     }
     const float not_dark = (v[2] / (3.0f * (float)a.J)) > 0.001f ? 1.0f : 0.0f;
-    const float m = (x.active && half == 0) ? (a.seg_small + (size_t)b * RC)[(unsigned)p] * a.env_ind[b] * not_dark : 0.0f;
+    const float m = (x.active && half == 0) ? seg_small_at(a, b, p) * a.env_ind[b] * not_dark : 0.0f;
     if (x.active && half == 0) (a.mask + (size_t)b * RC)[(unsigned)p] = m;
     float r0 = m * m * v[0], r1 = m * m * v[1], r2 = m;
 #pragma unroll

@@ -650,9 +650,9 @@ extern "C" int sgr_fused_recon_workspace_floats(int bn, int R, int C) {
 
 static int fused_fwd_recon_impl(const float* albedo, const float* normal, const float* rough, const float* axis, const float* lamb,
                                const float* weight, const float* dirs, const float* view, const float* env_gt,
-                               const float* seg_small, const float* env_ind, float* lamb_tan, float* weight_tan, float* diffuse,
-                               float* spec, float* mask, float* coef, float* parts, float* workspace, int bn, int K, int R, int C,
-                               int eh, int ew, int imH, int imW, float F0, int premap, void* stream) {
+                               const float* seg_small, int seg_pool2, const float* env_ind, float* lamb_tan, float* weight_tan,
+                               float* diffuse, float* spec, float* mask, float* coef, float* parts, float* workspace, int bn, int K, int R,
+                               int C, int eh, int ew, int imH, int imW, float F0, int premap, void* stream) {
   SGR_REQUIRE(albedo && normal && rough && axis && lamb && weight && dirs && view && env_gt && seg_small && env_ind && diffuse &&
                   spec && mask && coef && workspace,
               "sgr_fused_fwd_recon: NULL tensor");
@@ -662,7 +662,7 @@ static int fused_fwd_recon_impl(const float* albedo, const float* normal, const 
   Args a{};
   a.albedo = albedo; a.normal = normal; a.rough = rough; a.axis = axis; a.lamb = lamb; a.weight = weight;
   a.dirs = reinterpret_cast<const float4*>(dirs); a.view = view; a.diffuse = diffuse; a.spec = spec;
-  a.env_gt = env_gt; a.seg_small = seg_small; a.env_ind = env_ind; a.mask = mask;
+  a.env_gt = env_gt; a.seg_small = seg_small; a.seg_pool2 = seg_pool2; a.env_ind = env_ind; a.mask = mask;
   a.lamb_tan = lamb_tan; a.weight_tan = weight_tan;
   set_dims(a, bn, K, R, C, eh, ew, imH, imW);
   a.F0 = F0; a.premap = premap == 1 ? 1 : (premap == 3 ? 3 : 0);
@@ -732,7 +732,7 @@ extern "C" int sgr_fused_fwd_recon(const float* albedo, const float* normal, con
                                    const float* seg_small, const float* env_ind, float* diffuse, float* spec, float* mask,
                                    float* coef, float* parts, float* workspace, int bn, int K, int R, int C, int eh, int ew, int imH,
                                    int imW, float F0, int premap, void* stream) {
-  return fused_fwd_recon_impl(albedo, normal, rough, axis, lamb, weight, dirs, view, env_gt, seg_small, env_ind, nullptr, nullptr, diffuse,
+  return fused_fwd_recon_impl(albedo, normal, rough, axis, lamb, weight, dirs, view, env_gt, seg_small, 0, env_ind, nullptr, nullptr, diffuse,
                               spec, mask, coef, parts, workspace, bn, K, R, C, eh, ew, imH, imW, F0, premap, stream);
 }
 // also returns the post-tan sharpness / intensity for sgr_fused_bwd_recon(premap = 2)
@@ -742,7 +742,20 @@ extern "C" int sgr_fused_fwd_recon_tan(const float* albedo, const float* normal,
                                        float* weight_tan, float* diffuse, float* spec, float* mask, float* coef, float* parts,
                                        float* workspace, int bn, int K, int R, int C, int eh, int ew, int imH, int imW, float F0,
                                        int premap, void* stream) {
-  return fused_fwd_recon_impl(albedo, normal, rough, axis, lamb, weight, dirs, view, env_gt, seg_small, env_ind, lamb_tan, weight_tan,
+  return fused_fwd_recon_impl(albedo, normal, rough, axis, lamb, weight, dirs, view, env_gt, seg_small, 0, env_ind, lamb_tan, weight_tan,
+                              diffuse, spec, mask, coef, parts, workspace, bn, K, R, C, eh, ew, imH, imW, F0, premap, stream);
+}
+// the same with the object mask at its own resolution: [bn,1,segH,segW] with (segH, segW) = (R, C) or (2R, 2C) -- pooled 2x2 by the
+// kernel (wrapperBRDFLight.py:171), no separate pooling pass
+extern "C" int sgr_fused_fwd_recon_seg(const float* albedo, const float* normal, const float* rough, const float* axis,
+                                       const float* lamb, const float* weight, const float* dirs, const float* view,
+                                       const float* env_gt, const float* seg, int segH, int segW, const float* env_ind, float* lamb_tan,
+                                       float* weight_tan, float* diffuse, float* spec, float* mask, float* coef, float* parts,
+                                       float* workspace, int bn, int K, int R, int C, int eh, int ew, int imH, int imW, float F0,
+                                       int premap, void* stream) {
+  const bool same = segH == R && segW == C, twice = segH == 2 * R && segW == 2 * C;
+  SGR_SUPPORTED(same || twice, "sgr_fused_fwd_recon_seg: object mask / env-grid ratio must be 1 or 2 (pool first)");
+  return fused_fwd_recon_impl(albedo, normal, rough, axis, lamb, weight, dirs, view, env_gt, seg, twice ? 1 : 0, env_ind, lamb_tan, weight_tan,
                               diffuse, spec, mask, coef, parts, workspace, bn, K, R, C, eh, ew, imH, imW, F0, premap, stream);
 }
 

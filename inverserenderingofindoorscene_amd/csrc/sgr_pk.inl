@@ -501,7 +501,7 @@ __device__ __forceinline__ void fwd_pk_body(const Args& a, int unit, float* tile
   if (HAS_GT) {
     // env mask of the pixel (wrapperBRDFLight.py:172-174) and the wave's share of the per-image sums
     const float not_dark = ((s_g.x + s_g.y) / (3.0f * (float)a.J)) > 0.001f ? 1.0f : 0.0f;
-    const float m = x.active ? (a.seg_small + (size_t)b * RC)[(unsigned)p] * a.env_ind[b] * not_dark : 0.0f;
+    const float m = x.active ? seg_small_at(a, b, p) * a.env_ind[b] * not_dark : 0.0f;
     if (x.active) (a.mask + (size_t)b * RC)[(unsigned)p] = m;
     float r0 = m * m * (s_pg.x + s_pg.y), r1 = m * m * (s_pp.x + s_pp.y), r2 = m;
 #pragma unroll
@@ -736,7 +736,7 @@ __device__ __forceinline__ void fwd_pk_half_body(const Args& a, const Pix x, flo
       st[i] = d_ + s_;
     }
     const float not_dark = (st[2] / (3.0f * (float)a.J)) > 0.001f ? 1.0f : 0.0f;
-    const float m = x.active ? (a.seg_small + (size_t)b * RC)[(unsigned)p] * a.env_ind[b] * not_dark : 0.0f;
+    const float m = x.active ? seg_small_at(a, b, p) * a.env_ind[b] * not_dark : 0.0f;
     if (x.active && half == 0) (a.mask + (size_t)b * RC)[(unsigned)p] = m;
     const float hm = half == 0 ? m : 0.0f;
     float r0 = hm * m * st[0], r1 = hm * m * st[1], r2 = hm;

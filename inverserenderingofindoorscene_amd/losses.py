@@ -345,12 +345,8 @@ class _LightObjective(torch.autograd.Function):
         sg_args_tan = (_ptr(albedo_c), _ptr(normal_c), _ptr(rough_c), _ptr(axis_c), _ptr(lam_t), _ptr(w_t), _ptr(d), _ptr(v))
         with torch.cuda.device(dev):
             sharded = _sharded(group)
-            # the pooled object mask is an output of the render-loss pass; the env mask needs it first
-            if (imH, imW) == (R, C):
-                seg_small = seg_c
-            else:
-                seg_small = F.avg_pool2d(seg_c, 2)
-            _lib.call("sgr_fused_fwd_recon_tan", *sg_args, _ptr(gt), _ptr(seg_small), _ptr(ind), _ptr(lam_t) if handoff else None,
+            # the env mask needs the pooled object mask before the render-loss pass produces it: the kernel pools 2x2 itself
+            _lib.call("sgr_fused_fwd_recon_seg", *sg_args, _ptr(gt), _ptr(seg_c), imH, imW, _ptr(ind), _ptr(lam_t) if handoff else None,
                       _ptr(w_t) if handoff else None, _ptr(diffuse),
                       _ptr(spec), _ptr(mask), _ptr(coef), _ptr(parts_f) if sharded else None, _ptr(ws), bn, K, R, C, eh, ew, h, w, float(F0), pm, st)
             render_err, scale_r = torch.empty((), **f32), torch.empty(1, **f32)
