@@ -19,6 +19,23 @@
 
 namespace sgr {
 
+// Wave priority of the prologue (loads, pre-map, shading frame) over the row loop: a wave that has just started takes the issue slots
+// first and reaches its own row loop sooner -- the prologue is 25-40 % of a wave's life (tools/wavetrace) and runs next to one or two
+// waves that are in their loops.  Measured A/B on one box (round 3): +0.9 % on the fwd+bwd step at priority 1 or 3, forward -2 us;
+// raising the priority of the data-movement phases as well (env tile flush, cotangent row requests) changed nothing; issuing every
+// prologue load before the first use (lobes, BRDF maps, cotangents in one burst) changed nothing either -- the latencies are hidden by
+// the other waves already; and in the objective's backward kernel the same priority made the step 1-2 % SLOWER, so that one stays at
+// the default.  0 = hardware default.
+#ifndef SGR_PROLOGUE_PRIO
+#define SGR_PROLOGUE_PRIO 3
+#endif
+#if SGR_PROLOGUE_PRIO > 0
+#define SGR_PRIO_PROLOGUE __builtin_amdgcn_s_setprio(SGR_PROLOGUE_PRIO);
+#define SGR_PRIO_LOOP __builtin_amdgcn_s_setprio(0);
+#else
+#define SGR_PRIO_PROLOGUE
+#define SGR_PRIO_LOOP
+#endif
 // -DSGR_TRACE (development builds only, tools/wavetrace): every wave of the packed kernels records when and where it ran
 #ifdef SGR_TRACE
 struct TraceRec { unsigned long long t0, t1, tp; unsigned hw, xcc; };
@@ -34,8 +51,8 @@ static __device__ TraceRec* g_trace = nullptr;
     g_trace[blockIdx.x] = r_;                                                                          \
   }
 #else
-#define SGR_TRACE_BEGIN
-#define SGR_TRACE_MARK
+#define SGR_TRACE_BEGIN SGR_PRIO_PROLOGUE
+#define SGR_TRACE_MARK SGR_PRIO_LOOP
 #define SGR_TRACE_END
 #endif
 

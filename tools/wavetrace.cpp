@@ -69,7 +69,8 @@ int main(int argc, char** argv) {
              (h[i].hw >> 8) & 15, (h[i].hw >> 4) & 3, h[i].tp - h[i].t0);
   };
   const size_t w64 = (size_t)bn * ((RC + 63) / 64), w32 = (size_t)bn * ((RC + 31) / 32);
-  run("fwd_env", w64, [&] { return sgr_fused_fwd_p(albedo, normal, rough, axis, lamb, weight, dirs, view, env, diffuse, spec, bn, K, R, C, eh, ew, imH, imW, 0.05f, 1, st); });
+  const size_t wfe = w32;      // the forward that writes the env image: half-wave kernel, one workgroup per 32 pixels (round 3)
+  run("fwd_env", wfe, [&] { return sgr_fused_fwd_p(albedo, normal, rough, axis, lamb, weight, dirs, view, env, diffuse, spec, bn, K, R, C, eh, ew, imH, imW, 0.05f, 1, st); });
   run("fwd_noenv", w64, [&] { return sgr_fused_fwd_p(albedo, normal, rough, axis, lamb, weight, dirs, view, (float*)nullptr, diffuse, spec, bn, K, R, C, eh, ew, imH, imW, 0.05f, 1, st); });
   run("bwd_genv", w32, [&] { return sgr_fused_bwd_sg_p(g_env, g_d, g_s, albedo, normal, rough, axis, lamb, weight, dirs, view, g_axis, g_lamb, g_weight, bn, K, R, C, eh, ew, imH, imW, 0.05f, 1, st); });
   // inter-kernel gap: forward and backward back to back (separate trace buffers, absolute timestamps)
@@ -88,17 +89,17 @@ int main(int argc, char** argv) {
     CHECK(hipEventRecord(e2, st));
     CHECK(hipEventSynchronize(e2));
     float ms01, ms12; CHECK(hipEventElapsedTime(&ms01, e0, e1)); CHECK(hipEventElapsedTime(&ms12, e1, e2));
-    CHECK(hipMemcpy(h.data(), trace, sizeof(TraceRec) * w64, hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(h.data(), trace, sizeof(TraceRec) * wfe, hipMemcpyDeviceToHost));
     CHECK(hipMemcpy(h2.data(), trace2, sizeof(TraceRec) * w32, hipMemcpyDeviceToHost));
     unsigned long long f0 = ~0ull, f1 = 0, b0 = ~0ull, b1 = 0;
-    for (size_t i = 0; i < w64; ++i) { if (h[i].t0 < f0) f0 = h[i].t0; if (h[i].t1 > f1) f1 = h[i].t1; }
+    for (size_t i = 0; i < wfe; ++i) { if (h[i].t0 < f0) f0 = h[i].t0; if (h[i].t1 > f1) f1 = h[i].t1; }
     for (size_t i = 0; i < w32; ++i) { if (h2[i].t0 < b0) b0 = h2[i].t0; if (h2[i].t1 > b1) b1 = h2[i].t1; }
     // the second forward overwrote `trace`; f0/f1 are of the SECOND forward, b0/b1 of the backward before it
     printf("# back-to-back rep %d: events fwd+bwd %.1f us, second fwd %.1f us; bwd wave span %.1f us; gap bwd last wave end -> next fwd first wave start %.2f us; next fwd wave span %.1f us\n",
            rep, ms01 * 1e3, ms12 * 1e3, (b1 - b0) / 100.0, ((long long)f0 - (long long)b1) / 100.0, (f1 - f0) / 100.0);
     if (rep == 2) {
-      printf("# fwd_env_after_bwd waves=%zu\n", w64);
-      for (size_t i = 0; i < w64; ++i)
+      printf("# fwd_env_after_bwd waves=%zu\n", wfe);
+      for (size_t i = 0; i < wfe; ++i)
         printf("fwd_env_after_bwd %zu %llu %llu %u %u %u %u %u %llu\n", i, h[i].t0 - f0, h[i].t1 - f0, h[i].xcc & 0xf, (h[i].hw >> 13) & 7, (h[i].hw >> 12) & 1,
                (h[i].hw >> 8) & 15, (h[i].hw >> 4) & 3, h[i].tp - h[i].t0);
     }
