@@ -18,7 +18,7 @@ the all-reduce of the loss numerator/denominator pair over RCCL (SURVEY.md secti
 forward and backward, so the N-GPU number contains the exchange north_star names.  The N = 1 line
 carries the same with-loss step as `config.Mpix_per_s_with_render_loss` for a like-for-like ratio.
 
-Timing: `--reps` (default 9) repetitions of the K-step loop, each bracketed by barrier + device
+Timing: `--reps` (default 15) repetitions of the K-step loop, each bracketed by barrier + device
 synchronise on both sides and maximised over ranks; the line reports the MEDIAN repetition
 (`ms_per_step`) and lists all of them (`config.ms_per_step_repetitions`).
 
@@ -67,7 +67,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=300, help="untimed steps first (0.15 s at config 2: the GPU's clocks ramp up over the first ~100 ms of load)")
     ap.add_argument("--batch", type=int, default=16, help="images per GPU")
-    ap.add_argument("--reps", type=int, default=9, help="repetitions of the K-step timed loop; the median is reported (nine: with a short --warmup the first two or three repetitions still run on ramping clocks)")
+    ap.add_argument("--reps", type=int, default=15, help="repetitions of the K-step timed loop; the median is reported (fifteen: with a short --warmup the first three repetitions still run on ramping clocks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layer-only", action="store_true", help="skip the informational legs (two streams, HIP graph, light objective, baselines): profiling runs")
     ap.add_argument("--no-env", action="store_true", help="render-only variant (env image never materialised)")
