@@ -190,3 +190,70 @@ def test_c_tables_match_numpy():
         got = np.empty_like(want)
         assert lib.sgr_fill_view_vectors(got.ctypes.data, R, C, ctypes.c_float(fov), None) == 0
         assert np.abs(got - want).max() <= 1.2e-7
+
+
+# --------------------------------------------------------------------------- #
+# decoder heads as the kernels' prologue (premap = 3): the formulas of heads_two_lobes / heads_bwd_lobe (csrc/sgr_pk.inl)
+# --------------------------------------------------------------------------- #
+def _tanh_abs32(x):
+    """1 - 2 / (e^{2x} + 1) in fp32 (v_exp_f32 + v_rcp_f32 on the device): the prologue's tanh."""
+    f = np.float32
+    with np.errstate(over="ignore"):
+        e = np.exp2(x.astype(f) * f(2.8853900817779268)).astype(f)
+        r = (f(1.0) / (e + f(1.0))).astype(f)
+    return (f(1.0) - f(2.0) * r).astype(f)
+
+
+def test_heads_prologue_formulas_against_the_oracle():
+    """The prologue's restatement of models.py:336-346 -- tanh as 1 - 2/(e^{2x}+1), a / max(|a|, 1e-6) as a * min(rsqrt(|a|^2), 1e6),
+    the [0, 1] clamp behind torch's op-by-op rounding -- and its chain rule, in fp32 numpy against the fp64 oracle and its autograd:
+    absolute error a few 1e-7 forward (what the tan pre-map then sees is within an ulp or two of the standalone pass), gradients to
+    1e-5 of their norm."""
+    from oracle import sg_oracle as O
+    f = np.float32
+    rng = np.random.default_rng(5)
+    bn, K, R, C = 2, 6, 5, 7
+    xa = (1.5 * rng.standard_normal((bn, 3 * K, R, C))).astype(f)
+    xl = (1.5 * rng.standard_normal((bn, K, R, C))).astype(f)
+    xw = (1.5 * rng.standard_normal((bn, 3 * K, R, C))).astype(f)
+    for x in (xa, xl, xw):                                   # saturated entries either side, and huge ones (e^{2x} = inf / 0)
+        flat = x.reshape(-1)
+        flat[::17] = 7.0
+        flat[5::19] = -7.0
+        flat[3::101] = 60.0
+        flat[7::103] = -60.0
+    t64 = [torch.from_numpy(v).double().requires_grad_(True) for v in (xa, xl, xw)]
+    a64, l64, w64, _ = O.light_heads(*t64)
+
+    # forward
+    ta = _tanh_abs32(xa).reshape(bn, K, 3, R, C)
+    a = (f(1.01) * ta).astype(f)
+    n2 = (a * a).sum(axis=2, keepdims=True, dtype=f)
+    with np.errstate(divide="ignore"):
+        inv = np.minimum((f(1.0) / np.sqrt(n2, dtype=f)).astype(f), f(1e6))
+    y = (a * inv).astype(f)
+    unit = lambda t: np.clip((f(0.5) * ((f(1.01) * t).astype(f) + f(1.0)).astype(f)).astype(f), f(0.0), f(1.0))
+    lam, w = unit(_tanh_abs32(xl)), unit(_tanh_abs32(xw))
+    assert np.abs(y - a64.detach().numpy()).max() < 5e-7
+    assert np.abs(lam - l64.detach().numpy()).max() < 3e-7 and np.abs(w - w64.detach().numpy()).max() < 3e-7
+    assert np.isfinite(y).all() and np.isfinite(lam).all() and np.isfinite(w).all()
+
+    # chain rule (heads_bwd_lobe) against autograd through the oracle
+    ga = rng.standard_normal(a64.shape).astype(f)
+    gl = rng.standard_normal(l64.shape).astype(f)
+    gw = rng.standard_normal(w64.shape).astype(f)
+    tot = (a64 * torch.from_numpy(ga).double()).sum() + (l64 * torch.from_numpy(gl).double()).sum() + (w64 * torch.from_numpy(gw).double()).sum()
+    r64 = torch.autograd.grad(tot, t64)
+    s_a = (f(1.0) - ta * ta).astype(f)
+    live = n2 >= f(1e-12)
+    invb = np.where(live, (f(1.0) / np.sqrt(np.maximum(n2, f(1e-30)), dtype=f)).astype(f), f(1e6))
+    dot = np.where(live, (a * ga).sum(axis=2, keepdims=True, dtype=f) * invb * invb, f(0.0))
+    gxa = ((ga - a * dot) * invb * (f(1.01) * s_a)).astype(f).reshape(bn, 3 * K, R, C)
+
+    def unit_bwd(x, g):
+        t = _tanh_abs32(x)
+        pre = (f(0.5) * ((f(1.01) * t).astype(f) + f(1.0)).astype(f)).astype(f)
+        return np.where((pre >= 0) & (pre <= 1), g * (f(0.505) * (f(1.0) - t * t)), f(0.0)).astype(f)
+    gxl, gxw = unit_bwd(xl, gl), unit_bwd(xw, gw)
+    for name, mine, ref in (("x_axis", gxa, r64[0]), ("x_lamb", gxl, r64[1]), ("x_weight", gxw, r64[2])):
+        assert rel_l2(mine, ref.numpy()) < 1e-5, (name, rel_l2(mine, ref.numpy()))
