@@ -14,7 +14,10 @@
 namespace sgr {
 
 constexpr int kLossThreads = 256;
-constexpr int kSplit = 16;           // blocks per image
+constexpr int kSplit = 16;           // blocks per image (passes over data the previous pass left in cache)
+constexpr int kSplitA = 64;          // blocks per image of the FIRST pass (stage A / diffspec_partial_a): it reads the full-resolution
+                                     // image and mask cold from HBM, and a quarter of the blocks left it latency-bound (16.7 us in the
+                                     // training loop for 32 MB); = lanes of a wave, see fold_a
 #ifndef SGR_LOSS_FENCE
 #define SGR_LOSS_FENCE 0               // 1: __threadfence() around the ticket of loss_stage_c instead of the write-through store + s_waitcnt
 #endif
@@ -39,9 +42,9 @@ __device__ __forceinline__ void block_reduce(float (&v)[N], float* lds /* [4*N] 
   __syncthreads();
 }
 
-// fold the kSplit partials of image b (N values each) in double, fixed order.  (Measured in round 3: 64 blocks per image with
-// a wave-butterfly fold are 2 us SLOWER over the three passes than 16 with this serial one -- the passes are not short of
-// parallelism; what they cost is 13 us of data movement plus three dependent launches at 5-6 us each.)
+// fold the kSplit partials of image b (N values each) in double, fixed order.  (Measured in round 3 on WARM buffers: 64 blocks per
+// image for all three passes are 2 us slower than 16 -- the second and third pass read what the first left in cache and are not
+// short of parallelism; the first pass is another matter in a training loop, see kSplitA.)
 template <int N>
 __device__ __forceinline__ void fold(const float* __restrict__ ws, int b, double (&out)[N]) {
 #pragma unroll
@@ -49,6 +52,20 @@ __device__ __forceinline__ void fold(const float* __restrict__ ws, int b, double
   for (int s = 0; s < kSplit; ++s) {
 #pragma unroll
     for (int i = 0; i < N; ++i) out[i] += (double)ws[((size_t)b * kSplit + s) * N + i];
+  }
+}
+
+// the kSplitA stage-A partials of image b: lane l of every wave takes partial l, then an xor butterfly in double -- a fixed tree
+// whose additions commute pairwise, so all lanes of all waves end with the same bits
+__device__ __forceinline__ void fold_a(const float* __restrict__ wsA, int b, double (&out)[6]) {
+  static_assert(kSplitA == 64, "one partial per lane");
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) out[i] = (double)wsA[((size_t)b * kSplitA + lane) * 6 + i];
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) out[i] += __shfl_xor(out[i], off, 64);
   }
 }
 
@@ -87,7 +104,7 @@ __global__ __launch_bounds__(kLossThreads) void loss_stage_a(const float* __rest
   if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) ticket[0] = 0u;      // stage C's arrival counter (two kernel boundaries ahead of its use)
   float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const size_t plane = (size_t)imH * imW;
-  for (int i = blockIdx.x * kLossThreads + threadIdx.x; i < n; i += kSplit * kLossThreads) {
+  for (int i = blockIdx.x * kLossThreads + threadIdx.x; i < n; i += kSplitA * kLossThreads) {
     const int ch = i / RC, p = i - ch * RC, r = p / C, c = p - r * C;
     const float v = pool_at<POOL>(im + ((size_t)b * 3 + ch) * plane, r, c, imW);
     im_s[(size_t)b * n + i] = v;
@@ -104,7 +121,7 @@ __global__ __launch_bounds__(kLossThreads) void loss_stage_a(const float* __rest
   block_reduce<6>(acc, lds);
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) wsA[((size_t)b * kSplit + blockIdx.x) * 6 + k] = acc[k];
+    for (int k = 0; k < 6; ++k) wsA[((size_t)b * kSplitA + blockIdx.x) * 6 + k] = acc[k];
   }
 }
 
@@ -115,7 +132,7 @@ __global__ __launch_bounds__(kLossThreads) void loss_stage_b(const float* __rest
   __shared__ float lds[4 * 2];
   const int b = blockIdx.y;
   double sA[6];
-  fold<6>(wsA, b, sA);
+  fold_a(wsA, b, sA);
   const double s5[5] = {sA[0], sA[1], sA[2], sA[3], sA[4]};
   float cd, cs;
   diffspec_coefs(s5, (float)n, cd, cs);
@@ -154,7 +171,7 @@ __global__ __launch_bounds__(kLossThreads) void loss_stage_c(const float* __rest
   __shared__ unsigned last;
   const int b = blockIdx.y, n = 3 * RC;
   double sA[6], sB[2];
-  fold<6>(wsA, b, sA);
+  fold_a(wsA, b, sA);
   fold<2>(wsB, b, sB);
   const double s5[5] = {sA[0], sA[1], sA[2], sA[3], sA[4]};
   float cd, cs;
@@ -194,10 +211,8 @@ __global__ __launch_bounds__(kLossThreads) void loss_stage_c(const float* __rest
   __threadfence();
 #endif
   double num = 0.0, den = 0.0;
-  for (int i = threadIdx.x; i < nparts; i += kLossThreads) {
-    num += (double)__hip_atomic_load(&wsC[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    den += (double)wsA[(size_t)i * 6 + 5];                 // stage A's: a kernel boundary away
-  }
+  for (int i = threadIdx.x; i < nparts; i += kLossThreads) num += (double)__hip_atomic_load(&wsC[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int i = threadIdx.x; i < (int)gridDim.y * kSplitA; i += kLossThreads) den += (double)wsA[(size_t)i * 6 + 5];      // stage A's: a kernel boundary away
   fold_lds[threadIdx.x * 2] = num;
   fold_lds[threadIdx.x * 2 + 1] = den;
   __syncthreads();
@@ -291,7 +306,7 @@ __global__ __launch_bounds__(kLossThreads) void diffspec_partial_a(const float* 
   __shared__ float lds[4 * 6];
   const int b = blockIdx.y;
   float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int i = blockIdx.x * kLossThreads + threadIdx.x; i < n; i += kSplit * kLossThreads) {
+  for (int i = blockIdx.x * kLossThreads + threadIdx.x; i < n; i += kSplitA * kLossThreads) {
     const size_t o = (size_t)b * n + i;
     const float v = im[o];
     const float m = v < 0.9f ? 1.0f : 0.0f;
@@ -302,28 +317,29 @@ __global__ __launch_bounds__(kLossThreads) void diffspec_partial_a(const float* 
   block_reduce<6>(acc, lds);
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) wsA[((size_t)b * kSplit + blockIdx.x) * 6 + k] = acc[k];
+    for (int k = 0; k < 6; ++k) wsA[((size_t)b * kSplitA + blockIdx.x) * 6 + k] = acc[k];
   }
 }
-__global__ void diffspec_finish(const float* __restrict__ wsA, const float* __restrict__ wsB, float* __restrict__ coef, int bn, int n) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= bn) return;
+__global__ __launch_bounds__(64) void diffspec_finish(const float* __restrict__ wsA, const float* __restrict__ wsB, float* __restrict__ coef, int n) {
+  const int b = blockIdx.x;      // one wave per image (fold_a is lane-cooperative)
   double sA[6], sB[2];
-  fold<6>(wsA, b, sA);
+  fold_a(wsA, b, sA);
   fold<2>(wsB, b, sB);
   const double s5[5] = {sA[0], sA[1], sA[2], sA[3], sA[4]};
   float cd, cs;
   diffspec_coefs(s5, (float)n, cd, cs);
   const float cim = unit_coef(sB[0], sB[1]);
-  coef[2 * b] = cim * cd;
-  coef[2 * b + 1] = cim * cs;
+  if (threadIdx.x == 0) {
+    coef[2 * b] = cim * cd;
+    coef[2 * b + 1] = cim * cs;
+  }
 }
 
 }  // namespace sgr
 
 using namespace sgr;
 
-extern "C" int sgr_loss_workspace_floats(int bn) { return bn * kSplit * (6 + 2 + 1) + 1; }      // + the arrival counter
+extern "C" int sgr_loss_workspace_floats(int bn) { return bn * (kSplitA * 6 + kSplit * (2 + 1)) + 1; }      // + the arrival counter
 
 extern "C" int sgr_render_loss_fwd_total(const float* diffuse, const float* spec, const float* im, const float* seg,
                                          float* im_small, float* seg_small, float* rendered, float* coef, float* parts,
@@ -337,15 +353,15 @@ extern "C" int sgr_render_loss_fwd_total(const float* diffuse, const float* spec
   SGR_SUPPORTED(ok, "sgr_render_loss_fwd: image / env-grid ratio must be 1 or 2 (pool first)");
   const hipStream_t st = (hipStream_t)stream;
   float* wsA = workspace;
-  float* wsB = wsA + (size_t)bn * kSplit * 6;
+  float* wsB = wsA + (size_t)bn * kSplitA * 6;
   float* wsC = wsB + (size_t)bn * kSplit * 2;
   unsigned* ticket = reinterpret_cast<unsigned*>(wsC + (size_t)bn * kSplit);
   const dim3 grid(kSplit, bn), block(kLossThreads);
   const int RC = R * C;
   if (imH == R)
-    hipLaunchKernelGGL((loss_stage_a<1>), grid, block, 0, st, diffuse, spec, im, seg, im_small, seg_small, wsA, ticket, R, C, imH, imW);
+    hipLaunchKernelGGL((loss_stage_a<1>), dim3(kSplitA, bn), block, 0, st, diffuse, spec, im, seg, im_small, seg_small, wsA, ticket, R, C, imH, imW);
   else
-    hipLaunchKernelGGL((loss_stage_a<2>), grid, block, 0, st, diffuse, spec, im, seg, im_small, seg_small, wsA, ticket, R, C, imH, imW);
+    hipLaunchKernelGGL((loss_stage_a<2>), dim3(kSplitA, bn), block, 0, st, diffuse, spec, im, seg, im_small, seg_small, wsA, ticket, R, C, imH, imW);
   hipLaunchKernelGGL(loss_stage_b, grid, block, 0, st, diffuse, spec, im_small, wsA, wsB, 3 * RC);
   hipLaunchKernelGGL(loss_stage_c, grid, block, 0, st, diffuse, spec, im_small, seg_small, wsA, wsB, coef, rendered, wsC, RC, ticket, parts,
                      loss, scale, divisor);
@@ -406,10 +422,10 @@ extern "C" int sgr_lsregress_diffspec_coef(const float* diffuse, const float* sp
   SGR_REQUIRE(bn > 0 && n > 0, "sgr_lsregress_diffspec_coef: non-positive size");
   const hipStream_t st = (hipStream_t)stream;
   float* wsA = workspace;
-  float* wsB = wsA + (size_t)bn * kSplit * 6;
+  float* wsB = wsA + (size_t)bn * kSplitA * 6;
   const dim3 grid(kSplit, bn), block(kLossThreads);
-  hipLaunchKernelGGL(diffspec_partial_a, grid, block, 0, st, diffuse, spec, im, wsA, n);
+  hipLaunchKernelGGL(diffspec_partial_a, dim3(kSplitA, bn), block, 0, st, diffuse, spec, im, wsA, n);
   hipLaunchKernelGGL(loss_stage_b, grid, block, 0, st, diffuse, spec, im, wsA, wsB, n);
-  hipLaunchKernelGGL(diffspec_finish, dim3((bn + 63) / 64), dim3(64), 0, st, wsA, wsB, coef, bn, n);
+  hipLaunchKernelGGL(diffspec_finish, dim3(bn), dim3(64), 0, st, wsA, wsB, coef, n);
   return sgr_check((int)hipGetLastError(), "sgr_lsregress_diffspec_coef");
 }
