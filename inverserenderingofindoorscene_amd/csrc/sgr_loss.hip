@@ -14,7 +14,7 @@
 namespace sgr {
 
 constexpr int kLossThreads = 256;
-constexpr int kSplit = 16;           // blocks per image (passes over data the previous pass left in cache)
+constexpr int kSplit = 16;           // blocks per image (passes over data the previous pass left in cache; 32: no change in the loop)
 constexpr int kSplitA = 64;          // blocks per image of the FIRST pass (stage A / diffspec_partial_a): it reads the full-resolution
                                      // image and mask cold from HBM, and a quarter of the blocks left it latency-bound (16.7 us in the
                                      // training loop for 32 MB); = lanes of a wave, see fold_a

@@ -49,8 +49,18 @@ struct ObjectiveTail { const float* render_err; float ren_w, rec_w, divisor_e; f
 static __global__ __launch_bounds__(kRThreads) void recon_fold1(const float* __restrict__ ws, const float* __restrict__ den_img,
                                                           float* __restrict__ parts, int bn, int nblk, ObjectiveTail tail) {
   __shared__ double lds[kRThreads * 2];
-  double v[2] = {0.0, 0.0};
-  for (int i = threadIdx.x; i < bn * nblk; i += kRThreads) v[0] += (double)ws[i];
+  // four independent partial sums per thread (loads of one round in flight together: a single dependent chain over 9 600 partials
+  // was 13.8 us of pure latency in the training loop), combined in a fixed order
+  double v[2] = {0.0, 0.0}, w1 = 0.0, w2 = 0.0, w3 = 0.0;
+  const int n = bn * nblk;
+  for (int i = threadIdx.x; i < n; i += 4 * kRThreads) {
+    const float a0 = ws[i];
+    const float a1 = i + kRThreads < n ? ws[i + kRThreads] : 0.0f;
+    const float a2 = i + 2 * kRThreads < n ? ws[i + 2 * kRThreads] : 0.0f;
+    const float a3 = i + 3 * kRThreads < n ? ws[i + 3 * kRThreads] : 0.0f;
+    v[0] += (double)a0; w1 += (double)a1; w2 += (double)a2; w3 += (double)a3;
+  }
+  v[0] = (v[0] + w1) + (w2 + w3);
   for (int i = threadIdx.x; i < bn; i += kRThreads) v[1] += (double)den_img[i];
   block_sum_double<2>(v, lds);
   if (threadIdx.x == 0) {
