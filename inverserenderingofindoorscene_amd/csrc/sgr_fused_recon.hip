@@ -667,7 +667,8 @@ static int fused_fwd_recon_impl(const float* albedo, const float* normal, const 
   set_dims(a, bn, K, R, C, eh, ew, imH, imW);
   a.F0 = F0; a.premap = premap == 1 ? 1 : (premap == 3 ? 3 : 0);
   SGR_REQUIRE(premap >= 0 && premap <= 3, "sgr_fused_fwd_recon: premap must be 0..3");
-  SGR_SUPPORTED(premap != 3 || (K > 6 && getenv("SGR_F1_MODE") == nullptr), "sgr_fused_fwd_recon: premap 3 (decoder heads as a prologue) needs 6 < SGNum <= 24 and the default kernels");
+  static const bool f1_default = getenv("SGR_F1_MODE") == nullptr;
+  SGR_SUPPORTED(premap != 3 || (K > 6 && f1_default), "sgr_fused_fwd_recon: premap 3 (decoder heads as a prologue) needs 6 < SGNum <= 24 and the default kernels");
   // SGR_F1_MODE=half: half-wave statistics kernel (32-pixel work units); scalar: round 1's one pixel per lane; default: packed fp32
   static const int f1_mode = [] { const char* e = getenv("SGR_F1_MODE"); return !e ? 0 : (!strcmp(e, "half") ? 1 : (!strcmp(e, "scalar") ? 2 : 0)); }();
   // SGR_F1_MODE=pkhalf: the packed half-wave statistics kernel also for 7..12 lobes on the 8x16 grid (3 waves per SIMD)
@@ -770,7 +771,8 @@ static int fused_bwd_recon_impl(const float* albedo, const float* normal, const 
               "sgr_fused_bwd_recon: NULL tensor");
   SGR_REQUIRE(bn > 0 && K > 0 && R > 0 && C > 0 && eh > 0 && ew > 0, "sgr_fused_bwd_recon: non-positive size");
   SGR_REQUIRE(premap >= 0 && premap <= 3, "sgr_fused_bwd_recon: premap must be 0..3");
-  SGR_SUPPORTED(premap != 3 || (K > 6 && getenv("SGR_B1_MODE") == nullptr), "sgr_fused_bwd_recon: premap 3 (decoder heads as a prologue) needs 6 < SGNum <= 24 and the default kernels");
+  static const bool b1_default = getenv("SGR_B1_MODE") == nullptr;
+  SGR_SUPPORTED(premap != 3 || (K > 6 && b1_default), "sgr_fused_bwd_recon: premap 3 (decoder heads as a prologue) needs 6 < SGNum <= 24 and the default kernels");
   SGR_SUPPORTED(fused_recon_ok(K, R, C, eh, ew), "sgr_fused_bwd_recon: needs envWidth 16 or 32 and SGNum <= 24 (use the unfused calls)");
   if (int rc = check_pool(R, C, imH, imW, "sgr_fused_bwd_recon: BRDF-map / env-grid ratio must be 1 or 2 (pool first)")) return rc;
   Args a{};
