@@ -6,6 +6,7 @@ Two routes through the product, same fixtures:
   (A) drop-in:  light_heads -> output2env.output2env -> LSregress -> log-L2 (torch glue, as in the reference) ->
                 renderingLayer.forwardEnv -> LSregressDiffSpec -> clamp -> masked L2 (torch glue)
   (B) fused:    light_heads -> light_objective (env image never written)
+  (C) fused, decoder heads as the kernels' prologue:  light_objective(decoder_outputs=True) on the networks' last-convolution outputs
 Tolerances: BASELINE.md section 3 -- rel-L2 <= 1e-4 against the reference's fp32 values, and error against the fp64
 oracle evaluated on the same fp32 inputs no worse than 2 x the reference's own (floor 1e-5 where the reference is exact).
 """
@@ -136,19 +137,26 @@ def test_wrapper_sequence_dropin(sgr, name):
     assert np.allclose(norms, z["ref32_gx_norms"], rtol=2e-4), (norms, z["ref32_gx_norms"])
 
 
+@pytest.mark.parametrize("prologue", [False, True], ids=["heads_pass", "heads_prologue"])
 @pytest.mark.parametrize("name", CASES)
-def test_wrapper_sequence_fused_objective(sgr, name):
-    """Route (B): the same step through sgr.light_heads -> sgr.light_objective (two heavy kernels, no env image)."""
+def test_wrapper_sequence_fused_objective(sgr, name, prologue):
+    """Routes (B) and (C): the same step through sgr.light_heads -> sgr.light_objective (two heavy kernels, no env image), and
+    with the decoder heads inside those kernels (``decoder_outputs=True``: the activated SG parameters never exist)."""
     z, cfg, t = _load(name)
     R, C, K, eh, ew, s = cfg["R"], cfg["C"], cfg["K"], cfg["eh"], cfg["ew"], cfg["s"]
     ref64 = _oracle64(t, cfg)
     g = {k: v.cuda() for k, v in t.items()}
     xa, xl, xw = (g[k].clone().requires_grad_(True) for k in ("x_axis", "x_lamb", "x_weight"))
     renderLayer = sgr.renderingLayer(imWidth=C, imHeight=R, envWidth=ew, envHeight=eh)
-    axisPred, lambPred, weightPred, _ = sgr.light_heads(xa, xl, xw)
-    obj, renderErr, reconstErr, renderedImPred, envScale = sgr.light_objective(
-        renderLayer, g["albedoPred"], g["normalPred"], g["roughPred"], axisPred, lambPred, weightPred, g["im"], g["segBRDF"],
-        g["envmaps"], g["envmapsInd"], REN_W, REC_W, OFFSET)
+    if prologue:
+        obj, renderErr, reconstErr, renderedImPred, envScale = sgr.light_objective(
+            renderLayer, g["albedoPred"], g["normalPred"], g["roughPred"], xa, xl, xw, g["im"], g["segBRDF"],
+            g["envmaps"], g["envmapsInd"], REN_W, REC_W, OFFSET, decoder_outputs=True)
+    else:
+        axisPred, lambPred, weightPred, _ = sgr.light_heads(xa, xl, xw)
+        obj, renderErr, reconstErr, renderedImPred, envScale = sgr.light_objective(
+            renderLayer, g["albedoPred"], g["normalPred"], g["roughPred"], axisPred, lambPred, weightPred, g["im"], g["segBRDF"],
+            g["envmaps"], g["envmapsInd"], REN_W, REC_W, OFFSET)
     obj.backward()
     assert _scalar_ok(reconstErr.item(), float(z["ref32_reconstErr"]), ref64["reconstErr"]), (name, reconstErr.item(), float(z["ref32_reconstErr"]))
     assert _scalar_ok(renderErr.item(), float(z["ref32_renderErr"]), ref64["renderErr"]), (name, renderErr.item(), float(z["ref32_renderErr"]))
