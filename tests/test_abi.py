@@ -62,3 +62,27 @@ def test_layer_attributes_mirror_reference():
     assert tuple(rl.envWeight.shape) == (1, 128, 1, 1, 1) and abs(rl.fov - 57 / 180 * np.pi) < 1e-12
     o2e = pkg.output2env(12)
     assert tuple(o2e.ls.shape) == (1, 1, 3, 1, 1, 8, 16) and o2e.SGNum == 12
+
+
+def test_premap_modes_and_configuration_queries_without_gpu():
+    """premap = 3 (decoder heads as the kernels' prologue) is offered where a packed kernel implements it and refused -- before
+    any launch -- elsewhere; the workspace / support queries are pure host functions."""
+    lib = _lib.load()
+    assert lib.sgr_heads_prologue_supported(12, 120, 160, 8, 16) == 1 and lib.sgr_heads_prologue_supported(24, 240, 320, 16, 32) == 1
+    assert lib.sgr_heads_prologue_supported(6, 120, 160, 8, 16) == 0        # SGNum <= 6: no prologue (standalone heads pass)
+    assert lib.sgr_heads_prologue_supported(25, 120, 160, 8, 16) == 0
+    assert lib.sgr_heads_prologue_supported(12, 120, 160, 4, 8) == 0        # a direction grid without packed kernels
+    assert lib.sgr_fused_recon_supported(24, 240, 320, 16, 32) == 1 and lib.sgr_fused_recon_supported(12, 120, 160, 4, 8) == 0
+    assert lib.sgr_loss_workspace_floats(16) > 16 * 16 * 9 and lib.sgr_fused_recon_workspace_floats(16, 120, 160) > 0
+    fake = ctypes.c_void_p(4096)
+    f0 = ctypes.c_float(0.05)
+    # out of range, and in range but not implemented for this shape: both rejected with a message, nothing launched
+    rc = lib.sgr_fused_fwd(fake, fake, fake, fake, fake, fake, fake, fake, None, fake, fake, 1, 12, 4, 4, 8, 16, 4, 4, f0, 4, None)
+    assert rc == -1 and b"premap" in lib.sgr_last_error()
+    rc = lib.sgr_fused_fwd(fake, fake, fake, fake, fake, fake, fake, fake, None, fake, fake, 1, 5, 4, 4, 8, 16, 4, 4, f0, 3, None)
+    assert rc == -2 and b"premap 3" in lib.sgr_last_error()
+    rc = lib.sgr_fused_bwd_sg(None, fake, fake, fake, fake, fake, fake, fake, fake, fake, fake, fake, fake, fake, 1, 5, 4, 4, 8, 16, 4, 4,
+                              f0, 3, None)
+    assert rc == -2 and b"premap 3" in lib.sgr_last_error()
+    rc = lib.sgr_sg_to_env_fwd(fake, fake, fake, fake, fake, None, None, 1, 12, 4, 4, 8, 16, 3, None)
+    assert rc == -1 and b"premap" in lib.sgr_last_error()
