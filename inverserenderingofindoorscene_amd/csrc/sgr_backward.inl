@@ -204,43 +204,6 @@ static int sgbwd_launch_k(const Args& a, hipStream_t st) {
   return sgbwd_launch_vec<12, POOL, HAS_GENV, HAS_RENDER>(a, st);
 }
 
-template <int EW, bool HAS_GENV, bool HAS_RENDER>
-static int sgbwd_fast_launch_pool(const Args& a, hipStream_t st) {
-  // one workgroup per (pixel group, register group of lobes), ids interleaved in chunks of 8 (see sg_bwd_fast_kernel)
-  const int kp = a.K <= 6 ? 6 : 12, ng = (a.K + kp - 1) / kp;
-  const unsigned tiles = wave_grid(a.bn, a.R, a.C).x;
-  const dim3 grid(((tiles + 7) / 8) * 8 * (unsigned)ng), block(kWave);
-  const bool p1 = (!HAS_RENDER || (a.imH == a.R && a.imW == a.C));
-  if (a.K <= 6) {   // fewer lobes in registers -> higher occupancy
-    if (p1) hipLaunchKernelGGL((sg_bwd_fast_kernel<6, 1, EW, HAS_GENV, HAS_RENDER>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((sg_bwd_fast_kernel<6, 2, EW, HAS_GENV, HAS_RENDER>), grid, block, 0, st, a);
-  } else {
-    if (p1) hipLaunchKernelGGL((sg_bwd_fast_kernel<12, 1, EW, HAS_GENV, HAS_RENDER>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((sg_bwd_fast_kernel<12, 2, EW, HAS_GENV, HAS_RENDER>), grid, block, 0, st, a);
-  }
-  return (int)hipGetLastError();
-}
-
-// lobes split over two waves (envWidth 16, more than 6 lobes)
-template <bool HAS_GENV, bool HAS_RENDER>
-static int sgbwd_split_launch(const Args& a, hipStream_t st) {
-  const dim3 grid = wave_grid(a.bn, a.R, a.C), block(2 * kWave);
-  if (!HAS_RENDER || (a.imH == a.R && a.imW == a.C))
-    hipLaunchKernelGGL((sg_bwd_split_kernel<6, 1, HAS_GENV, HAS_RENDER>), grid, block, 0, st, a);
-  else
-    hipLaunchKernelGGL((sg_bwd_split_kernel<6, 2, HAS_GENV, HAS_RENDER>), grid, block, 0, st, a);
-  return (int)hipGetLastError();
-}
-// lobes split over the two halves of a wave (envWidth 16, more than 6 lobes); SGR_BWD_MODE = half2 | half3 | split
-template <bool HAS_GENV, bool HAS_RENDER, int OCC>
-static int sgbwd_half_launch(const Args& a, hipStream_t st) {
-  const dim3 grid((unsigned)(a.bn * ((a.R * a.C + kPx - 1) / kPx))), block(kWave);
-  if (!HAS_RENDER || (a.imH == a.R && a.imW == a.C))
-    hipLaunchKernelGGL((sg_bwd_half_kernel<1, HAS_GENV, HAS_RENDER, OCC>), grid, block, 0, st, a);
-  else
-    hipLaunchKernelGGL((sg_bwd_half_kernel<2, HAS_GENV, HAS_RENDER, OCC>), grid, block, 0, st, a);
-  return (int)hipGetLastError();
-}
 // packed-fp32 half-wave backward (envWidth 16 or 32; one workgroup per 32 pixels and group of 12 lobes), sgr_pk.inl
 template <bool HAS_GENV, bool HAS_RENDER, int EW, bool HEADS = false>
 static int sgbwd_pk_launch_ew(const Args& a, hipStream_t st) {
@@ -261,40 +224,18 @@ static int sgbwd_pk_launch(const Args& a, hipStream_t st) {
   }
   return a.ew == 16 ? sgbwd_pk_launch_ew<HAS_GENV, HAS_RENDER, 16>(a, st) : sgbwd_pk_launch_ew<HAS_GENV, HAS_RENDER, 32>(a, st);
 }
-static inline int bwd_mode() {     // 4 packed half-wave (default), 0 split (two waves), 2 / 3 scalar half-wave kernel built for that many waves per SIMD
-  static const int mode = [] {       // round 1, config 2 (g_env + gD,gS): split 350 us, half2 328 us, half3 320 us
-    const char* e = getenv("SGR_BWD_MODE");
-    if (!e || !strcmp(e, "pk")) return 4;
-    if (e && !strcmp(e, "half2")) return 2;
-    if (e && !strcmp(e, "split")) return 0;
-    return 3;
-  }();
-  return mode;
-}
-static inline bool bwd_split_enabled() {
-  static const bool on = [] { const char* e = getenv("SGR_BWD_SPLIT"); return !(e && atoi(e) == 0); }();
-  return on;
-}
-
 template <bool HAS_GENV, bool HAS_RENDER>
 static int sgbwd_launch(const Args& a, hipStream_t st) {
-  // packed: SGNum 7..12 on the 8x16 grid (the headline), and everything above 6 lobes on 16-wide and 32-wide grids
-  // (config 5: 24 lobes, 16x32: 2.50 ms with the scalar kernel)
-  if (fast_ok(a) && a.K > 6 && bwd_mode() == 4 && !sgr_generic_forced())
-    return sgbwd_pk_launch<HAS_GENV, HAS_RENDER>(a, st);
-  if (fast_ok(a) && a.ew == 16 && a.K > 6 && a.K <= 12 && bwd_mode() != 0 && !sgr_generic_forced())
-    return bwd_mode() == 3 ? sgbwd_half_launch<HAS_GENV, HAS_RENDER, 3>(a, st) : sgbwd_half_launch<HAS_GENV, HAS_RENDER, 2>(a, st);
-  if (fast_ok(a) && a.ew == 16 && a.K > 6 && HAS_GENV && bwd_split_enabled() && !sgr_generic_forced())   // measured: only pays with the LDS tile
-    return sgbwd_split_launch<HAS_GENV, HAS_RENDER>(a, st);
-  if (fast_ok(a) && !sgr_generic_forced())
-    return a.ew == 16 ? sgbwd_fast_launch_pool<16, HAS_GENV, HAS_RENDER>(a, st) : sgbwd_fast_launch_pool<32, HAS_GENV, HAS_RENDER>(a, st);
+  // the reference's direction grids (16- and 32-wide): the packed half-wave kernel for every SGNum -- six lobes per half-wave,
+  // one workgroup per 32 pixels and group of 12 lobes (SGNum <= 6 leaves the upper half's lobe slots empty)
+  if (fast_ok(a) && !sgr_generic_forced()) return sgbwd_pk_launch<HAS_GENV, HAS_RENDER>(a, st);
   if (!HAS_RENDER || (a.imH == a.R && a.imW == a.C)) return sgbwd_launch_k<1, HAS_GENV, HAS_RENDER>(a, st);
   return sgbwd_launch_k<2, HAS_GENV, HAS_RENDER>(a, st);
 }
 
 // premap == 3: see fwd_heads_ok (sgr_forward.inl)
 static inline bool bwd_heads_ok(const Args& a) {
-  return fast_ok(a) && !sgr_generic_forced() && bwd_mode() == 4 && a.K > 6 && a.K <= 24;
+  return fast_ok(a) && !sgr_generic_forced() && a.K > 6 && a.K <= 24;
 }
 
 static inline int check_pool_b(int R, int C, int imH, int imW, const char* who) {

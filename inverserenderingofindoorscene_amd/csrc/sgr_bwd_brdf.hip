@@ -111,84 +111,13 @@ __global__ __launch_bounds__(kWave, 1) void brdf_bwd_kernel(const Args a) {
   }
 }
 
-// env given, envWidth 16: the env rows arrive by double-buffered LDS-DMA (as in render_fast_kernel) instead of being
-// staged through registers behind two workgroup barriers per tile; the arithmetic is the generic kernel's.
-template <int POOL>
-__global__ __launch_bounds__(kWave, 2) void brdf_bwd_dma_kernel(const Args a) {
-  constexpr int EW = 16, HALF = 8;
-  using D = DmaTile<EW>;
-  __shared__ __attribute__((aligned(16))) float tile[2 * D::kFloats];
-
-  const Pix x = locate(a);
-  const int lane = x.lane, b = x.b, p = x.p;
-  const int RC = a.R * a.C;
-  float pooled[7];
-  const Frame f = load_frame_pooled<POOL>(a, x, pooled);
-  const size_t o = (size_t)b * 3 * RC + p;
-  const float gD0 = a.g_diffuse[o], gD1 = a.g_diffuse[o + RC], gD2 = a.g_diffuse[o + 2 * (size_t)RC];
-  const float gs0 = a.g_spec[o], gs1 = a.g_spec[o + RC], gs2 = a.g_spec[o + 2 * (size_t)RC];
-  const float gd0 = gD0 * (pooled[0] * kInvPi), gd1 = gD1 * (pooled[1] * kInvPi), gd2 = gD2 * (pooled[2] * kInvPi);
-
-  FrameGrad g;
-  frame_grad_zero(g);
-  float ds0 = 0.f, ds1 = 0.f, ds2 = 0.f;
-  const DirTable dirs = as_dir_table(a.dirs);
-  __amdgpu_buffer_rsrc_t eimg = env_rsrc(a.env_in + (size_t)b * 3 * RC * a.J, RC, a.J);
-  const int eh = a.J / EW;
-
-  tile_dma_issue<EW>(tile, eimg, x.p0, RC, a.J, 0, lane);
-  for (int e = 0; e < eh; ++e) {
-    const float* cur = tile + (e & 1) * D::kFloats;
-    if (e + 1 < eh) {
-      tile_dma_issue<EW>(tile + ((e + 1) & 1) * D::kFloats, eimg, x.p0, RC, a.J, (e + 1) * EW, lane);
-      wait_vmcnt<D::kInstr>();
-    } else {
-      wait_vmcnt<0>();
-    }
-#pragma unroll 1
-    for (int ap = 0; ap < HALF / 2; ++ap) {
-      float ev[2][3][2];
-      tile_dma_read_pairs<EW>(cur, lane, ap * 2, HALF + ap * 2, ev);
-#pragma unroll
-      for (int sg = 0; sg < 2; ++sg)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const f32x4 dir = dirs[e * EW + sg * HALF + ap * 2 + i];
-          const float e0 = ev[sg][0][i], e1 = ev[sg][1][i], e2 = ev[sg][2][i];
-          const float Ed = dir.w * (gd0 * e0 + gd1 * e1 + gd2 * e2);
-          const float Es = dir.w * (gs0 * e0 + gs1 * e1 + gs2 * e2);
-          const float ndl = brdf_dir_bwd(f, dir.x, dir.y, dir.z, a.F0, Ed, Es, g);
-          const float wt = ndl * dir.w;
-          ds0 = fmaf(wt, e0, ds0); ds1 = fmaf(wt, e1, ds1); ds2 = fmaf(wt, e2, ds2);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-  }
-
-  float gpn[3], gprho;
-  frame_bwd(pooled[3], pooled[4], pooled[5], pooled[6], f, g, gpn, gprho);
-  if (x.active) {
-    const unsigned off = pooled_offset<POOL>(p, a.C, a.imW);
-    const size_t plane = (size_t)a.imH * a.imW;
-    float* ga = a.g_albedo + (size_t)b * 3 * plane;
-    float* gn = a.g_normal + (size_t)b * 3 * plane;
-    float* gr = a.g_rough + (size_t)b * plane;
-    scatter_pooled<POOL>(ga, off, a.imW, gD0 * kInvPi * ds0);
-    scatter_pooled<POOL>(ga + plane, off, a.imW, gD1 * kInvPi * ds1);
-    scatter_pooled<POOL>(ga + 2 * plane, off, a.imW, gD2 * kInvPi * ds2);
-    scatter_pooled<POOL>(gn, off, a.imW, gpn[0]);
-    scatter_pooled<POOL>(gn + plane, off, a.imW, gpn[1]);
-    scatter_pooled<POOL>(gn + 2 * plane, off, a.imW, gpn[2]);
-    scatter_pooled<POOL>(gr, off, a.imW, gprho);
-  }
-}
 
 // ============================== round 3: the same adjoint, two directions per instruction ========================================
 // brdf_dir_bwd (sgr_math.h) restated over the azimuth pair (a, a+1) of one table row and sign, the packing of sgr_pk.inl: every
 // multiply-add of the world-space adjoint is one half of a v_pk_fma_f32; what stays per element are the clamps (v_med3), their
 // gradient gates, the transcendentals and the Newton steps' seeds.  Directions come from the separable table
 // (l = (ss ca_a, ss sa_a, c_e): the pair's (ca, sa) are SGPR pairs), the env rows by the double-buffered LDS-DMA of
-// brdf_bwd_dma_kernel with the pairs read as ds_read_b64.  ~150 packed + ~40 scalar instructions per PAIR against ~170 scalar per
+// render_fast_kernel, the pairs read as ds_read_b64.  ~150 packed + ~40 scalar instructions per PAIR against ~170 scalar per
 // direction.  World-space throughout, so degenerate frames need no separate path.
 struct FrameGradPk {
   f32x2 gN[3], gcx[3], gcy[3], galpha2, gk, gndv;
@@ -285,84 +214,8 @@ __device__ __forceinline__ void fold_frame_grad(const FrameGradPk& gp, FrameGrad
   g.galpha2 = gp.galpha2.x + gp.galpha2.y; g.gk = gp.gk.x + gp.gk.y; g.gndv = gp.gndv.x + gp.gndv.y;
 }
 
-// env given, envWidth 16: brdf_bwd_dma_kernel with the adjoint in azimuth pairs
-template <int POOL>
-__global__ __launch_bounds__(kWave, 2) void brdf_bwd_pk_kernel(const Args a) {
-  constexpr int EW = 16, HALF = 8;
-  using D = DmaTile<EW>;
-  __shared__ __attribute__((aligned(16))) float tile[2 * D::kFloats];
 
-  const Pix x = locate(a);
-  const int lane = x.lane, b = x.b, p = x.p;
-  const int RC = a.R * a.C;
-  float pooled[7];
-  const Frame f = load_frame_pooled<POOL>(a, x, pooled);
-  const size_t o = (size_t)b * 3 * RC + p;
-  const float gD0 = a.g_diffuse[o], gD1 = a.g_diffuse[o + RC], gD2 = a.g_diffuse[o + 2 * (size_t)RC];
-  const float gs0 = a.g_spec[o], gs1 = a.g_spec[o + RC], gs2 = a.g_spec[o + 2 * (size_t)RC];
-  const float gd0 = gD0 * (pooled[0] * kInvPi), gd1 = gD1 * (pooled[1] * kInvPi), gd2 = gD2 * (pooled[2] * kInvPi);
-
-  FrameGradPk gp;
-#pragma unroll
-  for (int i = 0; i < 3; ++i) gp.gN[i] = gp.gcx[i] = gp.gcy[i] = splat2(0.f);
-  gp.galpha2 = gp.gk = gp.gndv = splat2(0.f);
-  f32x2 ds[3] = {splat2(0.f), splat2(0.f), splat2(0.f)};
-  const SepTable rows = as_sep_table(a.rows);
-  const PairTable cpt = as_pair_table(a.cols, EW);
-  __amdgpu_buffer_rsrc_t eimg = env_rsrc(a.env_in + (size_t)b * 3 * RC * a.J, RC, a.J);
-  const int eh = a.eh;
-
-  tile_dma_issue<EW>(tile, eimg, x.p0, RC, a.J, 0, lane);
-  for (int e = 0; e < eh; ++e) {
-    const float* cur = tile + (e & 1) * D::kFloats;
-    if (e + 1 < eh) {
-      tile_dma_issue<EW>(tile + ((e + 1) & 1) * D::kFloats, eimg, x.p0, RC, a.J, (e + 1) * EW, lane);
-      wait_vmcnt<D::kInstr>();
-    } else {
-      wait_vmcnt<0>();
-    }
-    const f32x8 row = rows[e];
-    const float sr = row[0], cr = row[1], om = row[2];
-#pragma unroll 1
-    for (int ap = 0; ap < HALF / 2; ++ap) {
-      float ev[2][3][2];
-      tile_dma_read_pairs<EW>(cur, lane, ap * 2, HALF + ap * 2, ev);
-      const f32x4 cs = cpt[ap];
-      const f32x2 ca = {cs[0], cs[1]}, sa = {cs[2], cs[3]};
-#pragma unroll
-      for (int sg = 0; sg < 2; ++sg) {
-        const f32x2 ss = splat2(sg ? -sr : sr);
-        const f32x2 e0 = {ev[sg][0][0], ev[sg][0][1]}, e1 = {ev[sg][1][0], ev[sg][1][1]}, e2 = {ev[sg][2][0], ev[sg][2][1]};
-        const f32x2 Ed = splat2(om) * pfma(splat2(gd2), e2, pfma(splat2(gd1), e1, splat2(gd0) * e0));
-        const f32x2 Es = splat2(om) * pfma(splat2(gs2), e2, pfma(splat2(gs1), e1, splat2(gs0) * e0));
-        const f32x2 ndl = brdf_pair_bwd(f, ss * ca, ss * sa, cr, a.F0, Ed, Es, gp);
-        const f32x2 wt = ndl * splat2(om);
-        ds[0] = pfma(wt, e0, ds[0]); ds[1] = pfma(wt, e1, ds[1]); ds[2] = pfma(wt, e2, ds[2]);
-      }
-    }
-  }
-
-  FrameGrad g;
-  fold_frame_grad(gp, g);
-  float gpn[3], gprho;
-  frame_bwd(pooled[3], pooled[4], pooled[5], pooled[6], f, g, gpn, gprho);
-  if (x.active) {
-    const unsigned off = pooled_offset<POOL>(p, a.C, a.imW);
-    const size_t plane = (size_t)a.imH * a.imW;
-    float* ga = a.g_albedo + (size_t)b * 3 * plane;
-    float* gn = a.g_normal + (size_t)b * 3 * plane;
-    float* gr = a.g_rough + (size_t)b * plane;
-    scatter_pooled<POOL>(ga, off, a.imW, gD0 * kInvPi * (ds[0].x + ds[0].y));
-    scatter_pooled<POOL>(ga + plane, off, a.imW, gD1 * kInvPi * (ds[1].x + ds[1].y));
-    scatter_pooled<POOL>(ga + 2 * plane, off, a.imW, gD2 * kInvPi * (ds[2].x + ds[2].y));
-    scatter_pooled<POOL>(gn, off, a.imW, gpn[0]);
-    scatter_pooled<POOL>(gn + plane, off, a.imW, gpn[1]);
-    scatter_pooled<POOL>(gn + 2 * plane, off, a.imW, gpn[2]);
-    scatter_pooled<POOL>(gr, off, a.imW, gprho);
-  }
-}
-
-// the same with the half-wave split of the other backward kernels: one wave = 32 pixels, lanes l and l + 32 own the same pixel
+// env given, envWidth 16: the adjoint in azimuth pairs with the half-wave split of the other backward kernels: one wave = 32 pixels, lanes l and l + 32 own the same pixel
 // and integrate one half row (sign) each -- 6 KB row tiles (double-buffered: 12 KB, so LDS no longer caps the CU at six waves),
 // half as long work units; the two halves' sums meet once at the end (15 swaps), the lower half applies the frame adjoint
 template <int POOL>
@@ -546,21 +399,14 @@ static int brdf_launch_vec(const Args& a, hipStream_t st) {
 template <int POOL>
 static int brdf_launch(const Args& a, hipStream_t st) {
   if (a.K == 0 && a.ew == 16 && 3LL * a.R * a.C * a.J * 4 < (1LL << 31) && !sgr_generic_forced()) {
-    // SGR_BRDF_MODE = scalar (round 1 / 2 kernel) | pk (packed, one pixel per lane) | default: packed, half-wave
-    static const int mode = [] { const char* e = getenv("SGR_BRDF_MODE"); return !e ? 0 : (!strcmp(e, "scalar") ? 1 : (!strcmp(e, "pk") ? 2 : 0)); }();
-    if (mode == 1) hipLaunchKernelGGL((brdf_bwd_dma_kernel<POOL>), wave_grid(a.bn, a.R, a.C), dim3(kWave), 0, st, a);
-    else if (mode == 2) hipLaunchKernelGGL((brdf_bwd_pk_kernel<POOL>), wave_grid(a.bn, a.R, a.C), dim3(kWave), 0, st, a);
-    else hipLaunchKernelGGL((brdf_bwd_pk_half_kernel<POOL>), dim3((unsigned)(a.bn * ((a.R * a.C + kPx - 1) / kPx))), dim3(kWave), 0, st, a);
+    hipLaunchKernelGGL((brdf_bwd_pk_half_kernel<POOL>), dim3((unsigned)(a.bn * ((a.R * a.C + kPx - 1) / kPx))), dim3(kWave), 0, st, a);
     return (int)hipGetLastError();
   }
   if (a.K > 0 && a.K <= 12 && a.ew == 16 && !sgr_generic_forced()) {
-    static const bool scalar = [] { const char* e = getenv("SGR_BRDF_MODE"); return e && !strcmp(e, "scalar"); }();
-    if (!scalar) {
-      const dim3 grid((unsigned)(a.bn * ((a.R * a.C + kPx - 1) / kPx))), block(kWave);
-      if (a.K <= 6) hipLaunchKernelGGL((brdf_bwd_pk_sg_kernel<POOL, 6>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((brdf_bwd_pk_sg_kernel<POOL, 12>), grid, block, 0, st, a);
-      return (int)hipGetLastError();
-    }
+    const dim3 grid((unsigned)(a.bn * ((a.R * a.C + kPx - 1) / kPx))), block(kWave);
+    if (a.K <= 6) hipLaunchKernelGGL((brdf_bwd_pk_sg_kernel<POOL, 6>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((brdf_bwd_pk_sg_kernel<POOL, 12>), grid, block, 0, st, a);
+    return (int)hipGetLastError();
   }
   if (a.K == 0) return brdf_launch_vec<1, POOL, false>(a, st);
   if (a.K <= 4) return brdf_launch_vec<4, POOL, true>(a, st);

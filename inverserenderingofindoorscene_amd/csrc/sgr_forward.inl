@@ -141,40 +141,13 @@ template <int POOL, bool FROM_SG, bool WRITE_ENV, bool DO_RENDER>
 static int fwd_launch_k(const Args& a, hipStream_t st) {
   if (!FROM_SG) return fwd_launch_vec<1, POOL, FROM_SG, WRITE_ENV, DO_RENDER>(a, st);
   if (a.K <= 4) return fwd_launch_vec<4, POOL, FROM_SG, WRITE_ENV, DO_RENDER>(a, st);
-  if (a.K <= 8) return fwd_launch_vec<8, POOL, FROM_SG, WRITE_ENV, DO_RENDER>(a, st);
   if (a.K <= 12) return fwd_launch_vec<12, POOL, FROM_SG, WRITE_ENV, DO_RENDER>(a, st);
-  if (a.K <= 16) return fwd_launch_vec<16, POOL, FROM_SG, WRITE_ENV, DO_RENDER>(a, st);
   if (a.K <= 24) return fwd_launch_vec<24, POOL, FROM_SG, WRITE_ENV, DO_RENDER>(a, st);
   return fwd_launch_vec<32, POOL, FROM_SG, WRITE_ENV, DO_RENDER>(a, st);
 }
 
-// fast path (separable table, EW in {16,32}, K <= 24)
-template <int KP, int EW, int TJ, bool WRITE_ENV, bool DO_RENDER>
-static int fwd_fast_launch_pool(const Args& a, hipStream_t st) {
-  const dim3 grid = wave_grid(a.bn, a.R, a.C), block(kWave);
-  if (!DO_RENDER || (a.imH == a.R && a.imW == a.C))
-    hipLaunchKernelGGL((fwd_fast_kernel<KP, 1, EW, TJ, WRITE_ENV, DO_RENDER>), grid, block, 0, st, a);
-  else
-    hipLaunchKernelGGL((fwd_fast_kernel<KP, 2, EW, TJ, WRITE_ENV, DO_RENDER>), grid, block, 0, st, a);
-  return (int)hipGetLastError();
-}
-// tile width for EW = 16: 32 directions (two table rows, full 128-byte lines, 27 KB LDS) or 16 (one
-// row, 64-byte segments, 15 KB LDS -> twice the resident waves).  Tuning knob: SGR_FWD_TJ.
-static inline int fwd_tile_width() {
-  static const int tj = [] { const char* e = getenv("SGR_FWD_TJ"); return (e && atoi(e) == 32) ? 32 : 16; }();   // 16 measured faster
-  return tj;
-}
-// lobes split over the two halves of a wave (envWidth 16, 6 < SGNum <= 12); SGR_FWD_MODE = full | half2 | half3
-template <bool WRITE_ENV, bool DO_RENDER, int OCC>
-static int fwd_half_launch(const Args& a, hipStream_t st) {
-  const dim3 grid((unsigned)(a.bn * ((a.R * a.C + kPx - 1) / kPx))), block(kWave);
-  if (!DO_RENDER || (a.imH == a.R && a.imW == a.C))
-    hipLaunchKernelGGL((fwd_half_kernel<1, WRITE_ENV, DO_RENDER, OCC>), grid, block, 0, st, a);
-  else
-    hipLaunchKernelGGL((fwd_half_kernel<2, WRITE_ENV, DO_RENDER, OCC>), grid, block, 0, st, a);
-  return (int)hipGetLastError();
-}
-// packed-fp32 forward (envWidth 16, SGNum <= 12): one pixel per lane, arithmetic in azimuth pairs (sgr_pk.inl)
+// ---- fast path (separable table, envWidth 16 or 32, SGNum <= 24): the packed-fp32 kernels of sgr_pk.inl ---------------
+// packed forward, one pixel per lane (envWidth 16, SGNum <= KP)
 template <int KP, bool WRITE_ENV, bool DO_RENDER, bool HEADS = false>
 static int fwd_pk_launch(const Args& a, hipStream_t st) {
   const dim3 grid = wave_grid(a.bn, a.R, a.C), block(kWave);
@@ -184,91 +157,44 @@ static int fwd_pk_launch(const Args& a, hipStream_t st) {
     hipLaunchKernelGGL((fwd_pk_kernel<KP, 2, WRITE_ENV, DO_RENDER, false, HEADS>), grid, block, 0, st, a);
   return (int)hipGetLastError();
 }
-// packed half-wave forward (envWidth 16, 6 < SGNum <= 12), OCC resident waves per SIMD
-template <bool WRITE_ENV, bool DO_RENDER, int OCC, int EW = 16, int RPF = 1, bool HEADS = false>
+// packed half-wave forward: 32 pixels x 2 groups of KPW lobes per wave, OCC resident waves per SIMD, RPF table rows per env flush
+template <bool WRITE_ENV, bool DO_RENDER, int OCC, int KPW, int EW, int RPF, bool HEADS>
 static int fwd_pk_half_launch(const Args& a, hipStream_t st) {
   const dim3 grid((unsigned)(a.bn * ((a.R * a.C + kPx - 1) / kPx))), block(kWave);
   if (!DO_RENDER || (a.imH == a.R && a.imW == a.C))
-    hipLaunchKernelGGL((fwd_pk_half_kernel<1, WRITE_ENV, DO_RENDER, OCC, 6, EW, RPF, HEADS>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((fwd_pk_half_kernel<1, WRITE_ENV, DO_RENDER, OCC, KPW, EW, RPF, HEADS>), grid, block, 0, st, a);
   else
-    hipLaunchKernelGGL((fwd_pk_half_kernel<2, WRITE_ENV, DO_RENDER, OCC, 6, EW, RPF, HEADS>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((fwd_pk_half_kernel<2, WRITE_ENV, DO_RENDER, OCC, KPW, EW, RPF, HEADS>), grid, block, 0, st, a);
   return (int)hipGetLastError();
 }
-// packed half-wave forward with 12 lobes per half: 12 < SGNum <= 24, envWidth 16 or 32 (config 5)
-template <bool WRITE_ENV, bool DO_RENDER, int EW, bool HEADS = false>
-static int fwd_pk_half24_launch(const Args& a, hipStream_t st) {
-  const dim3 grid((unsigned)(a.bn * ((a.R * a.C + kPx - 1) / kPx))), block(kWave);
-  if (!DO_RENDER || (a.imH == a.R && a.imW == a.C))
-    hipLaunchKernelGGL((fwd_pk_half_kernel<1, WRITE_ENV, DO_RENDER, 2, 12, EW, 1, HEADS>), grid, block, 0, st, a);
-  else
-    hipLaunchKernelGGL((fwd_pk_half_kernel<2, WRITE_ENV, DO_RENDER, 2, 12, EW, 1, HEADS>), grid, block, 0, st, a);
-  return (int)hipGetLastError();
-}
-static inline int fwd_mode() {     // 4 packed (default; 7: one pixel per lane always, 5 / 6: half-wave always), 0 scalar one pixel per lane, 2 / 3 scalar half-wave kernel, -1 round-1 default
-  static const int mode = [] {
-    const char* e = getenv("SGR_FWD_MODE");
-    if (!e) return 4;
-    if (!strcmp(e, "pk")) return 7;      // packed, one pixel per lane for every forward variant
-    if (e && !strcmp(e, "pkhalf2")) return 5;
-    if (e && !strcmp(e, "pkhalf3")) return 6;
-    if (e && !strcmp(e, "pkhalf2w")) return 8;     // half-wave, two table rows per env flush (128-byte segments), 2 / 3 waves per SIMD
-    if (e && !strcmp(e, "pkhalf3w")) return 9;
-    if (e && !strcmp(e, "scalar")) return -1;
-    if (e && !strcmp(e, "full")) return 0;
-    if (e && !strcmp(e, "half2")) return 2;
-    if (e && !strcmp(e, "half3")) return 3;
-    return -1;
-  }();
-  return mode;
+// Which packed kernel runs which shape.  Every choice is a measured one (the A/B records are
+// profiles/r02*, r03c_fwd_mode_sweep.txt); the superseded scalar kernels and the knobs that selected them were retired in round 4.
+//   SGNum 13..24          half-wave, 12 lobes per half (config 5: 16x32 grid, 24 lobes)
+//   envWidth 32, <= 12    half-wave, 6 lobes per half, three waves per SIMD
+//   envWidth 16, 7..12    env image written: half-wave with a two-row (128-byte line) env tile, three waves per SIMD --
+//                         in the bench loop the forward tracks the WRITE path and whole lines write at ~5 TB/s where 64-byte
+//                         segments reach ~3;  render only: one pixel per lane (no duplicated frame set-up)
+//   envWidth 16, <= 6     one pixel per lane, six lobe slots
+template <bool WRITE_ENV, bool DO_RENDER, bool HEADS>
+static int fwd_fast_launch_h(const Args& a, hipStream_t st) {
+  if (a.K > 12)
+    return a.ew == 16 ? fwd_pk_half_launch<WRITE_ENV, DO_RENDER, 2, 12, 16, 1, HEADS>(a, st)
+                      : fwd_pk_half_launch<WRITE_ENV, DO_RENDER, 2, 12, 32, 1, HEADS>(a, st);
+  if (a.ew == 32) return fwd_pk_half_launch<WRITE_ENV, DO_RENDER, 3, 6, 32, 1, HEADS>(a, st);
+  if constexpr (WRITE_ENV) {
+    if (a.K > 6) return fwd_pk_half_launch<WRITE_ENV, DO_RENDER, 3, 6, 16, 2, HEADS>(a, st);
+  }
+  if constexpr (!HEADS) {
+    if (a.K <= 6) return fwd_pk_launch<6, WRITE_ENV, DO_RENDER>(a, st);
+  }
+  return fwd_pk_launch<12, WRITE_ENV, DO_RENDER, HEADS>(a, st);
 }
 template <bool WRITE_ENV, bool DO_RENDER>
 static int fwd_fast_launch(const Args& a, hipStream_t st) {
-  // measured at config 2, one pixel per lane / half-wave: in the bench loop (working set cycling through HBM) env + render
-  // 239 / 206 us, render only 163 / 172 us; relaunched on the same buffers (tools/kbench, inputs partly cache-resident)
-  // env + render 214-223 / 209-219 us, env only 178 / 149 us  ->  half-wave whenever the env image is written
-  if constexpr (DO_RENDER) {
-    // premap == 3 (decoder heads as the prologue; fwd_heads_ok holds): the default kernel of each shape, built with HEADS
-    if (a.premap == 3) {
-      if (a.K > 12) return a.ew == 16 ? fwd_pk_half24_launch<WRITE_ENV, DO_RENDER, 16, true>(a, st) : fwd_pk_half24_launch<WRITE_ENV, DO_RENDER, 32, true>(a, st);
-      if (a.ew == 32) return fwd_pk_half_launch<WRITE_ENV, DO_RENDER, 3, 32, 1, true>(a, st);
-      if constexpr (WRITE_ENV) return fwd_pk_half_launch<WRITE_ENV, DO_RENDER, 3, 16, 2, true>(a, st);
-      return fwd_pk_launch<12, WRITE_ENV, DO_RENDER, true>(a, st);
-    }
+  if constexpr (DO_RENDER) {      // premap == 3 (decoder heads as the prologue; fwd_heads_ok holds): the same kernels built with HEADS
+    if (a.premap == 3) return fwd_fast_launch_h<WRITE_ENV, DO_RENDER, true>(a, st);
   }
-  if (fwd_mode() >= 4 && a.K > 12 && a.K <= 24)      // 24 lobes: 12 per half-wave, packed (config 5: 1.32 -> ms with the scalar 24-lobe kernel)
-    return a.ew == 16 ? fwd_pk_half24_launch<WRITE_ENV, DO_RENDER, 16>(a, st) : fwd_pk_half24_launch<WRITE_ENV, DO_RENDER, 32>(a, st);
-  if (fwd_mode() >= 4 && a.ew == 32 && a.K > 6 && a.K <= 12)      // 16x32 grid, up to 12 lobes: six per half-wave, packed
-    return fwd_pk_half_launch<WRITE_ENV, DO_RENDER, 3, 32>(a, st);
-  // packed kernels at 7..12 lobes on the 8x16 grid.  Round 3, measured in the bench loop (the only place where the working set
-  // cycles through HBM; relaunched on warm buffers the env stores land in the Infinity Cache): once the env image is written the
-  // forward is bound by the WRITE path, and 64-byte segments (one table row per pixel and colour) write at ~3 TB/s where whole
-  // 128-byte lines reach ~5 (profiles/r02b_storebench*).  The half-wave kernel's 32-pixel tile holds two table rows in 12 KB --
-  // three waves per SIMD still fit -- so it is the default whenever the env image is written: forward per image 9.2 us at
-  // batch 16 (one pixel per lane, 64-byte segments: 9.2), 9.0 against 10.7-11.3 at batch 32-64 (profiles/r03c_fwd_mode_sweep.txt).
-  // Render only (no env image): one pixel per lane.  SGR_FWD_MODE = pk | pkhalf2 | pkhalf3 | pkhalf2w | pkhalf3w forces one form.
-  if constexpr (WRITE_ENV) {
-    if (a.ew == 16 && a.K > 6 && a.K <= 12 && (fwd_mode() == 4 || fwd_mode() >= 8))
-      return fwd_mode() == 8 ? fwd_pk_half_launch<WRITE_ENV, DO_RENDER, 2, 16, 2>(a, st) : fwd_pk_half_launch<WRITE_ENV, DO_RENDER, 3, 16, 2>(a, st);
-  }
-  if (a.ew == 16 && a.K > 6 && a.K <= 12 && (fwd_mode() == 5 || fwd_mode() == 6 || fwd_mode() >= 8))
-    return fwd_mode() == 5 || fwd_mode() == 8 ? fwd_pk_half_launch<WRITE_ENV, DO_RENDER, 2>(a, st) : fwd_pk_half_launch<WRITE_ENV, DO_RENDER, 3>(a, st);
-  if (fwd_mode() >= 4 && a.ew == 16 && a.K <= 12)
-    return a.K <= 6 ? fwd_pk_launch<6, WRITE_ENV, DO_RENDER>(a, st) : fwd_pk_launch<12, WRITE_ENV, DO_RENDER>(a, st);
-  const int mode = (fwd_mode() >= 0 && fwd_mode() < 4) ? fwd_mode() : (WRITE_ENV ? 2 : 0);
-  if (a.ew == 16 && a.K > 6 && a.K <= 12 && mode != 0)
-    return mode == 3 ? fwd_half_launch<WRITE_ENV, DO_RENDER, 3>(a, st) : fwd_half_launch<WRITE_ENV, DO_RENDER, 2>(a, st);
-  if (a.ew == 16) {
-    if (WRITE_ENV && fwd_tile_width() == 16) {
-      if (a.K <= 6) return fwd_fast_launch_pool<6, 16, 16, WRITE_ENV, DO_RENDER>(a, st);
-      return a.K <= 12 ? fwd_fast_launch_pool<12, 16, 16, WRITE_ENV, DO_RENDER>(a, st)
-                       : fwd_fast_launch_pool<24, 16, 16, WRITE_ENV, DO_RENDER>(a, st);
-    }
-    if (a.K <= 6) return fwd_fast_launch_pool<6, 16, 32, WRITE_ENV, DO_RENDER>(a, st);
-    return a.K <= 12 ? fwd_fast_launch_pool<12, 16, 32, WRITE_ENV, DO_RENDER>(a, st)
-                     : fwd_fast_launch_pool<24, 16, 32, WRITE_ENV, DO_RENDER>(a, st);
-  }
-  return a.K <= 12 ? fwd_fast_launch_pool<12, 32, 32, WRITE_ENV, DO_RENDER>(a, st)
-                   : fwd_fast_launch_pool<24, 32, 32, WRITE_ENV, DO_RENDER>(a, st);
+  return fwd_fast_launch_h<WRITE_ENV, DO_RENDER, false>(a, st);
 }
 
 static int render_fast_launch(const Args& a, hipStream_t st) {
@@ -295,7 +221,7 @@ static int fwd_launch(const Args& a, hipStream_t st) {
 // premap == 3 (the decoder heads as a prologue) is implemented in the packed kernels' lobe loader (sgr_pk.inl) only: the shapes
 // the default dispatch above sends there
 static inline bool fwd_heads_ok(const Args& a) {
-  return fast_ok(a) && !sgr_generic_forced() && fwd_mode() == 4 && a.K > 6 && a.K <= 24;
+  return fast_ok(a) && !sgr_generic_forced() && a.K > 6 && a.K <= 24;
 }
 
 static inline int check_pool(int R, int C, int imH, int imW, const char* who) {

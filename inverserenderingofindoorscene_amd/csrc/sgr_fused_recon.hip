@@ -29,255 +29,7 @@
 
 namespace sgr {
 
-template <int POOL>
-__global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_kernel(const Args a) {
-  constexpr int EW = 16, HALF = 8, NP = 4, KPW = 6;
-  __shared__ __attribute__((aligned(16))) float tile[2 * kT32Floats];          // ground-truth rows, double-buffered
-
-  const int lane = threadIdx.x, half = lane >> 5, pl = lane & 31;
-  const int own = 1 - half;                         // the half row (sign) this half-wave evaluates the cotangent of
-  const int RC = a.R * a.C, K = a.K;
-  Pix x;
-  x.lane = lane;
-  {
-    const int tiles = (RC + kPx - 1) / kPx;
-    x.b = blockIdx.x / tiles;
-    x.p0 = (blockIdx.x - x.b * tiles) * kPx;
-    x.active = (x.p0 + pl) < RC;
-    x.p = x.active ? (x.p0 + pl) : (RC - 1);
-  }
-  const int b = x.b, p = x.p;
-
-  __amdgpu_buffer_rsrc_t gimg = env_rsrc(a.env_gt + (size_t)b * 3 * RC * a.J, RC, a.J);
-  tile32_dma_issue(tile, gimg, x.p0, RC, a.J, 0, lane);
-
-  float alb[3];
-  const Frame f = load_frame<POOL>(a, x, alb);
-  PixLocal q = make_local(f, a.F0);
-  const bool ortho = __all(frame_is_orthonormal(q));
-  float gd0, gd1, gd2, gs0, gs1, gs2;
-  {
-    const size_t o = (size_t)b * 3 * RC;
-    const unsigned up = (unsigned)p;
-    gd0 = (a.g_diffuse + o)[up] * (alb[0] * kInvPi);
-    gd1 = (a.g_diffuse + o + RC)[up] * (alb[1] * kInvPi);
-    gd2 = (a.g_diffuse + o + 2 * (size_t)RC)[up] * (alb[2] * kInvPi);
-    gs0 = (a.g_spec + o)[up];
-    gs1 = (a.g_spec + o + RC)[up];
-    gs2 = (a.g_spec + o + 2 * (size_t)RC)[up];
-  }
-  // reconstruction side: x = cf p + off;  dnum/dp = 2 m (ln x - ln(gt + off)) cf / x        (coef is a constant)
-  const float cf = a.coef[b], off = a.offset;
-  const float m = x.active ? (a.mask_in + (size_t)b * RC)[(unsigned)p] : 0.0f;
-  // d objective / d num = rec_weight / (3 J max(den, 1e-5)), den = the env-mask sum of the (global) batch
-  float den;
-  if (a.den_global) {
-    den = a.den_global[0];
-  } else {
-    double sden = 0.0;
-    for (int i = 0; i < a.bn; ++i) sden += (double)a.den_img[i];
-    den = (float)sden;
-  }
-  const float rec_scale = a.rec_w3j / fmaxf(den, 1e-5f);
-  const float grec = 2.0f * m * rec_scale * cf * kLn2;     // times dl (in log2 units) / x
-  float loss = 0.0f;
-
-  // this half's lobes: per-lane offsets into the image's SG block (lobe index differs between the halves)
-  Lobes<KPW> L;
-  const float* axis_b = a.axis + (size_t)b * K * 3 * RC;
-  const float* lamb_b = a.lamb + (size_t)b * K * RC;
-  const float* weight_b = a.weight + (size_t)b * K * 3 * RC;
-#pragma unroll
-  for (int k = 0; k < KPW; ++k) {
-    const int kk = half * KPW + k, kc = min(kk, K - 1);
-    const unsigned o3 = (unsigned)(kc * 3 * RC + p), o1 = (unsigned)(kc * RC + p);
-    L.ax[k] = axis_b[o3]; L.ay[k] = axis_b[o3 + RC]; L.az[k] = axis_b[o3 + 2 * RC];
-    L.lp[k] = lamb_b[o1];
-    L.w0[k] = weight_b[o3]; L.w1[k] = weight_b[o3 + RC]; L.w2[k] = weight_b[o3 + 2 * RC];
-  }
-#pragma unroll
-  for (int k = 0; k < KPW; ++k) {
-    const bool live = half * KPW + k < K;
-    float l = L.lp[k], t0 = L.w0[k], t1 = L.w1[k], t2 = L.w2[k];
-    if (a.premap == 1) { l = premap(l); t0 = premap(t0); t1 = premap(t1); t2 = premap(t2); }
-    L.lp[k] = l * kLog2e;
-    L.w0[k] = live ? t0 : 0.0f; L.w1[k] = live ? t1 : 0.0f; L.w2[k] = live ? t2 : 0.0f;
-  }
-  float gax[KPW], gay[KPW], gaz[KPW], glam[KPW], gw0[KPW], gw1[KPW], gw2[KPW];
-#pragma unroll
-  for (int k = 0; k < KPW; ++k) gax[k] = gay[k] = gaz[k] = glam[k] = gw0[k] = gw1[k] = gw2[k] = 0.0f;
-
-  const SepTable rows = as_sep_table(a.rows);
-  const XTable cst = (XTable)(a.cols);
-  const XTable xt = (XTable)(a.cols + EW);
-  const int eh = a.eh;
-
-  f32x8 row_next = rows[0];
-  auto row_loop = [&](auto ortho_c) {
-    for (int e = 0; e < eh; ++e) {
-      const float* cur = tile + (e & 1) * kT32Floats;
-      if (e + 1 < eh) {
-        tile32_dma_issue(tile + ((e + 1) & 1) * kT32Floats, gimg, x.p0, RC, a.J, (e + 1) * EW, lane);
-        wait_vmcnt<6>();        // row e has landed; row e+1 stays in flight
-      } else {
-        wait_vmcnt<0>();
-      }
-#pragma unroll
-      for (int k = 0; k < KPW; ++k) { asm volatile("" : "+v"(L.ax[k])); asm volatile("" : "+v"(L.ay[k])); }   // no LICM of u_ka
-      fence_row_invariants(q);
-      // scalar table entries are requested one iteration ahead (and after the wait for the current one, since
-      // scalar loads can only be waited for all together)
-      const f32x8 row = row_next;
-      {
-        int ne = e + 1 < eh ? e + 1 : e;
-        asm volatile("" : "+s"(ne) : "s"(row));
-        row_next = rows[ne];
-      }
-      f32x4 cs_next = cst[0];
-      __builtin_amdgcn_sched_barrier(0);
-      const float sr = row[0], cr = row[1];
-      const RowCtx rc = make_row_ctx(q, row, true);
-
-#pragma unroll 1
-      for (int ap = 0; ap < NP; ++ap) {
-        const f32x4 cs = cs_next;
-        {
-          int nxt = (ap + 1) & (NP - 1);
-          asm volatile("" : "+s"(nxt) : "s"(cs));
-          cs_next = cst[nxt];
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        const float ca[2] = {cs[0], cs[2]}, sa[2] = {cs[1], cs[3]};
-        // ---- 1. this half's lobes: exponentials and partial radiance of the 4 directions -----------------
-        float ex[KPW][2][2], u[KPW][2];
-        float v[2][3][2];        // [half row][colour][azimuth]
-#pragma unroll
-        for (int sg = 0; sg < 2; ++sg)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) v[sg][c][0] = v[sg][c][1] = 0.0f;
-#pragma unroll
-        for (int k = 0; k < KPW; ++k) {
-          const float czr = fmaf(L.az[k], cr, -1.0f);
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            u[k][i] = fmaf(L.ay[k], sa[i], L.ax[k] * ca[i]);
-#pragma unroll
-            for (int sg = 0; sg < 2; ++sg) {
-              const float t = fmaf(sg ? -sr : sr, u[k][i], czr);
-              const float e_ = fexp2(L.lp[k] * t);
-              ex[k][i][sg] = e_;
-              v[sg][0][i] = fmaf(L.w0[k], e_, v[sg][0][i]);
-              v[sg][1][i] = fmaf(L.w1[k], e_, v[sg][1][i]);
-              v[sg][2][i] = fmaf(L.w2[k], e_, v[sg][2][i]);
-            }
-          }
-        }
-        // ---- 2. full radiance of the half row this half-wave owns (lanes 0..31: half row 1, 32..63: half row 0)
-        float tot[3][2];
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            float d_ = v[1][c][i], s_ = v[0][c][i];
-            swap32(d_, s_);
-            tot[c][i] = d_ + s_;
-          }
-        // ---- 3. its cotangent: reconstruction term (and loss) + render term --------------------------------
-        float gt[3][2];
-        tile32_read_pair(cur, pl, own * HALF + ap * 2, gt);
-        float go[3][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          float wt, sp;
-          shade_dir<decltype(ortho_c)::value>(q, rc, own, ca[i], sa[i], xt, ap * 2 + i, wt, sp);
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const float xx = fmaf(cf, tot[c][i], off);
-            const float r = __builtin_amdgcn_rcpf(xx);
-            const float dl = -__builtin_amdgcn_logf((gt[c][i] + off) * r);   // log2(x / (gt + off))
-            loss = fmaf(dl, dl, loss);
-            const float gr = c == 0 ? fmaf(gs0, sp, gd0) : (c == 1 ? fmaf(gs1, sp, gd1) : fmaf(gs2, sp, gd2));
-            go[c][i] = fmaf(grec * dl, r, wt * gr);
-          }
-        }
-        // ---- 4. both half rows' cotangents to all lanes --------------------------------------------------------
-        float g[2][3][2];
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            float d_ = go[c][i], s_ = go[c][i];
-            swap32(d_, s_);
-            g[1][c][i] = d_;     // from lanes 0..31
-            g[0][c][i] = s_;     // from lanes 32..63
-          }
-        // ---- 5. this half's lobes: gradient accumulation -------------------------------------------------------
-#pragma unroll
-        for (int k = 0; k < KPW; ++k) {
-          const float czr = fmaf(L.az[k], cr, -1.0f);
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            float A = 0.0f;
-#pragma unroll
-            for (int sg = 0; sg < 2; ++sg) {
-              const float ss = sg ? -sr : sr;
-              const float t = fmaf(ss, u[k][i], czr);
-              const float e_ = ex[k][i][sg];
-              const float c0 = g[sg][0][i], c1 = g[sg][1][i], c2 = g[sg][2][i];
-              gw0[k] = fmaf(c0, e_, gw0[k]);
-              gw1[k] = fmaf(c1, e_, gw1[k]);
-              gw2[k] = fmaf(c2, e_, gw2[k]);
-              const float T = fmaf(c2, L.w2[k], fmaf(c1, L.w1[k], c0 * L.w0[k])) * e_;
-              glam[k] = fmaf(T, t, glam[k]);
-              A = fmaf(ss, T, A);
-              gaz[k] = fmaf(cr, T, gaz[k]);
-            }
-            gax[k] = fmaf(ca[i], A, gax[k]);
-            gay[k] = fmaf(sa[i], A, gay[k]);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  };
-  if (ortho) row_loop(std::true_type{}); else row_loop(std::false_type{});
-
-  // loss partial of the tile: sum_p m_p sum_{c,j} (ln x - ln(gt+off))^2   (each half holds its half rows' share)
-  {
-    float r0 = m * loss * (kLn2 * kLn2);
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) r0 += __shfl_xor(r0, s, 64);
-    if (lane == 0) a.ws[blockIdx.x] = r0;
-  }
-
-  if (x.active) {
-    float* g_axis_b = a.g_axis + (size_t)b * K * 3 * RC;
-    float* g_lamb_b = a.g_lamb + (size_t)b * K * RC;
-    float* g_weight_b = a.g_weight + (size_t)b * K * 3 * RC;
-#pragma unroll
-    for (int k = 0; k < KPW; ++k) {
-      const int kk = half * KPW + k;
-      if (kk < K) {
-        const unsigned o3 = (unsigned)(kk * 3 * RC + p), o1 = (unsigned)(kk * RC + p);
-        const float lam = L.lp[k] * kLn2;
-        g_axis_b[o3] = lam * gax[k];
-        g_axis_b[o3 + RC] = lam * gay[k];
-        g_axis_b[o3 + 2 * RC] = lam * gaz[k];
-        float gl = glam[k], q0 = gw0[k], q1 = gw1[k], q2 = gw2[k];
-        if (a.premap) {
-          gl *= premap_grad(lam);
-          q0 *= premap_grad(L.w0[k]); q1 *= premap_grad(L.w1[k]); q2 *= premap_grad(L.w2[k]);
-        }
-        g_lamb_b[o1] = gl;
-        g_weight_b[o3] = q0;
-        g_weight_b[o3 + RC] = q1;
-        g_weight_b[o3 + 2 * RC] = q2;
-      }
-    }
-  }
-}
-
-// ---- the same pass with the arithmetic in azimuth pairs (sgr_pk.inl): v_pk_fma_f32 over the directions (e, a), (e, a+1) ----
+// ---- the pass in azimuth pairs (sgr_pk.inl): v_pk_fma_f32 over the directions (e, a), (e, a+1) ----
 // Per azimuth pair and lobe: 8 packed instructions + 4 v_exp for the exponentials and the partial radiance, 23 packed for the
 // gradient accumulation (the exponentials are kept, u / t are re-formed: registers); per pair 6 swaps + 3 packed adds for the
 // radiance, 6 v_rcp + 6 v_log for loss and cotangent, 6 swaps to hand the cotangents round.
@@ -667,18 +419,13 @@ static int fused_fwd_recon_impl(const float* albedo, const float* normal, const 
   set_dims(a, bn, K, R, C, eh, ew, imH, imW);
   a.F0 = F0; a.premap = premap == 1 ? 1 : (premap == 3 ? 3 : 0);
   SGR_REQUIRE(premap >= 0 && premap <= 3, "sgr_fused_fwd_recon: premap must be 0..3");
-  static const bool f1_default = getenv("SGR_F1_MODE") == nullptr;
-  SGR_SUPPORTED(premap != 3 || (K > 6 && f1_default), "sgr_fused_fwd_recon: premap 3 (decoder heads as a prologue) needs 6 < SGNum <= 24 and the default kernels");
-  // SGR_F1_MODE=half: half-wave statistics kernel (32-pixel work units); scalar: round 1's one pixel per lane; default: packed fp32
-  static const int f1_mode = [] { const char* e = getenv("SGR_F1_MODE"); return !e ? 0 : (!strcmp(e, "half") ? 1 : (!strcmp(e, "scalar") ? 2 : 0)); }();
-  // SGR_F1_MODE=pkhalf: the packed half-wave statistics kernel also for 7..12 lobes on the 8x16 grid (3 waves per SIMD)
-  static const bool f1_pkhalf = [] { const char* e = getenv("SGR_F1_MODE"); return e && !strcmp(e, "pkhalf"); }();
-  // premap == 3 (decoder heads as the prologue): always the half-wave kernel -- at three waves per SIMD the 42 tanh per lane
-  // disappear behind the other waves' row loops (165 us with or without them at config 2), where the one-pixel-per-lane
-  // kernel's 84 per lane at two waves per SIMD cost 22-32 us
-  const bool wide = K > 12 || ew == 32 || (f1_pkhalf && K > 6) || premap == 3;      // beyond the 12-lobe 8x16 kernels: packed half-wave statistics kernel (12 lobes per half for K > 12)
-  const bool f1_half = !wide && f1_mode == 1 && K > 6;
-  const int tiles = (f1_half || wide) ? recon_tiles32(R * C) : recon_tiles(R * C);
+  SGR_SUPPORTED(premap != 3 || K > 6, "sgr_fused_fwd_recon: premap 3 (decoder heads as a prologue) needs 6 < SGNum <= 24");
+  // 7..12 lobes on the 8x16 grid with pre-mapped or post-tan inputs: packed, one pixel per lane.  Everything else -- more lobes,
+  // the 16x32 grid, and premap == 3 -- the packed half-wave statistics kernel: at three waves per SIMD the 42 tanh per lane of
+  // the decoder heads disappear behind the other waves' row loops (165 us with or without them at config 2), where the
+  // one-pixel-per-lane kernel's 84 per lane at two waves per SIMD cost 22-32 us
+  const bool wide = K > 12 || ew == 32 || premap == 3;
+  const int tiles = wide ? recon_tiles32(R * C) : recon_tiles(R * C);
   float* den_img = workspace;
   float* ws0 = workspace + bn + 4;
   a.ws = ws0;
@@ -702,24 +449,14 @@ static int fused_fwd_recon_impl(const float* albedo, const float* normal, const 
     else if (ew == 16) SGR_LAUNCH_GT(12, 16, 2);
     else SGR_LAUNCH_GT(12, 32, 2);
 #undef SGR_LAUNCH_GT
-  } else if (f1_half) {
-    const dim3 grid((unsigned)(bn * tiles)), block(kWave);
-    if (p1) hipLaunchKernelGGL((fwd_half_kernel<1, false, true, 2, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((fwd_half_kernel<2, false, true, 2, true>), grid, block, 0, st, a);
   } else {
     const dim3 grid = wave_grid(bn, R, C), block(kWave);
-    if (f1_mode == 0 && K <= 6) {
+    if (K <= 6) {
       if (p1) hipLaunchKernelGGL((fwd_pk_kernel<6, 1, false, true, true>), grid, block, 0, st, a);
       else hipLaunchKernelGGL((fwd_pk_kernel<6, 2, false, true, true>), grid, block, 0, st, a);
-    } else if (f1_mode == 0) {
+    } else {
       if (p1) hipLaunchKernelGGL((fwd_pk_kernel<12, 1, false, true, true>), grid, block, 0, st, a);
       else hipLaunchKernelGGL((fwd_pk_kernel<12, 2, false, true, true>), grid, block, 0, st, a);
-    } else if (K <= 6) {
-      if (p1) hipLaunchKernelGGL((fwd_fast_kernel<6, 1, 16, 16, false, true, true>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((fwd_fast_kernel<6, 2, 16, 16, false, true, true>), grid, block, 0, st, a);
-    } else {
-      if (p1) hipLaunchKernelGGL((fwd_fast_kernel<12, 1, 16, 16, false, true, true>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((fwd_fast_kernel<12, 2, 16, 16, false, true, true>), grid, block, 0, st, a);
     }
   }
   hipLaunchKernelGGL(recon_fold0, dim3(bn), dim3(kRThreads), 0, st, ws0, coef, den_img, tiles);
@@ -771,8 +508,7 @@ static int fused_bwd_recon_impl(const float* albedo, const float* normal, const 
               "sgr_fused_bwd_recon: NULL tensor");
   SGR_REQUIRE(bn > 0 && K > 0 && R > 0 && C > 0 && eh > 0 && ew > 0, "sgr_fused_bwd_recon: non-positive size");
   SGR_REQUIRE(premap >= 0 && premap <= 3, "sgr_fused_bwd_recon: premap must be 0..3");
-  static const bool b1_default = getenv("SGR_B1_MODE") == nullptr;
-  SGR_SUPPORTED(premap != 3 || (K > 6 && b1_default), "sgr_fused_bwd_recon: premap 3 (decoder heads as a prologue) needs 6 < SGNum <= 24 and the default kernels");
+  SGR_SUPPORTED(premap != 3 || K > 6, "sgr_fused_bwd_recon: premap 3 (decoder heads as a prologue) needs 6 < SGNum <= 24");
   SGR_SUPPORTED(fused_recon_ok(K, R, C, eh, ew), "sgr_fused_bwd_recon: needs envWidth 16 or 32 and SGNum <= 24 (use the unfused calls)");
   if (int rc = check_pool(R, C, imH, imW, "sgr_fused_bwd_recon: BRDF-map / env-grid ratio must be 1 or 2 (pool first)")) return rc;
   Args a{};
@@ -790,13 +526,8 @@ static int fused_bwd_recon_impl(const float* albedo, const float* normal, const 
   a.ws = ws1; a.den_img = den_img; a.den_global = den_global; a.rec_w3j = rec_weight / (3.0f * (float)(eh * ew));
   const hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)(bn * tiles)), block(kWave);
-  // SGR_B1_MODE=scalar: round 1's kernel (envWidth 16, SGNum <= 12 only); default: the same pass in packed fp32
-  static const bool b1_scalar = [] { const char* e = getenv("SGR_B1_MODE"); return e && !strcmp(e, "scalar"); }();
   const bool p1 = (imH == R && imW == C);
-  if (b1_scalar && !four && ew == 16) {
-    if (p1) hipLaunchKernelGGL((sg_bwd_recon_kernel<1>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((sg_bwd_recon_kernel<2>), grid, block, 0, st, a);
-  } else {
+  {
 #define SGR_LAUNCH_BR(EW_, NG_)                                                                              \
     do {                                                                                                     \
       if (premap == 3) {                                                                                     \

@@ -53,6 +53,5 @@ extern "C" int sgr_debug_trace_fwd(void* device_buffer) {
 extern "C" int sgr_heads_prologue_supported(int K, int R, int C, int eh, int ew) {
   Args a{};
   set_dims(a, 1, K, R, C, eh, ew, R, C);
-  static const bool recon_default = [] { return getenv("SGR_F1_MODE") == nullptr && getenv("SGR_B1_MODE") == nullptr && getenv("SGR_BWD_MODE") == nullptr; }();
-  return (K > 0 && R > 0 && C > 0 && eh > 0 && ew > 0 && fwd_heads_ok(a) && recon_default) ? 1 : 0;
+  return (K > 0 && R > 0 && C > 0 && eh > 0 && ew > 0 && fwd_heads_ok(a)) ? 1 : 0;
 }

@@ -198,6 +198,10 @@ def test_sg_only_grads_like_trainlight(sgr, golden):
     dict(bn=1, imH=10, imW=12, R=5, C=6, K=12, eh=3, ew=32),     # envWidth 32: table rows walked as two virtual rows
     dict(bn=2, imH=12, imW=16, R=6, C=8, K=32, eh=3, ew=16),     # three groups of 12 lobes (one workgroup each in the backward)
     dict(bn=1, imH=14, imW=18, R=7, C=9, K=17, eh=5, ew=32),     # two lobe groups, the second partly empty, envWidth 32, ragged tiles
+    # round 4: SGNum <= 6 runs the packed half-wave kernels with the upper half's lobe slots empty (the scalar kernels are gone)
+    dict(bn=1, imH=10, imW=12, R=5, C=6, K=4, eh=4, ew=32),      # envWidth 32, four lobes
+    dict(bn=2, imH=7, imW=9, R=7, C=9, K=6, eh=8, ew=16),        # exactly one half's worth of lobes
+    dict(bn=1, imH=12, imW=16, R=6, C=8, K=1, eh=8, ew=16),      # a single lobe
 ])
 def test_shapes_vs_oracle(sgr, shape):
     from oracle import sg_oracle as O
