@@ -75,6 +75,14 @@ def oracle_with_noise(O, inp, cts, eh, ew, wrt, device, b=None, fov=57.0, F0=0.0
     return r64, r32, e32
 
 
+def scalar_close(got, ref, e_ref=0.0, rtol=1e-5):
+    """Reported loss VALUES (renderErr, reconstErr, the objective): ``|got - ref| <= max(2 e_ref, rtol |ref|)`` -- relative, so
+    that a render error of 0.05 is held as tightly as one of 5 (an absolute 1e-4 below 1 would be 2e-3 relative there).
+    ``e_ref`` = ``|ref32 - ref64|``, the reference's (or the fp32 oracle's) own error on that value, where the test has both."""
+    got, ref = float(got), float(ref)
+    return abs(got - ref) <= max(2.0 * abs(float(e_ref)), rtol * abs(ref))
+
+
 def tol2(e_ref, floor=1e-4):
     """BASELINE.md section 3 / north_star: no worse than twice the reference's own fp32 error, floored at the 1e-4 the
     contract names."""

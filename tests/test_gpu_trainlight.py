@@ -30,5 +30,5 @@ def test_synthetic_trainlight_loop_descends_and_matches_oracle(fused, hip_heads)
     env, d, s = O.render_from_sg(cpu["albedo"], cpu["normal"], cpu["rough"], axis, lam, w)
     rerr, _, _, _ = O.render_loss(d, s, cpu["im"], cpu["seg"], R, C)
     cerr, _, _, _ = O.recon_loss(env, cpu["env_gt"], cpu["seg"], cpu["env_ind"], R, C)
-    assert abs(hist[0][1] - rerr.item()) < 2e-4 * max(1.0, rerr.item()), (hist[0][1], rerr.item())
-    assert abs(hist[0][2] - cerr.item()) < 2e-4 * max(1.0, cerr.item()), (hist[0][2], cerr.item())
+    assert abs(hist[0][1] - rerr.item()) < 5e-5 * rerr.item(), (hist[0][1], rerr.item())      # relative: the fp32 example vs the fp64 oracle (measured ~1e-6)
+    assert abs(hist[0][2] - cerr.item()) < 5e-5 * cerr.item(), (hist[0][2], cerr.item())

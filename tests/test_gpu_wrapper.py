@@ -74,7 +74,7 @@ def _check(name, what, got, ref32, ref64, sub=None):
 
 def _scalar_ok(got, ref32, ref64):
     e_ref = abs(ref32 - ref64)
-    return abs(got - ref32) <= TOL * max(1.0, abs(ref32)) and abs(got - ref64) <= max(2.0 * e_ref, 1e-5 * max(1.0, abs(ref64)))
+    return abs(got - ref32) <= max(2.0 * e_ref, TOL * abs(ref32)) and abs(got - ref64) <= max(2.0 * e_ref, 1e-5 * abs(ref64))
 
 
 @pytest.mark.parametrize("name", CASES)
