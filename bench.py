@@ -443,8 +443,12 @@ def eager_gpu_baseline(O, dev, imH, imW, R, C, K, eh, ew) -> dict:
 
 
 def cpu_baseline(O, imH, imW, R, C, K, eh, ew) -> dict:
-    """The fp32 CPU port (oracle/sg_oracle.py) of the same step, timed on this box's host cores on a
-    bounded sample: ONE image of the workload (1/16 of a step), forward + backward (SG grads)."""
+    """The reference's CPU path for the same step, timed on this box's host cores on a bounded sample: ONE image of the
+    workload (1/16 of a step), forward + backward (SG grads), fp32.  Where the reference checkout is mounted (the authoring
+    container) that is the UNMODIFIED models.output2env.output2env + models.renderingLayer.forwardEnv (kind "reference");
+    on the GPU box, where it is not, the torch port in the reference's OWN tensor formulation -- whole-image broadcast
+    temporaries, oracle.render_from_sg_broadcast (kind "port"; profiles/cpu_calibration.json: 0.95x the reference's speed
+    on the same cores; the bounded-memory per-lobe formulation the parity tests use is 1.5x slower and is not timed here)."""
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -461,8 +465,22 @@ def cpu_baseline(O, imH, imW, R, C, K, eh, ew) -> dict:
     ct_d = torch.randn((1, 3, R, C), generator=g)
     ct_s = torch.randn((1, 3, R, C), generator=g)
 
+    kind, what = "port", "torch fp32 CPU port of the reference algorithm in its broadcast formulation (oracle.render_from_sg_broadcast)"
+    ref_layers = None
+    try:
+        from oracle import ref_import as RI
+        if RI.available():
+            ref_layers = RI.make_layers(K, R, C, eh, ew)
+            kind, what = "reference", "the UNMODIFIED reference (models.output2env.output2env + models.renderingLayer.forwardEnv, imported from the mounted checkout)"
+    except Exception:
+        ref_layers = None
+
     def one():
-        env, d, s = O.render_from_sg(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], eh, ew)
+        if ref_layers is not None:
+            env, _, _, _ = ref_layers[0].output2env(x["axis"], x["lamb"], x["weight"])
+            d, s = ref_layers[1].forwardEnv(x["albedo"], x["normal"], x["rough"], env)
+        else:
+            env, d, s = O.render_from_sg_broadcast(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], eh, ew)
         torch.autograd.grad([env, d, s], [x["axis"], x["lamb"], x["weight"]], grad_outputs=[ct_env, ct_d, ct_s])
 
     t0 = time.perf_counter()
@@ -483,9 +501,8 @@ def cpu_baseline(O, imH, imW, R, C, K, eh, ew) -> dict:
                 break
     except OSError:
         pass
-    return {"value": round(imH * imW / best / 1e6, 4), "unit": "Mpix/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 image (1/16 of a step) of the same workload, fwd+bwd (SG grads), torch fp32 CPU port of the "
-                      f"reference algorithm (oracle/sg_oracle.py), best of {len(times)}; {best:.3f} s per image",
+    return {"value": round(imH * imW / best / 1e6, 4), "unit": "Mpix/s", "cores": torch.get_num_threads(), "kind": kind,
+            "sample": f"1 image (1/16 of a step) of the same workload, fwd+bwd (SG grads), {what}, best of {len(times)}; {best:.3f} s per image",
             "cpu": model}
 
 

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SGR_ABI_VERSION 3
+#define SGR_ABI_VERSION 4
 #define SGR_MAX_LOBES 32
 
 #define SGR_OK 0
@@ -182,10 +182,12 @@ int sgr_render_loss_bwd(const float* g_num, const float* diffuse, const float* s
  *   sgr_loss_finalize:  *loss = parts[0] / max(parts[1], 1e-5) / divisor  (renderErr, wrapperBRDFLight.py:192,205-207:
  *                       divisor 3; reconstErr, :179-188: divisor 3 * envHeight * envWidth),  *scale = d loss / d parts[0]
  *                       (two separate device scalars: one is returned to the caller, the other kept for the backward pass);
- *   sgr_render_loss_bwd_scaled:  sgr_render_loss_bwd with *g_num = *g_loss * *g_scale (g_scale = scale; NULL = 1). */
+ *   sgr_render_loss_bwd_scaled:  sgr_render_loss_bwd with *g_num = *g_loss * weight * *g_scale (g_scale = scale; a NULL device
+ *                       scalar = 1; `weight` is a host float: the render weight of trainLight.py:237 travels as a kernel argument,
+ *                       not through a cached device tensor -- ABI 4). */
 int sgr_loss_finalize(const float* parts /* [2], rank-summed */, float* loss /* [1] */, float* scale /* [1] */, float divisor, void* stream);
 
-int sgr_render_loss_bwd_scaled(const float* g_loss, const float* g_scale /* nullable */, const float* diffuse, const float* spec,
+int sgr_render_loss_bwd_scaled(const float* g_loss /* nullable */, float weight, const float* g_scale /* nullable */, const float* diffuse, const float* spec,
                                const float* im_small, const float* seg_small, const float* coef,
                                float* g_diffuse, float* g_spec, int bn, int R, int C, void* stream);
 
@@ -270,12 +272,15 @@ int sgr_fused_fwd_recon_seg(const float* albedo, const float* normal, const floa
  *   reconstErr = num / max(den, 1e-5) / 3 / (eh*ew),  num = sum mask (log(coef env + offset) - log(env_gt + offset))^2,
  * w.r.t. the SG parameters, with env recomputed in registers.  den = *den_global when given (the mask sum
  * all-reduced over ranks) else this shard's own.  Also returns parts = (num, local sum mask): the loss value
- * comes out of the same pass.  g_axis [bn,K,3,R,C]  g_lamb [bn,K,R,C]  g_weight [bn,3K,R,C]. */
+ * comes out of the same pass.  g_axis [bn,K,3,R,C]  g_lamb [bn,K,R,C]  g_weight [bn,3K,R,C].
+ * ABI 4: the three gradient outputs may be NULL together (g_diffuse / g_spec are then ignored and may be NULL too): the pass
+ * skips its gradient half -- no shading frame, no cotangents, no accumulators -- and only returns parts: the loss value for
+ * forward-only callers of the objective (evaluation loops under torch.no_grad(), testLight.py). */
 int sgr_fused_bwd_recon(const float* albedo, const float* normal, const float* rough, const float* axis,
                         const float* lamb, const float* weight, const float* dirs, const float* view,
                         const float* env_gt, const float* mask, const float* coef, const float* den_global,
-                        const float* g_diffuse, const float* g_spec,
-                        float* g_axis, float* g_lamb, float* g_weight, float* parts, float* workspace,
+                        const float* g_diffuse /* nullable with the gradients */, const float* g_spec,
+                        float* g_axis /* nullable trio */, float* g_lamb, float* g_weight, float* parts, float* workspace,
                         int bn, int K, int R, int C, int eh, int ew, int imH, int imW, float F0, int premap,
                         float offset, float rec_weight, void* stream);
 

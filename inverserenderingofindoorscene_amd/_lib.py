@@ -1,7 +1,9 @@
 """ctypes binding of ``libsgrender.so`` (the C ABI declared in ``include/sgrender.h``).
 
-The shared library is the product; this module only finds it, declares the
-argument types and turns non-zero return codes into Python exceptions.  There
+The shared library is the product.  Since round 4 the package's operators reach it through the C++ torch extension
+(``csrc/sgr_torch.cpp``); this module is the binding INTEGRATION.md shows a maintainer -- it finds the library, declares the
+argument types and turns non-zero return codes into Python exceptions -- and what the ABI tests (``tests/test_abi.py``,
+raw C-ABI calls in the GPU tests) and the host-side queries (``sgr_fused_recon_supported`` ...) go through.  There
 is deliberately no fallback: if the library is missing, every entry point of
 the package raises ``SgrenderUnavailable`` (build it with
 ``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C
@@ -16,7 +18,7 @@ from ctypes import c_char_p, c_float, c_int, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SGR_LIB", os.path.join(_HERE, "libsgrender.so"))
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class SgrenderUnavailable(RuntimeError):
@@ -54,7 +56,7 @@ SIGNATURES = {
     "sgr_render_loss_bwd": ([_P] * 8 + [_I] * 3 + [_P], c_int),
     "sgr_loss_finalize": ([_P, _P, _P, _F, _P], c_int),
     "sgr_objective_finalize": ([_P, _P, _F, _F, _F, _P, _P, _P], c_int),
-    "sgr_render_loss_bwd_scaled": ([_P] * 9 + [_I] * 3 + [_P], c_int),
+    "sgr_render_loss_bwd_scaled": ([_P, _F] + [_P] * 8 + [_I] * 3 + [_P], c_int),
     "sgr_lsregress_coef": ([_P] * 4 + [_I, ctypes.c_longlong, _P], c_int),
     "sgr_lsregress_diffspec_coef": ([_P] * 5 + [_I, _I, _P], c_int),
     "sgr_sg_shading": ([_P] * 5 + [_I] * 7 + [_P], c_int),

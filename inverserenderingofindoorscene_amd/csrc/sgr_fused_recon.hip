@@ -43,6 +43,26 @@ namespace sgr {
 // of the azimuth pair -- sign 1 - half, azimuth component 1 - sub -- evaluates loss, reconstruction and render cotangent for
 // it (scalar: the transcendental count per pixel is what it was), and the four cotangents travel back the same way:
 // 6 + 3 swaps for the reduce-scatter, 3 + 6 for the all-gather.
+// Register relief for the gradient form (round 4; each A/B-ed on one box):
+//   SGR_RECON_LDS_E   1: the 24 kept exponentials of an azimuth pair wait in LDS between the radiance half and the gradient half of the
+//                     loop body (6 KB per wave next to the 12 KB ground-truth ring: 18 KB, eight waves per CU still fit) instead of in
+//                     registers -- six ds_write_b128 + six ds_read_b128 per azimuth pair on a pipe the kernel otherwise leaves idle
+//   SGR_RECON_KEEP_U  1: u_k = lp (ax ca + ay sa) of the pair is kept from the radiance half (12 registers) instead of re-formed in the
+//                     gradient half (12 packed instructions per azimuth pair)
+//   SGR_RECON_BPERM   1 (two lane groups): the halves trade their partial radiance and the cotangents with ds_bpermute_b32 -- the LDS
+//                     crossbar, which this kernel otherwise leaves idle -- instead of v_permlane32_swap, a VALU instruction that costs
+//                     the issue time of a transcendental (12 per azimuth pair: ~7 % of the loop's issue cycles).  Made select-free by
+//                     giving each half-wave the SIGN of the half row it owns: lanes of the upper half evaluate (+s_e, -s_e), lanes of the
+//                     lower half (-s_e, +s_e), so "own row" / "other row" are the same registers in every lane
+#ifndef SGR_RECON_LDS_E
+#define SGR_RECON_LDS_E 0
+#endif
+#ifndef SGR_RECON_BPERM
+#define SGR_RECON_BPERM 0
+#endif
+#ifndef SGR_RECON_KEEP_U
+#define SGR_RECON_KEEP_U 0
+#endif
 #ifndef SGR_RECON_FENCES
 #define SGR_RECON_FENCES 1      // loop-body register fences of sg_bwd_recon_pk_kernel: 1 = lobes + row constants (default), 2 = also the BRDF / cotangent constants (round 2: 36 more bytes of scratch, +1 %), 0 = none (op_sel broadcasts get hoisted into register pairs: 543 vs 330 us)
 #endif
@@ -67,12 +87,21 @@ __device__ __forceinline__ void tile16_dma_issue_vrow(float* tile, __amdgpu_buff
 }
 template <> __device__ __forceinline__ void wait_vmcnt<3>() { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
 
-template <int POOL, int EW = 16, int NG = 2, bool HEADS = false>
+// GRADS = false (round 4): the same pass without its gradient half -- the reconstruction-loss VALUE alone, for forward-only callers
+// of the objective (torch.no_grad(): testLight.py-style evaluation): lobes -> exponentials -> radiance of the azimuth pair -> the
+// log-L2 term.  No shading frame, no cotangents, no accumulators, no all-gather; the first 6 (+3) swaps stay.
+template <int POOL, int EW = 16, int NG = 2, bool HEADS = false, bool GRADS = true>
 __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a) {
   constexpr int HALF = 8, NP = 4, KPW = 6, Q = EW / 16, PXW = kWave / NG;       // PXW pixels per wave
   constexpr int kTile = 3 * PXW * 16;                                           // floats per ground-truth virtual-row tile
   __shared__ __attribute__((aligned(16))) float tile[2 * kTile];               // double-buffered
+  constexpr bool LDS_E = SGR_RECON_LDS_E && GRADS;
+  constexpr bool BPERM = SGR_RECON_BPERM && NG == 2;
+  const unsigned partner_addr = ((unsigned)threadIdx.x ^ 32u) * 4u;      // ds_bpermute_b32 source lane: the other half's lane of this pixel
+  auto bperm = [&](float v) { float r; asm volatile("ds_bpermute_b32 %0, %1, %2" : "=v"(r) : "v"(partner_addr), "v"(v) : "memory"); return r; };
+  __shared__ __attribute__((aligned(16))) float estash[LDS_E ? 4 * KPW * kWave : 4];      // [KPW][64 lanes][4]: (ep.x, ep.y, em.x, em.y) of lobe k
   static_assert(NG == 2 || NG == 4, "two or four lane groups per pixel");
+  const unsigned estash_addr = lds_addr(estash) + (unsigned)threadIdx.x * 16u;
 
   const int lane = threadIdx.x, half = lane >> 5, sub = (lane >> 4) & 1, pl = lane & (PXW - 1);
   const int grp = NG == 2 ? half : (lane >> 4);       // this lane's group of six lobes
@@ -98,13 +127,16 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
   };
   issue(tile, 0);
 
-  float alb[3];
-  const Frame f = load_frame<POOL>(a, x, alb);
-  PixLocal q = make_local(f, a.F0);
-  OrthoPix oq = make_ortho_pix(q);
-  const bool ortho = __all(frame_is_orthonormal(q));
-  f32x2 gds[3];                                     // (gD_c A_c / pi, gS_c)
-  {
+  PixLocal q{};
+  OrthoPix oq{};
+  bool ortho = true;
+  f32x2 gds[3] = {splat2(0.f), splat2(0.f), splat2(0.f)};      // (gD_c A_c / pi, gS_c)
+  if constexpr (GRADS) {
+    float alb[3];
+    const Frame f = load_frame<POOL>(a, x, alb);
+    q = make_local(f, a.F0);
+    oq = make_ortho_pix(q);
+    ortho = __all(frame_is_orthonormal(q));
     const size_t o = (size_t)b * 3 * RC;
     const unsigned up = (unsigned)p;
 #pragma unroll
@@ -123,7 +155,9 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
     den = (float)sden;
   }
   const float rec_scale = a.rec_w3j / fmaxf(den, 1e-5f);
-  f32x2 grec = splat2(2.0f * m * rec_scale * cf * kLn2);     // times dl (in log2 units) / x
+  // times dl (in log2 units) / x.  Negated: the loop evaluates log2((gt + off) / x) = -dl as it comes out of v_log_f32 -- the loss term
+  // is its square, and the sign rides in this factor instead of six v_xor per azimuth pair
+  f32x2 grec = splat2(-2.0f * m * rec_scale * cf * kLn2);
   f32x2 lossp = splat2(0.0f);
 
   LobesPk<KPW> P;      // axes pre-multiplied by lp = lam * log2e (floored), as in sg_bwd_pk_kernel
@@ -147,13 +181,13 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
       } else {
         wait_vmcnt<0>();
       }
-      if (!ORTHO) fence_row_invariants(q);
+      if (GRADS && !ORTHO) fence_row_invariants(q);
       const f32x8 row = rows[e];
       const float sr = row[0], cr = row[1];
       f32x2 czr[KPW / 2];
 #pragma unroll
       for (int mm = 0; mm < KPW / 2; ++mm) czr[mm] = pfma(P.azp[mm], splat2(cr), -P.lpp[mm]);      // lp (az c_e - 1)
-      const RowCtx rc = make_row_ctx(q, row, true);
+      const RowCtx rc = make_row_ctx(q, row, GRADS);
       OrthoRow orow = make_ortho_row(rc.ro);
 
 #pragma unroll 1
@@ -173,9 +207,13 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
 #endif
         const f32x4 cs = cpt[aoff + ap];
         const f32x2 ca = {cs[0], cs[1]}, sa = {cs[2], cs[3]};
-        const f32x2 srv = splat2(sr);
+        // BPERM: +srv is the half row this lane OWNS (ep / v[0] / g[0]), -srv the other half's (em / v[1] / g[1])
+        const f32x2 srv = splat2(BPERM && own ? -sr : sr);
         // ---- 1. this group's lobes: exponentials and partial radiance of the 4 directions -----------------
         f32x2 ep[KPW], em[KPW];
+#if SGR_RECON_KEEP_U
+        f32x2 uk[KPW];
+#endif
         f32x2 v[2][3];        // [half row][colour], the azimuth pair
 #pragma unroll
         for (int sg = 0; sg < 2; ++sg)
@@ -188,45 +226,76 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
           const f32x2 xp = pfma(srv, u, cz), xm = pfma(-srv, u, cz);      // lp t
           ep[k] = f32x2{fexp2(xp.x), fexp2(xp.y)};
           em[k] = f32x2{fexp2(xm.x), fexp2(xm.y)};
+#if SGR_RECON_KEEP_U
+          uk[k] = u;
+#endif
+          if constexpr (LDS_E) {      // inline asm: a ds access the compiler can see makes it drain the LDS-DMA in flight (vmcnt(0)) first
+            const f32x4 e4 = {ep[k].x, ep[k].y, em[k].x, em[k].y};
+            asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(estash_addr), "v"(e4), "n"(k * kWave * 16) : "memory");
+          }
           v[0][0] = pfma(SGR_LO(P.w01[k]), ep[k], v[0][0]); v[0][1] = pfma(SGR_HI(P.w01[k]), ep[k], v[0][1]); v[0][2] = pfma(w2, ep[k], v[0][2]);
           v[1][0] = pfma(SGR_LO(P.w01[k]), em[k], v[1][0]); v[1][1] = pfma(SGR_HI(P.w01[k]), em[k], v[1][1]); v[1][2] = pfma(w2, em[k], v[1][2]);
         }
         // ---- 2. full radiance of the half row this half-wave owns (lanes 0..31: half row 1, 32..63: half row 0)
         f32x2 tot[3];
+        if constexpr (BPERM) {
+          f32x2 rv[3];      // the partner's partial for the half row THIS lane owns
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          float dx = v[1][c].x, sx = v[0][c].x, dy = v[1][c].y, sy = v[0][c].y;
-          swap32(dx, sx);
-          swap32(dy, sy);
-          tot[c] = f32x2{dx + sx, dy + sy};
+          for (int c = 0; c < 3; ++c) rv[c] = f32x2{bperm(v[1][c].x), bperm(v[1][c].y)};
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) tot[c] = v[0][c] + rv[c];
+        } else {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            float dx = v[1][c].x, sx = v[0][c].x, dy = v[1][c].y, sy = v[0][c].y;
+            swap32(dx, sx);
+            swap32(dy, sy);
+            tot[c] = f32x2{dx + sx, dy + sy};
+          }
         }
         f32x2 g[2][3];
         if constexpr (NG == 2) {
           // ---- 3. its cotangent: reconstruction term (and loss) + render term --------------------------------
           float gt[3][2];
           tile32_read_pair(cur, pl, own * HALF + ap * 2, gt);
-          const f32x2 Pv = pfma(SGR_HI(oq.vB), sa, SGR_LO(oq.vB) * ca);
-          f32x2 wt, sp;
-          shade_pair<ORTHO>(q, oq, rc, orow, own, ca, sa, Pv, xt, (aoff + ap) * 2, wt, sp);
+          f32x2 wt = splat2(0.f), sp = splat2(0.f);
+          if constexpr (GRADS) {
+            const f32x2 Pv = pfma(SGR_HI(oq.vB), sa, SGR_LO(oq.vB) * ca);
+            shade_pair<ORTHO>(q, oq, rc, orow, own, ca, sa, Pv, xt, (aoff + ap) * 2, wt, sp);
+          }
           f32x2 go[3];
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
             const f32x2 xx = pfma(splat2(cf), tot[c], splat2(off));
             const f32x2 r = {__builtin_amdgcn_rcpf(xx.x), __builtin_amdgcn_rcpf(xx.y)};
             const f32x2 ar = (f32x2{gt[c][0], gt[c][1]} + splat2(off)) * r;
-            const f32x2 dl = {-__builtin_amdgcn_logf(ar.x), -__builtin_amdgcn_logf(ar.y)};   // log2(x / (gt + off))
+            const f32x2 dl = {__builtin_amdgcn_logf(ar.x), __builtin_amdgcn_logf(ar.y)};   // -log2(x / (gt + off)); see grec
             lossp = pfma(dl, dl, lossp);
-            const f32x2 gr = pfma(SGR_HI(gds[c]), sp, SGR_LO(gds[c]));
-            go[c] = pfma(grec * dl, r, wt * gr);
+            if constexpr (GRADS) {
+              const f32x2 gr = pfma(SGR_HI(gds[c]), sp, SGR_LO(gds[c]));
+              go[c] = pfma(grec * dl, r, wt * gr);
+            }
           }
           // ---- 4. both half rows' cotangents to all lanes --------------------------------------------------------
+          if constexpr (GRADS && BPERM) {
 #pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            float dx = go[c].x, sx = go[c].x, dy = go[c].y, sy = go[c].y;
-            swap32(dx, sx);
-            swap32(dy, sy);
-            g[1][c] = f32x2{dx, dy};     // from lanes 0..31
-            g[0][c] = f32x2{sx, sy};     // from lanes 32..63
+            for (int c = 0; c < 3; ++c) {
+              g[0][c] = go[c];                                       // the half row this lane owns
+              g[1][c] = f32x2{bperm(go[c].x), bperm(go[c].y)};       // the partner's
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+          } else if constexpr (GRADS) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              float dx = go[c].x, sx = go[c].x, dy = go[c].y, sy = go[c].y;
+              swap32(dx, sx);
+              swap32(dy, sy);
+              g[1][c] = f32x2{dx, dy};     // from lanes 0..31
+              g[0][c] = f32x2{sx, sy};     // from lanes 32..63
+            }
           }
         } else {
           // ---- 2b. second stage of the reduce-scatter: rows of 16 lanes.  swap16(D = y totals, S = x totals); D + S leaves
@@ -248,36 +317,52 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
           const float ca1 = oaz ? ca.y : ca.x, sa1 = oaz ? sa.y : sa.x;
-          float wt1, sp1;
-          shade_dir<ORTHO>(q, rc, own, ca1, sa1, xt, (aoff + ap) * 2 + oaz, wt1, sp1);
+          float wt1 = 0.f, sp1 = 0.f;
+          if constexpr (GRADS) shade_dir<ORTHO>(q, rc, own, ca1, sa1, xt, (aoff + ap) * 2 + oaz, wt1, sp1);
           float go1[3];
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
             const float xx = fmaf(cf, t1[c], off);
             const float r = __builtin_amdgcn_rcpf(xx);
-            const float dl = -__builtin_amdgcn_logf((gt[c] + off) * r);
+            const float dl = __builtin_amdgcn_logf((gt[c] + off) * r);      // -log2(x / (gt + off)); see grec
             lossp.x = fmaf(dl, dl, lossp.x);
-            go1[c] = fmaf(grec.x * dl, r, wt1 * fmaf(gds[c].y, sp1, gds[c].x));
+            if constexpr (GRADS) go1[c] = fmaf(grec.x * dl, r, wt1 * fmaf(gds[c].y, sp1, gds[c].x));
           }
           // ---- 4. all-gather: rows first (swap16(D = go, S = go): D = the even row's value = azimuth y, S = the odd row's =
           // azimuth x, in both rows of the half), then the halves
+          if constexpr (GRADS) {
 #pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            float d_ = go1[c], s_ = go1[c];
-            swap16(d_, s_);
-            float dx = s_, sx = s_, dy = d_, sy = d_;
-            swap32(dx, sx);
-            swap32(dy, sy);
-            g[1][c] = f32x2{dx, dy};     // from lanes 0..31
-            g[0][c] = f32x2{sx, sy};     // from lanes 32..63
+            for (int c = 0; c < 3; ++c) {
+              float d_ = go1[c], s_ = go1[c];
+              swap16(d_, s_);
+              float dx = s_, sx = s_, dy = d_, sy = d_;
+              swap32(dx, sx);
+              swap32(dy, sy);
+              g[1][c] = f32x2{dx, dy};     // from lanes 0..31
+              g[0][c] = f32x2{sx, sy};     // from lanes 32..63
+            }
           }
         }
         // ---- 5. this group's lobes: gradient accumulation (sg_bwd_pk_kernel's inner loop with the kept exponentials)
         const f32x2 sca = srv * ca, ssa = srv * sa;
+        if constexpr (GRADS) {
+        if constexpr (LDS_E) {      // the kept exponentials come back: six ds_read_b128, one wait
+          f32x4 e4[KPW];
+#pragma unroll
+          for (int k = 0; k < KPW; ++k) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(e4[k]) : "v"(estash_addr), "n"(k * kWave * 16) : "memory");
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int k = 0; k < KPW; ++k) { ep[k] = f32x2{e4[k][0], e4[k][1]}; em[k] = f32x2{e4[k][2], e4[k][3]}; }
+        }
 #pragma unroll
         for (int k = 0; k < KPW; ++k) {
           const f32x2 cz = half_of(czr[k / 2], k & 1), w2 = half_of(P.w2p[k / 2], k & 1);
+#if SGR_RECON_KEEP_U
+          const f32x2 u = uk[k];
+#else
           const f32x2 u = pfma(SGR_HI(P.axy[k]), sa, SGR_LO(P.axy[k]) * ca);
+#endif
           const f32x2 tp = pfma(srv, u, cz), tm = pfma(-srv, u, cz);      // lp t: gl accumulates lp sum T t
           gw0[k] = pfma(g[0][0], ep[k], gw0[k]); gw1[k] = pfma(g[0][1], ep[k], gw1[k]); gw2[k] = pfma(g[0][2], ep[k], gw2[k]);
           gw0[k] = pfma(g[1][0], em[k], gw0[k]); gw1[k] = pfma(g[1][1], em[k], gw1[k]); gw2[k] = pfma(g[1][2], em[k], gw2[k]);
@@ -289,6 +374,7 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
           gz[k] = pfma(splat2(cr), Ts, gz[k]);
           gx[k] = pfma(sca, Td, gx[k]);
           gy[k] = pfma(ssa, Td, gy[k]);
+        }
         }
       }
     }
@@ -303,7 +389,7 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
     if (lane == 0) a.ws[blockIdx.x] = r0;
   }
 
-  if (x.active) {
+  if (GRADS && x.active) {
     // wave-uniform plane base of lobe slot k + the lane's 32-bit byte offset (see load_lobes_pk)
     const unsigned o3_own = ((unsigned)(grp * KPW * 3 * RC) + (unsigned)p) * 4u, o1_own = ((unsigned)(grp * KPW * RC) + (unsigned)p) * 4u;
     char* g_axis_b = reinterpret_cast<char*>(a.g_axis + (size_t)b * K * 3 * RC);
@@ -503,9 +589,11 @@ static int fused_bwd_recon_impl(const float* albedo, const float* normal, const 
                                float* g_axis, float* g_lamb, float* g_weight, float* parts, float* workspace, int bn, int K, int R,
                                int C, int eh, int ew, int imH, int imW, float F0, int premap, float offset, float rec_weight,
                                ObjectiveTail tail, void* stream) {
-  SGR_REQUIRE(albedo && normal && rough && axis && lamb && weight && dirs && view && env_gt && mask && coef && g_diffuse && g_spec &&
-                  g_axis && g_lamb && g_weight && parts && workspace,
+  const bool grads = g_axis != nullptr;      // all three or none: none = the loss value alone (forward-only callers)
+  SGR_REQUIRE(albedo && normal && rough && axis && lamb && weight && dirs && view && env_gt && mask && coef && parts && workspace,
               "sgr_fused_bwd_recon: NULL tensor");
+  SGR_REQUIRE((g_axis && g_lamb && g_weight && g_diffuse && g_spec) || (!g_axis && !g_lamb && !g_weight),
+              "sgr_fused_bwd_recon: the gradient outputs come all three (with g_diffuse / g_spec) or not at all");
   SGR_REQUIRE(bn > 0 && K > 0 && R > 0 && C > 0 && eh > 0 && ew > 0, "sgr_fused_bwd_recon: non-positive size");
   SGR_REQUIRE(premap >= 0 && premap <= 3, "sgr_fused_bwd_recon: premap must be 0..3");
   SGR_SUPPORTED(premap != 3 || K > 6, "sgr_fused_bwd_recon: premap 3 (decoder heads as a prologue) needs 6 < SGNum <= 24");
@@ -530,7 +618,10 @@ static int fused_bwd_recon_impl(const float* albedo, const float* normal, const 
   {
 #define SGR_LAUNCH_BR(EW_, NG_)                                                                              \
     do {                                                                                                     \
-      if (premap == 3) {                                                                                     \
+      if (!grads) {                                                                                          \
+        if (premap == 3) hipLaunchKernelGGL((sg_bwd_recon_pk_kernel<1, EW_, NG_, true, false>), grid, block, 0, st, a);   \
+        else hipLaunchKernelGGL((sg_bwd_recon_pk_kernel<1, EW_, NG_, false, false>), grid, block, 0, st, a);              \
+      } else if (premap == 3) {                                                                              \
         if (p1) hipLaunchKernelGGL((sg_bwd_recon_pk_kernel<1, EW_, NG_, true>), grid, block, 0, st, a);      \
         else hipLaunchKernelGGL((sg_bwd_recon_pk_kernel<2, EW_, NG_, true>), grid, block, 0, st, a);         \
       } else {                                                                                               \

@@ -18,9 +18,6 @@ constexpr int kSplit = 16;           // blocks per image (passes over data the p
 constexpr int kSplitA = 64;          // blocks per image of the FIRST pass (stage A / diffspec_partial_a): it reads the full-resolution
                                      // image and mask cold from HBM, and a quarter of the blocks left it latency-bound (16.7 us in the
                                      // training loop for 32 MB); = lanes of a wave, see fold_a
-#ifndef SGR_LOSS_FENCE
-#define SGR_LOSS_FENCE 0               // 1: __threadfence() around the ticket of loss_stage_c instead of the write-through store + s_waitcnt
-#endif
 
 template <int N>
 __device__ __forceinline__ void block_reduce(float (&v)[N], float* lds /* [4*N] */) {
@@ -198,18 +195,15 @@ __global__ __launch_bounds__(kLossThreads) void loss_stage_c(const float* __rest
   const int nparts = (int)(gridDim.x * gridDim.y);
   if (threadIdx.x == 0) {
     __hip_atomic_store(&wsC[(size_t)b * kSplit + blockIdx.x], acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#if SGR_LOSS_FENCE
-    __threadfence();
-#else
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the write-through store has reached the coherence point before the ticket is drawn
-#endif
-    last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nparts - 1) ? 1u : 0u;
+    // RELEASE on the ticket: this workgroup's partial is visible at agent scope before its ticket is; the RMWs of the other
+    // workgroups continue the release sequence, so the ACQUIRE fence of the last arrival synchronises with every one of them
+    // (round 3 relied on the write-through store being counted in vmcnt -- true on gfx950, a data race in the memory model)
+    const bool mine = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nparts - 1);
+    if (mine) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    last = mine ? 1u : 0u;
   }
-  __syncthreads();
+  __syncthreads();      // workgroup-scope release / acquire: the other waves of the last workgroup inherit thread 0's view
   if (!last) return;
-#if SGR_LOSS_FENCE
-  __threadfence();
-#endif
   double num = 0.0, den = 0.0;
   for (int i = threadIdx.x; i < nparts; i += kLossThreads) num += (double)__hip_atomic_load(&wsC[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (int i = threadIdx.x; i < (int)gridDim.y * kSplitA; i += kLossThreads) den += (double)wsA[(size_t)i * 6 + 5];      // stage A's: a kernel boundary away
@@ -255,13 +249,13 @@ __global__ void objective_finalize(const float* __restrict__ render_err, const f
 // detached (wrapperBRDFLight.py:197-201; coefIm and the det indicator are detached by the reference itself, models.py:54,76).
 // The reference does not detach coefDiffuse / coefSpecular: call sites that pass live images differentiate through them;
 // that mode runs in torch on the host layer (losses.py: _lsregress_diffspec_live), not through this kernel.
-__global__ __launch_bounds__(kLossThreads) void loss_bwd(const float* __restrict__ g_num /* device scalar */,
+__global__ __launch_bounds__(kLossThreads) void loss_bwd(const float* __restrict__ g_num /* device scalar or NULL */, float weight,
                                                           const float* __restrict__ g_scale /* device scalar or NULL */,
                                                           const float* __restrict__ diffuse, const float* __restrict__ spec,
                                                           const float* __restrict__ im_s, const float* __restrict__ seg_s,
                                                           const float* __restrict__ coef, float* __restrict__ g_diffuse,
                                                           float* __restrict__ g_spec, int RC, size_t total) {
-  const float gn = g_scale ? g_num[0] * g_scale[0] : g_num[0];
+  const float gn = (g_num ? g_num[0] : 1.0f) * weight * (g_scale ? g_scale[0] : 1.0f);
   const int n = 3 * RC;
   for (size_t o = (size_t)blockIdx.x * kLossThreads + threadIdx.x; o < total; o += (size_t)gridDim.x * kLossThreads) {
     const int b = (int)(o / n);
@@ -375,14 +369,14 @@ extern "C" int sgr_render_loss_fwd(const float* diffuse, const float* spec, cons
                                    bn, R, C, imH, imW, stream);
 }
 
-extern "C" int sgr_render_loss_bwd_scaled(const float* g_loss, const float* g_scale, const float* diffuse, const float* spec,
+extern "C" int sgr_render_loss_bwd_scaled(const float* g_loss, float weight, const float* g_scale, const float* diffuse, const float* spec,
                                           const float* im_small, const float* seg_small, const float* coef, float* g_diffuse,
                                           float* g_spec, int bn, int R, int C, void* stream) {
-  SGR_REQUIRE(g_loss && diffuse && spec && im_small && seg_small && coef && g_diffuse && g_spec, "sgr_render_loss_bwd: NULL tensor");
+  SGR_REQUIRE(diffuse && spec && im_small && seg_small && coef && g_diffuse && g_spec, "sgr_render_loss_bwd: NULL tensor");
   SGR_REQUIRE(bn > 0 && R > 0 && C > 0, "sgr_render_loss_bwd: non-positive size");
   const size_t total = (size_t)bn * 3 * R * C;
   const int blocks = (int)((total + kLossThreads * 4 - 1) / (kLossThreads * 4));
-  hipLaunchKernelGGL(loss_bwd, dim3(blocks > 2048 ? 2048 : blocks), dim3(kLossThreads), 0, (hipStream_t)stream, g_loss, g_scale,
+  hipLaunchKernelGGL(loss_bwd, dim3(blocks > 2048 ? 2048 : blocks), dim3(kLossThreads), 0, (hipStream_t)stream, g_loss, weight, g_scale,
                      diffuse, spec, im_small, seg_small, coef, g_diffuse, g_spec, R * C, total);
   return sgr_check((int)hipGetLastError(), "sgr_render_loss_bwd");
 }
@@ -390,7 +384,8 @@ extern "C" int sgr_render_loss_bwd_scaled(const float* g_loss, const float* g_sc
 extern "C" int sgr_render_loss_bwd(const float* g_num, const float* diffuse, const float* spec, const float* im_small,
                                    const float* seg_small, const float* coef, float* g_diffuse, float* g_spec, int bn,
                                    int R, int C, void* stream) {
-  return sgr_render_loss_bwd_scaled(g_num, nullptr, diffuse, spec, im_small, seg_small, coef, g_diffuse, g_spec, bn, R, C, stream);
+  SGR_REQUIRE(g_num, "sgr_render_loss_bwd: NULL cotangent");
+  return sgr_render_loss_bwd_scaled(g_num, 1.0f, nullptr, diffuse, spec, im_small, seg_small, coef, g_diffuse, g_spec, bn, R, C, stream);
 }
 
 extern "C" int sgr_loss_finalize(const float* parts, float* loss, float* scale, float divisor, void* stream) {

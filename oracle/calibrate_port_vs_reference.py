@@ -1,4 +1,4 @@
-"""How fast is the CPU port (oracle/sg_oracle.py, what bench.py's ``cpu_baseline`` times on the GPU box) against the
+"""How fast is the CPU port (oracle/sg_oracle.py; its broadcast formulation ``render_from_sg_broadcast`` is what bench.py's ``cpu_baseline`` times on the GPU box) against the
 UNMODIFIED reference on the same cores?  TEST INFRASTRUCTURE ONLY, authoring container (the reference is not on the GPU box):
 
     python -m oracle.calibrate_port_vs_reference      # writes profiles/cpu_calibration.json
@@ -55,7 +55,11 @@ def main():
         env, d, s = O.render_from_sg(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], eh, ew)
         torch.autograd.grad([env, d, s], [x["axis"], x["lamb"], x["weight"]], grad_outputs=cts)
 
-    t_ref, t_port = best_of(reference), best_of(port)
+    def port_broadcast():      # the reference's own tensor formulation (whole-image broadcast temporaries): what bench.py's cpu_baseline times
+        env, d, s = O.render_from_sg_broadcast(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], eh, ew)
+        torch.autograd.grad([env, d, s], [x["axis"], x["lamb"], x["weight"]], grad_outputs=cts)
+
+    t_ref, t_port, t_bc = best_of(reference), best_of(port), best_of(port_broadcast)
     model = "unknown"
     for line in open("/proc/cpuinfo"):
         if line.startswith("model name"):
@@ -65,7 +69,10 @@ def main():
            "sample": "1 image of BASELINE configs[1] (240x320 -> 120x160, SGNum 12, 8x16), fwd + bwd (SG grads), fp32, best of 3",
            "reference_seconds": round(t_ref, 3), "port_seconds": round(t_port, 3),
            "reference_Mpix_per_s": round(imH * imW / t_ref / 1e6, 4), "port_Mpix_per_s": round(imH * imW / t_port / 1e6, 4),
-           "port_over_reference_speed": round(t_ref / t_port, 3)}
+           "port_over_reference_speed": round(t_ref / t_port, 3),
+           "broadcast_port_seconds": round(t_bc, 3), "broadcast_port_Mpix_per_s": round(imH * imW / t_bc / 1e6, 4),
+           "broadcast_port_over_reference_speed": round(t_ref / t_bc, 3),
+           "note": "bench.py's cpu_baseline times the BROADCAST port (kind 'port'), or the unmodified reference itself where it is mounted (kind 'reference')"}
     path = os.path.join(ROOT, "profiles", "cpu_calibration.json")
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out))

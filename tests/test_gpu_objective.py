@@ -281,3 +281,47 @@ def test_light_objective_from_decoder_outputs_full_size(sgr):
     assert scalar_close(o1[1].item(), o3[1].item(), 0.0, 2e-5) and scalar_close(o1[2].item(), o3[2].item(), 0.0, 2e-5)
     for name, ga, gb in zip(("x_axis", "x_lamb", "x_weight"), g1, g3):
         assert rel_l2(ga, gb) < 1e-4, (name, rel_l2(ga, gb))
+
+
+def test_forward_only_objective_launches_no_gradient_kernel(sgr):
+    """``light_objective`` under ``torch.no_grad()`` (the evaluation loops: testLight.py drives wrapperBRDFLight.py:167-207 without a
+    backward) and with no grad-requiring SG input: the same five values as the grad-mode call, bit for bit for the render terms and to
+    fp32 summation noise for the reconstruction term, from a pass that launches neither the objective's gradient kernel nor the
+    render-loss backward (the kernel names of the two calls are read back from the profiler)."""
+    from oracle import sg_oracle as O
+    from torch.profiler import ProfilerActivity, profile
+    bn, imH, imW, R, C, K = 2, 24, 32, 12, 16, 12
+    inp = O.synthetic_inputs(bn, imH, imW, R, C, K, seed=91)
+    dev = {k: v.cuda() for k, v in inp.items()}
+    ind = torch.ones(bn, 1, 1, 1, device="cuda")
+    layer = sgr.renderingLayer(imWidth=C, imHeight=R)
+
+    def call(grad):
+        x = [dev[k].clone().requires_grad_(grad) for k in ("axis", "lamb", "weight")]
+        return sgr.light_objective(layer, dev["albedo"], dev["normal"], dev["rough"], x[0], x[1], x[2], dev["im"], dev["seg"], dev["env_gt"], ind, 1.0, 10.0)
+
+    def kernels(fn):
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            out = fn()
+            torch.cuda.synchronize()
+        return out, [e.key for e in prof.key_averages() if "sgr::" in e.key]
+
+    ref = call(True)
+    assert ref[0].requires_grad
+    call(False)      # warm-up of the loss-only kernel
+    (o_ng, names_ng) = kernels(lambda: call(False))
+    with torch.no_grad():
+        (o_ng2, names_ng2) = kernels(lambda: call(True))
+    (o_g, names_g) = kernels(lambda: call(True))
+    for o in (o_ng, o_ng2):
+        assert not o[0].requires_grad and o[0].grad_fn is None
+        assert torch.equal(o[1], ref[1]) and torch.equal(o[3], ref[3]) and torch.equal(o[4], ref[4])      # render terms: the same kernels
+        assert scalar_close(o[2].item(), ref[2].item(), 0.0, 2e-6) and scalar_close(o[0].item(), ref[0].item(), 0.0, 2e-6)
+    if names_g:      # the profiler reports device kernels on this box
+        grad_kernel = [n for n in names_g if "sg_bwd_recon_pk_kernel" in n]
+        assert grad_kernel and any("loss_bwd" in n for n in names_g), names_g
+        for names in (names_ng, names_ng2):
+            assert names, "no device kernels recorded for the forward-only call"
+            assert not any("loss_bwd" in n for n in names), names
+            lossonly = [n for n in names if "sg_bwd_recon_pk_kernel" in n]
+            assert lossonly and all(n not in grad_kernel for n in lossonly), (lossonly, grad_kernel)      # the GRADS = false instantiation

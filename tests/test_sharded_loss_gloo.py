@@ -43,10 +43,16 @@ def _worker(rank, world, port, out):
     _, _, num, den = O.render_loss(d_l, s_l, inp["im"][sl], inp["seg"][sl], R, C)
     loss = combine_loss_parts(num, den, group=None)
     loss.backward()
-    # the fused light objective's collectives (mask sums before its backward pass, numerators after it)
-    from inverserenderingofindoorscene_amd.losses import _global_pair
-    a, b, sharded = _global_pair(torch.tensor(1.0 + rank, dtype=torch.float64), torch.tensor(10.0 * (rank + 1), dtype=torch.float64), None)
-    out[rank] = (loss.item(), d_l.grad.clone(), s_l.grad.clone(), (a.item(), b.item(), sharded))
+    # the fused light objective's two collectives as losses.light_objective issues them: the stage-1 vector [num_r, den_r, 0, den_e]
+    # all-reduced in place before the backward pass, then the reconstruction numerator -- a one-element VIEW of stage 2's pair --
+    # in place after it (the pair's second element, this shard's own mask sum, must stay untouched)
+    from inverserenderingofindoorscene_amd.losses import _sharded
+    sums = torch.tensor([1.0 + rank, 10.0 * (rank + 1), 0.0, 5.0])
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=None)
+    parts_b = torch.tensor([rank + 1.0, 99.0])
+    num_e = parts_b[0:1]
+    dist.all_reduce(num_e, op=dist.ReduceOp.SUM, group=None)
+    out[rank] = (loss.item(), d_l.grad.clone(), s_l.grad.clone(), (sums.tolist(), parts_b.tolist(), _sharded(None)))
     dist.destroy_process_group()
 
 
@@ -65,7 +71,7 @@ def test_sharded_render_loss_matches_full_batch():
     per = BN // world
     for r in range(world):
         loss_r, gd_r, gs_r, pair = out[r]
-        assert pair == (3.0, 30.0, True)
+        assert pair == ([3.0, 30.0, 0.0, 10.0], [3.0, 99.0], True)
         assert abs(loss_r - err.item()) < 1e-12 * max(1.0, abs(err.item()))
         assert torch.allclose(gd_r, d_f.grad[r * per:(r + 1) * per], rtol=1e-10, atol=1e-14)
         assert torch.allclose(gs_r, s_f.grad[r * per:(r + 1) * per], rtol=1e-10, atol=1e-14)
@@ -112,10 +118,9 @@ def test_ddp_gradients_match_single_process():
             assert torch.allclose(g, p.grad, rtol=1e-9, atol=1e-13)
 
 
-def test_global_pair_single_process_is_identity():
-    from inverserenderingofindoorscene_amd.losses import _global_pair
-    a, b, sharded = _global_pair(torch.tensor(2.0), torch.tensor(5.0), None)
-    assert (a.item(), b.item(), sharded) == (2.0, 5.0, False)
+def test_single_process_is_not_sharded():
+    from inverserenderingofindoorscene_amd.losses import _sharded
+    assert _sharded(None) is False      # no process group: light_objective / render_loss take their one-operator routes
 
 
 def test_combine_single_process_is_plain_ratio():
