@@ -71,6 +71,10 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layer-only", action="store_true", help="skip the informational legs (two streams, HIP graph, light objective, baselines): profiling runs")
     ap.add_argument("--no-env", action="store_true", help="render-only variant (env image never materialised)")
+    ap.add_argument("--pmc-workload", default="layer", choices=("layer", "objective", "objective_heads"),
+                    help="counter-collection runs (tools/pmc_traffic.sh, tools/pmc_sq.sh): 'objective' / 'objective_heads' run ONLY the fused light objective "
+                         "+ its backward (the trainLight step's kernels: fwd_pk*gt* and sg_bwd_recon_pk_kernel; _heads: decoder outputs in, premap 3) "
+                         "for --warmup + --steps iterations and print a short record instead of the contract line")
     ap.add_argument("--config", type=int, default=2, choices=(2, 5),
                     help="BASELINE.json configs index: 2 = headline (default); 5 = 480x640, SGNum 24, 16x32 stress (batch 4)")
     args = ap.parse_args()
@@ -114,6 +118,22 @@ def main() -> None:
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
     group = dist.group.WORLD if world > 1 else None
+
+    if args.pmc_workload != "layer":      # counter-collection workload: the objective's kernels alone
+        heads = args.pmc_workload == "objective_heads"
+        ind1 = torch.ones(bn, 1, 1, 1, device=dev)
+        if heads:
+            gh = torch.Generator().manual_seed(7)
+            sg = [(torch.randn(s, generator=gh) * 0.5).to(dev).requires_grad_(True) for s in ((bn, 3 * K, R, C), (bn, K, R, C), (bn, 3 * K, R, C))]
+        else:
+            sg = [x["axis"], x["lamb"], x["weight"]]
+        for _ in range(args.warmup + args.steps):
+            obj = pkg.light_objective(layer, x["albedo"], x["normal"], x["rough"], sg[0], sg[1], sg[2], x["im"], x["seg"], x["env_gt"], ind1, 1.0, 10.0,
+                                      decoder_outputs=heads)[0]
+            torch.autograd.grad(obj, sg)
+        torch.cuda.synchronize()
+        print(json.dumps({"pmc_workload": args.pmc_workload, "config": args.config, "batch": bn, "iterations": args.warmup + args.steps}), flush=True)
+        return
 
     def step(i=None):
         if i is not None:
@@ -242,28 +262,18 @@ def main() -> None:
         # HBM bytes per launch of the dominant kernel from the PMC passes (tools/pmc_traffic.sh -> tools/parse_pmc.py ->
         # profiles/traffic.json), recorded per WORKLOAD (config, batch, env written or not): a figure measured on another
         # workload is not reported
-        traffic, dom_name = None, ("sg_bwd" if dom[0] == "bwd" else "fwd") + " kernel (no PMC record for this workload)"
         tkey = f"config{args.config}_batch{bn}_{'env' if need_env else 'noenv'}"
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        import re
-        want = ([r"sg_bwd_pk_kernel<", r"sg_bwd_half_kernel<", r"sg_bwd_split_kernel<", r"sg_bwd_fast_kernel<"]
-                if dom[0] == "bwd" else [r"fwd_pk_half_kernel<", r"fwd_pk_kernel<", r"fwd_half_kernel<", r"fwd_fast_kernel<"])
-        if os.path.isfile(tpath):
-            try:
-                recs = json.load(open(tpath)).get(tkey, {})
-                for pat in want:
-                    hits = sorted((n for n in recs if re.search("::" + pat, n)), key=lambda n: -recs[n]["hbm_bytes"])
-                    if hits:
-                        traffic, dom_name = recs[hits[0]]["hbm_bytes"], hits[0].split("::")[-1]
-                        break
-            except Exception:
-                traffic = None
+        want = [r"sg_bwd_pk_kernel<"] if dom[0] == "bwd" else [r"fwd_pk_half_kernel<", r"fwd_pk_kernel<"]
+        traffic, dom_name, traffic_stale = pmc_traffic(tkey, want)
+        if dom_name is None:
+            dom_name = ("sg_bwd" if dom[0] == "bwd" else "fwd") + " kernel (no PMC record for this workload)"
         # the resource that actually binds the fused kernels: VALU issue.  SQ counters of the same workload (tools/pmc_sq.sh ->
         # profiles/sq.json): SQ_ACTIVE_INST_VALU counts, per SIMD quad, the cycles a VALU instruction is in flight; x 4 / SIMDs
-        # against the kernel's duration in shader-clock cycles (GRBM_GUI_ACTIVE / XCDs) is the fraction of issue cycles used
-        valu, limited_by = valu_roofline(tkey, want, dom[1]), "hbm"
-        if valu is not None and valu.get("frac") is not None and valu["frac"] > dom[3] / HBM_PEAK_GBPS:
-            limited_by = "valu_issue"
+        # against the kernel's duration in shader-clock cycles (GRBM_GUI_ACTIVE / XCDs) is the fraction of issue cycles used.
+        # Both records are OFFLINE (counter passes cannot run inside the timed loop) and stamped with the hash of the kernel sources
+        # they were measured on: a record from other sources is reported as stale and does not decide `limited_by`
+        valu = valu_roofline(tkey, want, dom[1])
+        limited_by = limited(valu, dom[3] / HBM_PEAK_GBPS)
         mpix = lambda ms: round(world * img_px / (ms * 1e-3) / 1e6, 1)
         out = {
             "metric": "Mpix/s shaded (fwd+bwd), 240x320x12-SG render layer" if args.config == 2 else "Mpix/s shaded (fwd+bwd), 480x640x24-SG 16x32 render layer (stress config)",
@@ -293,7 +303,7 @@ def main() -> None:
                        "config3": cfg3,
                        "parallelism": f"batch-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(dom[3], 1), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(dom[3] / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "unit": "GB/s", "frac": round(dom[3] / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_record_stale": traffic_stale,
                          "algorithmic_bytes_per_launch": dom[2], "avg_launch_ms": round(dom[1], 4),
                          "limited_by": limited_by},
             "roofline_valu": valu,
@@ -320,29 +330,116 @@ def main() -> None:
         dist.destroy_process_group()
 
 
-def valu_roofline(tkey, patterns, live_ms):
-    """`roofline_valu` from profiles/sq.json[tkey] for the first kernel matching `patterns` (the dominant kernel of the line)."""
-    import re
-    path = os.path.join(ROOT, "profiles", "sq.json")
+def csrc_sha16() -> str:
+    """Hash of the kernel sources the loaded library was built from (same function as tools/parse_sq.py / parse_pmc.py)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "inverserenderingofindoorscene_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.inl")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _records(fname, tkey):
+    path = os.path.join(ROOT, "profiles", fname)
     if not os.path.isfile(path):
-        return None
+        return {}, None
     try:
         recs = json.load(open(path)).get(tkey, {})
-        for pat in patterns:
-            hits = [n for n in recs if re.search("::" + pat, n)]
-            if not hits:
-                continue
-            n = max(hits, key=lambda h: recs[h].get("valu_busy_cycles_per_simd", 0))
-            r = recs[n]
-            busy, total = r["valu_busy_cycles_per_simd"], r["kernel_cycles"]
-            return {"bound": "valu_issue", "kernel": n.split("::")[-1], "achieved": round(busy), "peak": round(total),
-                    "unit": "SIMD issue cycles per launch (SQ_ACTIVE_INST_VALU x 4 / SIMDs vs GRBM_GUI_ACTIVE / XCDs)",
-                    "frac": round(busy / total, 4), "valu_instructions_per_wave": r.get("valu_insts_per_wave"),
-                    "transcendental_share": r.get("trans_share"), "pmc_kernel_ms": r.get("kernel_ms"), "live_kernel_ms": round(live_ms, 4),
-                    "source": "profiles/sq.json (tools/pmc_sq.sh on this workload; counters are per launch, not re-measured live)"}
     except Exception:
-        return None
+        return {}, None
+    stamp = recs.get("_csrc_sha16")
+    stale = None if stamp is None else (stamp != csrc_sha16())      # None: an unstamped record from before round 4
+    return {k: v for k, v in recs.items() if not k.startswith("_")}, stale
+
+
+def pmc_traffic(tkey, patterns):
+    """HBM bytes per launch of the first kernel matching `patterns` from the PMC passes (tools/pmc_traffic.sh -> tools/parse_pmc.py ->
+    profiles/traffic.json), recorded per WORKLOAD: a figure measured on another workload is not reported.  -> (bytes, kernel, stale)"""
+    import re
+    recs, stale = _records("traffic.json", tkey)
+    for pat in patterns:
+        hits = sorted((n for n in recs if re.search("::" + pat, n)), key=lambda n: -recs[n]["hbm_bytes"])
+        if hits:
+            return recs[hits[0]]["hbm_bytes"], hits[0].split("::")[-1], stale
+    return None, None, None
+
+
+def valu_roofline(tkey, patterns, live_ms):
+    """`roofline_valu` from profiles/sq.json[tkey] for the first kernel matching `patterns`."""
+    import re
+    recs, stale = _records("sq.json", tkey)
+    for pat in patterns:
+        hits = [n for n in recs if re.search("::" + pat, n)]
+        if not hits:
+            continue
+        n = max(hits, key=lambda h: recs[h].get("valu_busy_cycles_per_simd", 0))
+        r = recs[n]
+        busy, total = r["valu_busy_cycles_per_simd"], r["kernel_cycles"]
+        return {"bound": "valu_issue", "kernel": n.split("::")[-1], "achieved": round(busy), "peak": round(total),
+                "unit": "SIMD issue cycles per launch (SQ_ACTIVE_INST_VALU x 4 / SIMDs vs GRBM_GUI_ACTIVE / XCDs)",
+                "frac": round(busy / total, 4), "valu_instructions_per_wave": r.get("valu_insts_per_wave"),
+                "transcendental_share": r.get("trans_share"), "pmc_kernel_ms": r.get("kernel_ms"), "live_kernel_ms": round(live_ms, 4),
+                "record": "offline", "record_stale": stale,
+                "source": "profiles/sq.json (tools/pmc_sq.sh on this workload; counters are per launch, not re-measured live; "
+                          "record_stale = the kernel sources changed since it was taken)"}
     return None
+
+
+def limited(valu, hbm_frac) -> str:
+    if valu is None or valu.get("frac") is None:
+        return "hbm"
+    if valu.get("record_stale"):
+        return "hbm? (the VALU record is stale)"
+    return "valu_issue" if valu["frac"] > hbm_frac else "hbm"
+
+
+def kernel_ms_from_profiler(fn, n=10) -> dict:
+    """Average device time (ms) per launch of every sgr:: kernel over n calls of fn (torch.profiler / roctracer timestamps)."""
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+    out = {}
+    for e in prof.key_averages():
+        if "sgr::" in e.key and e.count:
+            tot = getattr(e, "device_time_total", None)
+            if tot is None:
+                tot = getattr(e, "cuda_time_total", 0.0)
+            out[e.key] = tot / e.count * 1e-3
+    return out
+
+
+def objective_rooflines(kernel_ms, tkey, P, K, J, q) -> dict:
+    """`roofline` + `roofline_valu` of the two heavy kernels of the trainLight step (the fused objective): algorithmic bytes per launch
+    (the forward reads the ground-truth env where the layer's writes the predicted one -- 2008 B per shaded pixel at
+    config 2 -- and the backward reads it again where the layer's reads the cotangent -- 2344 B) over the live per-launch time."""
+    import re
+    bpp = algorithmic_bytes_per_shaded_px(K, J, q)
+    out = {}
+    for tag, pats, nbytes in (("objective_forward", [r"fwd_pk_half_gt_kernel<", r"fwd_pk_kernel<"], P * bpp["fwd_env"]),
+                              ("objective_backward", [r"sg_bwd_recon_pk_kernel<"], P * bpp["bwd_sg"])):
+        hit = None
+        for pat in pats:
+            names = [n for n in kernel_ms if re.search("::" + pat, n)]
+            if names:
+                hit = max(names, key=lambda n: kernel_ms[n])
+                break
+        if hit is None:
+            continue
+        ms = kernel_ms[hit]
+        gbps = nbytes / (ms * 1e-3) / 1e9
+        traffic, _, t_stale = pmc_traffic(tkey, pats)
+        valu = valu_roofline(tkey, pats, ms)
+        out[tag] = {"roofline": {"bound": "hbm", "kernel": hit.split("::")[-1].split("(")[0], "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                 "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_record_stale": t_stale,
+                                 "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": round(ms, 4),
+                                 "timing": "torch.profiler device time per launch over the config-3 loop", "limited_by": limited(valu, gbps / HBM_PEAK_GBPS)},
+                    "roofline_valu": valu}
+    return out
 
 
 def config3_legs(pkg, layer, x, ind, bn, R, C, K, steps, barrier) -> dict:
@@ -381,6 +478,14 @@ def config3_legs(pkg, layer, x, ind, bn, R, C, K, steps, barrier) -> dict:
                 one()
             barrier()
             out["ms_per_step_config3" if prologue else "ms_per_step_config3_standalone_heads"] = round((time.perf_counter() - t0) / steps * 1e3, 4)
+            # the two heavy kernels of this step against their rooflines (round 4: the kernels the real trainLight step runs, not the
+            # layer's); per-launch device time from the profiler, counters from the PMC passes on the same workload
+            try:
+                J, q = layer.envHeight * layer.envWidth, (x["albedo"].shape[2] // R) * (x["albedo"].shape[3] // C)
+                tag = f"config2_batch{bn}_objective" + ("_heads" if prologue else "")
+                out["kernels_config3" if prologue else "kernels_config3_standalone_heads"] = objective_rooflines(kernel_ms_from_profiler(one), tag, bn * R * C, K, J, q)
+            except Exception as exc:
+                out["kernels_config3_error"] = str(exc)[:160]
         else:
             try:
                 side = torch.cuda.Stream(device=dev)

@@ -13,6 +13,22 @@ import os
 import sys
 from collections import defaultdict
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def csrc_sha16(root):
+    """Hash of the kernel sources (csrc/*.hip, *.inl, *.h): counter records are stamped with it, and bench.py reports a record as
+    stale when the sources it was measured on are not the ones the loaded library was built from."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(root, "inverserenderingofindoorscene_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.inl")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 root = sys.argv[1]
 acc = {"FETCH_SIZE": defaultdict(list), "WRITE_SIZE": defaultdict(list)}
 for cname in acc:
@@ -39,5 +55,6 @@ if len(sys.argv) > 3:
         allrec = json.load(open(target))
     except Exception:
         allrec = {}
+    out["_csrc_sha16"] = csrc_sha16(ROOT)
     allrec[tag] = out
     json.dump(allrec, open(target, "w"), indent=1)

@@ -12,6 +12,21 @@ import sys
 from collections import defaultdict
 
 SIMDS, XCDS = 1024, 8
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def csrc_sha16(root):
+    """Hash of the kernel sources (csrc/*.hip, *.inl, *.h): counter records are stamped with it, and bench.py reports a record as
+    stale when the sources it was measured on are not the ones the loaded library was built from."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(root, "inverserenderingofindoorscene_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.inl")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
 root, tag, target = sys.argv[1], sys.argv[2], sys.argv[3]
 acc = defaultdict(lambda: defaultdict(list))
 dur = defaultdict(list)
@@ -46,5 +61,6 @@ except Exception:
     allrec = {}
 allrec["_comment"] = ("VALU-issue figures per launch from SQ counters (tools/pmc_sq.sh + tools/parse_sq.py), keyed by workload then kernel; "
                       "bench.py's roofline_valu reports a figure only for the workload it was measured on")
+out["_csrc_sha16"] = csrc_sha16(ROOT)
 allrec[tag] = out
 json.dump(allrec, open(target, "w"), indent=1)
