@@ -43,26 +43,13 @@ namespace sgr {
 // of the azimuth pair -- sign 1 - half, azimuth component 1 - sub -- evaluates loss, reconstruction and render cotangent for
 // it (scalar: the transcendental count per pixel is what it was), and the four cotangents travel back the same way:
 // 6 + 3 swaps for the reduce-scatter, 3 + 6 for the all-gather.
-// Register relief for the gradient form (round 4; each A/B-ed on one box):
-//   SGR_RECON_LDS_E   1: the 24 kept exponentials of an azimuth pair wait in LDS between the radiance half and the gradient half of the
-//                     loop body (6 KB per wave next to the 12 KB ground-truth ring: 18 KB, eight waves per CU still fit) instead of in
-//                     registers -- six ds_write_b128 + six ds_read_b128 per azimuth pair on a pipe the kernel otherwise leaves idle
-//   SGR_RECON_KEEP_U  1: u_k = lp (ax ca + ay sa) of the pair is kept from the radiance half (12 registers) instead of re-formed in the
-//                     gradient half (12 packed instructions per azimuth pair)
-//   SGR_RECON_BPERM   1 (two lane groups): the halves trade their partial radiance and the cotangents with ds_bpermute_b32 -- the LDS
-//                     crossbar, which this kernel otherwise leaves idle -- instead of v_permlane32_swap, a VALU instruction that costs
-//                     the issue time of a transcendental (12 per azimuth pair: ~7 % of the loop's issue cycles).  Made select-free by
-//                     giving each half-wave the SIGN of the half row it owns: lanes of the upper half evaluate (+s_e, -s_e), lanes of the
-//                     lower half (-s_e, +s_e), so "own row" / "other row" are the same registers in every lane
-#ifndef SGR_RECON_LDS_E
-#define SGR_RECON_LDS_E 0
-#endif
-#ifndef SGR_RECON_BPERM
-#define SGR_RECON_BPERM 0
-#endif
-#ifndef SGR_RECON_KEEP_U
-#define SGR_RECON_KEEP_U 0
-#endif
+// Round 4, measured and NOT adopted (profiles/r04a_objective_bwd_variants.txt, one box): keeping the 24 exponentials of an azimuth
+// pair in LDS between the radiance half and the gradient half of the loop body (+6 KB per wave) -- 333 vs 318 us; trading the halves'
+// partial radiance / cotangents with ds_bpermute_b32 (the idle LDS crossbar, select-free by giving each half-wave the sign of the half
+// row it owns) instead of v_permlane32_swap -- 293 instead of 317 VALU instructions per azimuth pair, but 334 vs 318 us: two LDS round
+// trips per pair in the dependency chain cost more latency than the 12 swaps cost issue slots at two waves per SIMD.  The hot
+// (orthonormal-frame) loop has no scratch access: the spilled registers (private segment 140-170 B) belong to the degenerate-frame
+// loop and the code around the row loop, so register relief has nothing to buy (tools/loop_mix.py).
 #ifndef SGR_RECON_FENCES
 #define SGR_RECON_FENCES 1      // loop-body register fences of sg_bwd_recon_pk_kernel: 1 = lobes + row constants (default), 2 = also the BRDF / cotangent constants (round 2: 36 more bytes of scratch, +1 %), 0 = none (op_sel broadcasts get hoisted into register pairs: 543 vs 330 us)
 #endif
@@ -95,13 +82,7 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
   constexpr int HALF = 8, NP = 4, KPW = 6, Q = EW / 16, PXW = kWave / NG;       // PXW pixels per wave
   constexpr int kTile = 3 * PXW * 16;                                           // floats per ground-truth virtual-row tile
   __shared__ __attribute__((aligned(16))) float tile[2 * kTile];               // double-buffered
-  constexpr bool LDS_E = SGR_RECON_LDS_E && GRADS;
-  constexpr bool BPERM = SGR_RECON_BPERM && NG == 2;
-  const unsigned partner_addr = ((unsigned)threadIdx.x ^ 32u) * 4u;      // ds_bpermute_b32 source lane: the other half's lane of this pixel
-  auto bperm = [&](float v) { float r; asm volatile("ds_bpermute_b32 %0, %1, %2" : "=v"(r) : "v"(partner_addr), "v"(v) : "memory"); return r; };
-  __shared__ __attribute__((aligned(16))) float estash[LDS_E ? 4 * KPW * kWave : 4];      // [KPW][64 lanes][4]: (ep.x, ep.y, em.x, em.y) of lobe k
   static_assert(NG == 2 || NG == 4, "two or four lane groups per pixel");
-  const unsigned estash_addr = lds_addr(estash) + (unsigned)threadIdx.x * 16u;
 
   const int lane = threadIdx.x, half = lane >> 5, sub = (lane >> 4) & 1, pl = lane & (PXW - 1);
   const int grp = NG == 2 ? half : (lane >> 4);       // this lane's group of six lobes
@@ -207,13 +188,9 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
 #endif
         const f32x4 cs = cpt[aoff + ap];
         const f32x2 ca = {cs[0], cs[1]}, sa = {cs[2], cs[3]};
-        // BPERM: +srv is the half row this lane OWNS (ep / v[0] / g[0]), -srv the other half's (em / v[1] / g[1])
-        const f32x2 srv = splat2(BPERM && own ? -sr : sr);
+        const f32x2 srv = splat2(sr);
         // ---- 1. this group's lobes: exponentials and partial radiance of the 4 directions -----------------
         f32x2 ep[KPW], em[KPW];
-#if SGR_RECON_KEEP_U
-        f32x2 uk[KPW];
-#endif
         f32x2 v[2][3];        // [half row][colour], the azimuth pair
 #pragma unroll
         for (int sg = 0; sg < 2; ++sg)
@@ -226,27 +203,12 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
           const f32x2 xp = pfma(srv, u, cz), xm = pfma(-srv, u, cz);      // lp t
           ep[k] = f32x2{fexp2(xp.x), fexp2(xp.y)};
           em[k] = f32x2{fexp2(xm.x), fexp2(xm.y)};
-#if SGR_RECON_KEEP_U
-          uk[k] = u;
-#endif
-          if constexpr (LDS_E) {      // inline asm: a ds access the compiler can see makes it drain the LDS-DMA in flight (vmcnt(0)) first
-            const f32x4 e4 = {ep[k].x, ep[k].y, em[k].x, em[k].y};
-            asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(estash_addr), "v"(e4), "n"(k * kWave * 16) : "memory");
-          }
           v[0][0] = pfma(SGR_LO(P.w01[k]), ep[k], v[0][0]); v[0][1] = pfma(SGR_HI(P.w01[k]), ep[k], v[0][1]); v[0][2] = pfma(w2, ep[k], v[0][2]);
           v[1][0] = pfma(SGR_LO(P.w01[k]), em[k], v[1][0]); v[1][1] = pfma(SGR_HI(P.w01[k]), em[k], v[1][1]); v[1][2] = pfma(w2, em[k], v[1][2]);
         }
         // ---- 2. full radiance of the half row this half-wave owns (lanes 0..31: half row 1, 32..63: half row 0)
         f32x2 tot[3];
-        if constexpr (BPERM) {
-          f32x2 rv[3];      // the partner's partial for the half row THIS lane owns
-#pragma unroll
-          for (int c = 0; c < 3; ++c) rv[c] = f32x2{bperm(v[1][c].x), bperm(v[1][c].y)};
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int c = 0; c < 3; ++c) tot[c] = v[0][c] + rv[c];
-        } else {
+        {
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
             float dx = v[1][c].x, sx = v[0][c].x, dy = v[1][c].y, sy = v[0][c].y;
@@ -279,15 +241,7 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
             }
           }
           // ---- 4. both half rows' cotangents to all lanes --------------------------------------------------------
-          if constexpr (GRADS && BPERM) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              g[0][c] = go[c];                                       // the half row this lane owns
-              g[1][c] = f32x2{bperm(go[c].x), bperm(go[c].y)};       // the partner's
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-          } else if constexpr (GRADS) {
+          if constexpr (GRADS) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
               float dx = go[c].x, sx = go[c].x, dy = go[c].y, sy = go[c].y;
@@ -346,23 +300,10 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
         // ---- 5. this group's lobes: gradient accumulation (sg_bwd_pk_kernel's inner loop with the kept exponentials)
         const f32x2 sca = srv * ca, ssa = srv * sa;
         if constexpr (GRADS) {
-        if constexpr (LDS_E) {      // the kept exponentials come back: six ds_read_b128, one wait
-          f32x4 e4[KPW];
-#pragma unroll
-          for (int k = 0; k < KPW; ++k) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(e4[k]) : "v"(estash_addr), "n"(k * kWave * 16) : "memory");
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int k = 0; k < KPW; ++k) { ep[k] = f32x2{e4[k][0], e4[k][1]}; em[k] = f32x2{e4[k][2], e4[k][3]}; }
-        }
 #pragma unroll
         for (int k = 0; k < KPW; ++k) {
           const f32x2 cz = half_of(czr[k / 2], k & 1), w2 = half_of(P.w2p[k / 2], k & 1);
-#if SGR_RECON_KEEP_U
-          const f32x2 u = uk[k];
-#else
           const f32x2 u = pfma(SGR_HI(P.axy[k]), sa, SGR_LO(P.axy[k]) * ca);
-#endif
           const f32x2 tp = pfma(srv, u, cz), tm = pfma(-srv, u, cz);      // lp t: gl accumulates lp sum T t
           gw0[k] = pfma(g[0][0], ep[k], gw0[k]); gw1[k] = pfma(g[0][1], ep[k], gw1[k]); gw2[k] = pfma(g[0][2], ep[k], gw2[k]);
           gw0[k] = pfma(g[1][0], em[k], gw0[k]); gw1[k] = pfma(g[1][1], em[k], gw1[k]); gw2[k] = pfma(g[1][2], em[k], gw2[k]);

@@ -44,6 +44,46 @@ for name, fn in (("layer", layer_step), ("layer + render loss", loss_step), ("fu
     t2 = time.perf_counter()
     print(f"{name:22s} enqueue {1e3 * (t1 - t0) / n:.3f} ms/step   total {1e3 * (t2 - t0) / n:.3f} ms/step")
 
+# where the enqueue time goes (round 4): the raw C-ABI launch through ctypes, the registered operator without and with an autograd
+# node, the backward through torch.autograd.grad -- each enqueue-only, per call
+from inverserenderingofindoorscene_amd import _lib
+from inverserenderingofindoorscene_amd.ops import _dirs, _ptr, _stream, _view
+env_b = torch.empty((bn, 3, R, C, 8, 16), device=dev); dif_b = torch.empty((bn, 3, R, C), device=dev); spc_b = torch.empty_like(dif_b)
+d_tab, v_tab = _dirs(dev, 8, 16), _view(dev, R, C, 57.0)
+raw_args = [_ptr(x[k]) for k in ("albedo", "normal", "rough", "axis", "lamb", "weight")] + [_ptr(d_tab), _ptr(v_tab), _ptr(env_b), None, None, _ptr(dif_b), _ptr(spc_b),
+                                                                                             bn, K, R, C, 8, 16, imH, imW, 0.05, 1, _stream(dev)]
+lib = _lib.load()
+
+def raw_launch():
+    lib.sgr_fused_fwd_tan(*raw_args)
+
+def op_nograd():
+    with torch.no_grad():
+        torch.ops.sgrender.fused_render(x["albedo"], x["normal"], x["rough"], *sg, 8, 16, 57.0, 0.05, (0.0, 0.0, 0.0), 1, True, False)
+
+def op_grad():
+    torch.ops.sgrender.fused_render(x["albedo"], x["normal"], x["rough"], *sg, 8, 16, 57.0, 0.05, (0.0, 0.0, 0.0), 1, True, False)
+
+def fwd_wrapper():
+    layer.forwardSG(x["albedo"], x["normal"], x["rough"], *sg, need_env=True)
+
+def empty5():
+    for _ in range(5):
+        torch.empty((bn, 3, R, C), device=dev)
+
+for name, fn in (("C ABI via ctypes (1 launch)", raw_launch), ("5 x torch.empty", empty5), ("operator, no_grad", op_nograd), ("operator, autograd node", op_grad),
+                 ("layer.forwardSG", fwd_wrapper)):
+    for _ in range(50):
+        fn()
+    torch.cuda.synchronize()
+    n = 300
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    print(f"   {name:30s} enqueue {1e6 * (t1 - t0) / n:7.1f} us/call")
+
 if os.environ.get("SGR_HOST_PROFILE"):
     import cProfile, pstats
     for name, fn in (("layer", layer_step), ("layer + render loss", loss_step)):
