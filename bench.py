@@ -434,7 +434,7 @@ def objective_rooflines(kernel_ms, tkey, P, K, J, q) -> dict:
         gbps = nbytes / (ms * 1e-3) / 1e9
         traffic, _, t_stale = pmc_traffic(tkey, pats)
         valu = valu_roofline(tkey, pats, ms)
-        out[tag] = {"roofline": {"bound": "hbm", "kernel": hit.split("::")[-1].split("(")[0], "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        out[tag] = {"roofline": {"bound": "hbm", "kernel": hit.split("sgr::", 1)[-1].split("(")[0], "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                  "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_record_stale": t_stale,
                                  "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": round(ms, 4),
                                  "timing": "torch.profiler device time per launch over the config-3 loop", "limited_by": limited(valu, gbps / HBM_PEAK_GBPS)},

@@ -823,6 +823,91 @@ __device__ __forceinline__ void tile32_read_two_pairs2(const float* tile, int pl
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// ============================== forwardEnv alone (env image read), packed half-wave (round 4) ======
+// The un-fused drop-in call renderingLayer.forwardEnv (models.py:461-522): HBM-bound (1672 B per shaded pixel in).  Round 1's
+// kernel (one pixel per lane, scalar arithmetic, 24 KB of LDS per wave: six waves per CU) reached 59 % of the HBM peak.  This is
+// the half-wave form of the other kernels: one wave = 32 pixels, lanes l and l + 32 own the same pixel and integrate one half row
+// (sign) each, in azimuth pairs (shade_pair); the env rows arrive one virtual row (8 + 8 directions) at a time by double-buffered
+// LDS-DMA into 6 KB tiles -- 12 KB per wave, so twelve waves per CU keep twice the bytes in flight -- and the two halves' six
+// sums meet once at the end (6 swaps).
+template <int POOL, int EW>
+__global__ __launch_bounds__(kWave, 3) void render_pk_half_kernel(const Args a) {
+  constexpr int NP = 4, Q = EW / 16;
+  __shared__ __attribute__((aligned(16))) float tile[2 * kT32Floats];
+  const Pix x = locate_group32(a, (int)blockIdx.x);
+  const int lane = threadIdx.x, half = lane >> 5, pl = lane & 31;
+  const int own = 1 - half;                         // the half row (sign) this half-wave integrates
+  const int RC = a.R * a.C, b = x.b, p = x.p;
+  __amdgpu_buffer_rsrc_t eimg = env_rsrc(a.env_in + (size_t)b * 3 * RC * a.J, RC, a.J);
+  const int nvr = a.eh * Q;
+  tile32_dma_issue_vrow<SGR_DMA_AUX, EW>(tile, eimg, x.p0, RC, a.J, 0, lane);
+
+  float alb[3];
+  const Frame f = load_frame<POOL>(a, x, alb);
+  PixLocal q = make_local(f, a.F0);
+  OrthoPix oq = make_ortho_pix(q);
+  const bool ortho = __all(frame_is_orthonormal(q));
+  const SepTable rows = as_sep_table(a.rows);
+  const PairTable cpt = as_pair_table(a.cols, EW);
+  const XTable xt = (XTable)(a.cols + EW);
+  f32x2 dacc[3] = {splat2(0.f), splat2(0.f), splat2(0.f)}, sacc[3] = {splat2(0.f), splat2(0.f), splat2(0.f)};
+
+  auto row_loop = [&](auto ortho_c) {
+    constexpr bool ORTHO = decltype(ortho_c)::value;
+    for (int vr = 0; vr < nvr; ++vr) {
+      const int e = Q == 1 ? vr : (vr >> 1), aoff = Q == 1 ? 0 : (vr & 1) * NP;      // table row; first azimuth pair of this virtual row
+      const float* cur = tile + (vr & 1) * kT32Floats;
+      if (vr + 1 < nvr) {
+        tile32_dma_issue_vrow<SGR_DMA_AUX, EW>(tile + ((vr + 1) & 1) * kT32Floats, eimg, x.p0, RC, a.J, vr + 1, lane);
+        wait_vmcnt<6>();        // this virtual row has landed; the next stays in flight
+      } else {
+        wait_vmcnt<0>();
+      }
+      if (!ORTHO) fence_row_invariants(q);
+      const RowCtx rc = make_row_ctx(q, rows[e], true);
+      OrthoRow orow = make_ortho_row(rc.ro);
+#pragma unroll 1
+      for (int ap = 0; ap < NP; ++ap) {
+        if (ORTHO) { SGR_FENCE2(oq.vB); SGR_FENCE2(oq.ff); SGR_FENCE2(oq.vvk); SGR_FENCE2(orow.nwc); SGR_FENCE2(orow.cvc); }
+        const f32x4 cs = cpt[aoff + ap];
+        const f32x2 ca = {cs[0], cs[1]}, sa = {cs[2], cs[3]};
+        float g[3][2];
+        tile32_read_pair(cur, pl, own * 8 + ap * 2, g);
+        const f32x2 Pv = pfma(SGR_HI(oq.vB), sa, SGR_LO(oq.vB) * ca);
+        f32x2 wt, sp;
+        shade_pair<ORTHO>(q, oq, rc, orow, own, ca, sa, Pv, xt, (aoff + ap) * 2, wt, sp);
+        const f32x2 sw = sp * wt;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const f32x2 gv = {g[c][0], g[c][1]};
+          dacc[c] = pfma(wt, gv, dacc[c]);
+          sacc[c] = pfma(sw, gv, sacc[c]);
+        }
+      }
+    }
+  };
+  if (ortho) row_loop(std::true_type{}); else row_loop(std::false_type{});
+
+  // each half integrated one half row: add the two
+  float v[6] = {dacc[0].x + dacc[0].y, dacc[1].x + dacc[1].y, dacc[2].x + dacc[2].y, sacc[0].x + sacc[0].y, sacc[1].x + sacc[1].y, sacc[2].x + sacc[2].y};
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float d_ = v[i], s_ = v[i];
+    swap32(d_, s_);
+    v[i] = d_ + s_;
+  }
+  if (x.active && half == 0) {
+    const size_t o = (size_t)b * 3 * RC;
+    const unsigned up = (unsigned)p;
+    (a.diffuse + o)[up] = (alb[0] * kInvPi) * v[0];
+    (a.diffuse + o + RC)[up] = (alb[1] * kInvPi) * v[1];
+    (a.diffuse + o + 2 * (size_t)RC)[up] = (alb[2] * kInvPi) * v[2];
+    (a.spec + o)[up] = v[3];
+    (a.spec + o + RC)[up] = v[4];
+    (a.spec + o + 2 * (size_t)RC)[up] = v[5];
+  }
+}
+
 template <int POOL, bool HAS_GENV, bool HAS_RENDER, int EW = 16, bool HEADS = false>
 __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
   constexpr int HALF = 8, NP = 4, KPW = 6, Q = EW / 16;
