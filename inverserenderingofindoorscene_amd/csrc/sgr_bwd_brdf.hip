@@ -117,7 +117,7 @@ __global__ __launch_bounds__(kWave, 1) void brdf_bwd_kernel(const Args a) {
 // multiply-add of the world-space adjoint is one half of a v_pk_fma_f32; what stays per element are the clamps (v_med3), their
 // gradient gates, the transcendentals and the Newton steps' seeds.  Directions come from the separable table
 // (l = (ss ca_a, ss sa_a, c_e): the pair's (ca, sa) are SGPR pairs), the env rows by the double-buffered LDS-DMA of
-// render_fast_kernel, the pairs read as ds_read_b64.  ~150 packed + ~40 scalar instructions per PAIR against ~170 scalar per
+// render_pk_half_kernel, the pairs read as ds_read_b64.  ~150 packed + ~40 scalar instructions per PAIR against ~170 scalar per
 // direction.  World-space throughout, so degenerate frames need no separate path.
 struct FrameGradPk {
   f32x2 gN[3], gcx[3], gcy[3], galpha2, gk, gndv;

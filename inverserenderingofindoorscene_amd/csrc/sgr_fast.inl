@@ -124,83 +124,6 @@ __device__ __forceinline__ void shade_dir(const PixLocal& q, const RowCtx& rc, i
 
 
 
-// ============================== forwardEnv alone (env image read) =================================
-// The un-fused drop-in call renderingLayer.forwardEnv (models.py:461-522): HBM-bound (1672 B/px in,
-// ~45 VALU slots per direction), so the env rows stream in by double-buffered LDS-DMA exactly like the
-// cotangent rows of the backward pass.
-template <int POOL, int EW>
-__global__ __launch_bounds__(kWave, 4) void render_fast_kernel(const Args a) {
-  constexpr int TJ = EW;
-  constexpr int HALF = EW / 2;
-  constexpr int NP = HALF / 2;
-  constexpr int NBUF = (EW == 16) ? 2 : 1;
-  using D = DmaTile<TJ>;
-  __shared__ __attribute__((aligned(16))) float tile[NBUF * D::kFloats];
-
-  const Pix x = locate(a);
-  const int lane = x.lane, b = x.b, p = x.p;
-  const int RC = a.R * a.C;
-  float alb[3];
-  const Frame f = load_frame<POOL>(a, x, alb);
-  PixLocal q = make_local(f, a.F0);
-  const bool ortho = __all(frame_is_orthonormal(q));
-  const SepTable rows = as_sep_table(a.rows);
-  const XTable cst = (XTable)(a.cols);
-  const XTable xt = (XTable)(a.cols + EW);
-  __amdgpu_buffer_rsrc_t eimg = env_rsrc(a.env_in + (size_t)b * 3 * RC * a.J, RC, a.J);
-  const int eh = a.eh;
-  float d0 = 0.f, d1 = 0.f, d2 = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
-
-  tile_dma_issue<TJ>(tile, eimg, x.p0, RC, a.J, 0, lane);
-  // the wave-uniform frame test is hoisted out of the direction loops: two copies of the row loop
-  auto row_loop = [&](auto ortho_c) {
-  for (int e = 0; e < eh; ++e) {
-      const float* cur = tile + (NBUF == 2 ? (e & 1) * D::kFloats : 0);
-      if (NBUF == 2 && e + 1 < eh) {
-        tile_dma_issue<TJ>(tile + ((e + 1) & 1) * D::kFloats, eimg, x.p0, RC, a.J, (e + 1) * EW, lane);
-        wait_vmcnt<D::kInstr>();
-      } else {
-        wait_vmcnt<0>();
-      }
-      fence_row_invariants(q);
-      const RowCtx rc = make_row_ctx(q, rows[e], true);
-  #pragma unroll 1
-      for (int ap = 0; ap < NP; ++ap) {
-        const f32x4 cs = cst[ap];
-        float g[2][3][2];
-        tile_dma_read_pairs<TJ>(cur, lane, ap * 2, HALF + ap * 2, g);
-  #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-  #pragma unroll
-          for (int sg = 0; sg < 2; ++sg) {
-            float wt, sp;
-            shade_dir<decltype(ortho_c)::value>(q, rc, sg, cs[2 * i], cs[2 * i + 1], xt, ap * 2 + i, wt, sp);
-            const float sw = sp * wt;
-            d0 = fmaf(wt, g[sg][0][i], d0);
-            d1 = fmaf(wt, g[sg][1][i], d1);
-            d2 = fmaf(wt, g[sg][2][i], d2);
-            s0 = fmaf(sw, g[sg][0][i], s0);
-            s1 = fmaf(sw, g[sg][1][i], s1);
-            s2 = fmaf(sw, g[sg][2][i], s2);
-          }
-        }
-      }
-      if (NBUF == 1 && e + 1 < eh) tile_dma_issue<TJ>(tile, eimg, x.p0, RC, a.J, (e + 1) * EW, lane);
-    }
-  };
-  if (ortho) row_loop(std::true_type{}); else row_loop(std::false_type{});
-  if (x.active) {
-    const size_t o = (size_t)b * 3 * RC;
-    const unsigned up = (unsigned)p;
-    (a.diffuse + o)[up] = (alb[0] * kInvPi) * d0;
-    (a.diffuse + o + RC)[up] = (alb[1] * kInvPi) * d1;
-    (a.diffuse + o + 2 * (size_t)RC)[up] = (alb[2] * kInvPi) * d2;
-    (a.spec + o)[up] = s0;
-    (a.spec + o + RC)[up] = s1;
-    (a.spec + o + 2 * (size_t)RC)[up] = s2;
-  }
-}
-
 // ============================== utils.predToShading (utils.py:156-195) ============================
 // shading_c = max( sum_j env_c(l_j) cos(El_j) sin(El_j), 0 ): the SG mixture integrated against the
 // cosine-weighted hemisphere measure (no microfacet terms, no env image) -- the forward inner loop with a

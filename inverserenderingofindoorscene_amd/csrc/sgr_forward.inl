@@ -197,28 +197,17 @@ static int fwd_fast_launch(const Args& a, hipStream_t st) {
   return fwd_fast_launch_h<WRITE_ENV, DO_RENDER, false>(a, st);
 }
 
-// forwardEnv alone (env image given): SGR_RENDER_ENV=scalar selects round 1's one-pixel-per-lane kernel for the A/B record
+// forwardEnv alone (env image given): the packed half-wave kernel of sgr_pk.inl (round 4; round 1's scalar one-pixel-per-lane kernel
+// with its 24 KB of LDS per wave measured 110 us against 105 warm, 160 against 158 cold -- profiles/r04c_kbench.txt -- and is gone)
 static int render_fast_launch(const Args& a, hipStream_t st) {
-  static const bool scalar = [] { const char* e = getenv("SGR_RENDER_ENV"); return e && !strcmp(e, "scalar"); }();
   const bool p1 = (a.imH == a.R && a.imW == a.C);
-  if (!scalar) {
-    const dim3 grid((unsigned)(a.bn * ((a.R * a.C + kPx - 1) / kPx))), block(kWave);
-    if (a.ew == 16) {
-      if (p1) hipLaunchKernelGGL((render_pk_half_kernel<1, 16>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((render_pk_half_kernel<2, 16>), grid, block, 0, st, a);
-    } else {
-      if (p1) hipLaunchKernelGGL((render_pk_half_kernel<1, 32>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((render_pk_half_kernel<2, 32>), grid, block, 0, st, a);
-    }
-    return (int)hipGetLastError();
-  }
-  const dim3 grid = wave_grid(a.bn, a.R, a.C), block(kWave);
+  const dim3 grid((unsigned)(a.bn * ((a.R * a.C + kPx - 1) / kPx))), block(kWave);
   if (a.ew == 16) {
-    if (p1) hipLaunchKernelGGL((render_fast_kernel<1, 16>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((render_fast_kernel<2, 16>), grid, block, 0, st, a);
+    if (p1) hipLaunchKernelGGL((render_pk_half_kernel<1, 16>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((render_pk_half_kernel<2, 16>), grid, block, 0, st, a);
   } else {
-    if (p1) hipLaunchKernelGGL((render_fast_kernel<1, 32>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((render_fast_kernel<2, 32>), grid, block, 0, st, a);
+    if (p1) hipLaunchKernelGGL((render_pk_half_kernel<1, 32>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((render_pk_half_kernel<2, 32>), grid, block, 0, st, a);
   }
   return (int)hipGetLastError();
 }

@@ -81,15 +81,13 @@ template <int POOL, int EW = 16, int NG = 2, bool HEADS = false, bool GRADS = tr
 __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a) {
   constexpr int HALF = 8, NP = 4, KPW = 6, Q = EW / 16, PXW = kWave / NG;       // PXW pixels per wave
   constexpr int kTile = 3 * PXW * 16;                                           // floats per ground-truth virtual-row tile
-  // ground-truth rows: a ring of three one-row tiles, requested two rows at a time -- the two 64-byte halves of every 128-byte
-  // line of the image back to back, one row ahead of their use (sg_bwd_pk_kernel's scheme; round 4).  Requested one row at a time
-  // into a double buffer (rounds 2-3), the second half of each line came a row of arithmetic (~5 us) after the first, by which
-  // time the XCD's L2 had turned over: PMC showed 826 MB fetched where 610 MB are read (profiles/r04b_pmc_traffic_config2_objective.txt)
-#ifndef SGR_RECON_RING
-#define SGR_RECON_RING 1
-#endif
-  constexpr int NBUF = SGR_RECON_RING ? 3 : 2;
-  __shared__ __attribute__((aligned(16))) float tile[NBUF * kTile];
+  // ground-truth rows: double-buffered one-row tiles, row vr+1 requested while row vr is consumed.  PMC (round 4, profiles/r04b_pmc_traffic_
+  // config2_batch16_objective.txt): 826 MB fetched where ~610 MB are read -- a row is one 64-byte half of each 128-byte line, and the other
+  // half is requested a row of arithmetic (~5 us) later, after the XCD's L2 has turned over.  A ring of three tiles requested two rows at a
+  // time (sg_bwd_pk_kernel's scheme: both halves of a line back to back) brought the fetch down to 671 MB but cost 18 KB of LDS and ran
+  // SLOWER, 342 vs 321 us (r04c_kbench.txt): this kernel moves 3 TB/s and is bound by VALU issue, the re-fetches come out of the Infinity
+  // Cache, and the 12-instruction DMA bursts sit in front of the loads the next row's arithmetic is waiting for.  Not adopted.
+  __shared__ __attribute__((aligned(16))) float tile[2 * kTile];
   static_assert(NG == 2 || NG == 4, "two or four lane groups per pixel");
 
   const int lane = threadIdx.x, half = lane >> 5, sub = (lane >> 4) & 1, pl = lane & (PXW - 1);
@@ -115,7 +113,6 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
     else tile16_dma_issue_vrow<SGR_DMA_AUX, EW>(dst, gimg, x.p0, RC, a.J, vr, lane);
   };
   issue(tile, 0);
-  if (SGR_RECON_RING && nvr > 1) issue(tile + kTile, 1);
 
   PixLocal q{};
   OrthoPix oq{};
@@ -165,15 +162,6 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
     for (int vr = 0; vr < nvr; ++vr) {
       const int e = Q == 1 ? vr : (vr >> 1), aoff = Q == 1 ? 0 : (vr & 1) * NP;      // table row; first azimuth pair of this virtual row
       constexpr int kRow = NG == 2 ? 6 : 3;      // LDS-DMA instructions per virtual-row tile
-#if SGR_RECON_RING
-      const float* cur = tile + (vr % 3) * kTile;
-      // rows vr+1, vr+2 (vr odd) were requested when row vr-1 was done; up to two rows may stay in flight
-      if ((vr & 1) == 0) {
-        if (vr + 1 < nvr) wait_vmcnt<kRow>(); else wait_vmcnt<0>();
-      } else {
-        if (vr + 2 < nvr) wait_vmcnt<2 * kRow>(); else if (vr + 1 < nvr) wait_vmcnt<kRow>(); else wait_vmcnt<0>();
-      }
-#else
       const float* cur = tile + (vr & 1) * kTile;
       if (vr + 1 < nvr) {
         issue(tile + ((vr + 1) & 1) * kTile, vr + 1);
@@ -181,7 +169,6 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
       } else {
         wait_vmcnt<0>();
       }
-#endif
       if (GRADS && !ORTHO) fence_row_invariants(q);
       const f32x8 row = rows[e];
       const float sr = row[0], cr = row[1];
@@ -338,12 +325,6 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
         }
         }
       }
-#if SGR_RECON_RING
-      if ((vr & 1) == 0) {      // row vr is consumed: its tile and row vr-1's are free -> request rows vr+2 and vr+3 back to back
-        if (vr + 2 < nvr) issue(tile + ((vr + 2) % 3) * kTile, vr + 2);
-        if (vr + 3 < nvr) issue(tile + ((vr + 3) % 3) * kTile, vr + 3);
-      }
-#endif
     }
   };
   if (ortho) row_loop(std::true_type{}); else row_loop(std::false_type{});

@@ -825,7 +825,8 @@ __device__ __forceinline__ void tile32_read_two_pairs2(const float* tile, int pl
 
 // ============================== forwardEnv alone (env image read), packed half-wave (round 4) ======
 // The un-fused drop-in call renderingLayer.forwardEnv (models.py:461-522): HBM-bound (1672 B per shaded pixel in).  Round 1's
-// kernel (one pixel per lane, scalar arithmetic, 24 KB of LDS per wave: six waves per CU) reached 59 % of the HBM peak.  This is
+// kernel (one pixel per lane, scalar arithmetic, 24 KB of LDS per wave: six waves per CU) reached 58 % of the HBM peak, this one 61 %
+// (110 -> 105 us warm, 160 -> 158 us with cold buffers, where both sit on the 64-byte-per-128-byte-line access pattern).  This is
 // the half-wave form of the other kernels: one wave = 32 pixels, lanes l and l + 32 own the same pixel and integrate one half row
 // (sign) each, in azimuth pairs (shade_pair); the env rows arrive one virtual row (8 + 8 directions) at a time by double-buffered
 // LDS-DMA into 6 KB tiles -- 12 KB per wave, so twelve waves per CU keep twice the bytes in flight -- and the two halves' six

@@ -71,8 +71,22 @@ def empty5():
     for _ in range(5):
         torch.empty((bn, 3, R, C), device=dev)
 
+# PyTorch's own floor for "one forward node, one backward through torch.autograd.grad with three outputs / cotangents": the same
+# call pattern as layer_step, with aten kernels on 16-element tensors -- what the engine (graph task, hand-off to the device thread)
+# and torch.autograd.grad's Python cost whatever the node does
+tiny = [torch.randn(16, device=dev, requires_grad=True) for _ in range(3)]
+tiny_ct = [torch.randn(16, device=dev) for _ in range(3)]
+
+def torch_floor():
+    outs = [t * 2.0 for t in tiny]
+    torch.autograd.grad(outs, tiny, grad_outputs=tiny_ct)
+
+def bwd_only():
+    env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], *sg, need_env=True)
+    return env, d, s
+
 for name, fn in (("C ABI via ctypes (1 launch)", raw_launch), ("5 x torch.empty", empty5), ("operator, no_grad", op_nograd), ("operator, autograd node", op_grad),
-                 ("layer.forwardSG", fwd_wrapper)):
+                 ("layer.forwardSG", fwd_wrapper), ("torch floor: 3 aten mul + autograd.grad", torch_floor)):
     for _ in range(50):
         fn()
     torch.cuda.synchronize()
