@@ -1005,6 +1005,9 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
           if (ORTHO) { SGR_FENCE2(oq.vB); SGR_FENCE2(oq.ff); SGR_FENCE2(oq.vvk); SGR_FENCE2(orow.nwc); SGR_FENCE2(orow.cvc); }
         }
 #endif
+        // (round 4, measured and not adopted: this pair's table entries requested one iteration ahead, and the cotangent pairs read behind
+        // the BRDF terms instead of in front of them -- the loop head then waits for nothing -- 232.8 vs 228.8-230.1 us in the bench loop
+        // on one box, profiles/r04d_variants.txt: at two waves per SIMD the other wave already covers the ~150 cycles)
         const f32x4 cs = cpt[aoff + ap];
         const f32x2 ca = {cs[0], cs[1]}, sa = {cs[2], cs[3]};
         f32x2 g[2][3];            // [sign][colour], the azimuth pair (2 ap, 2 ap + 1) of this virtual row
