@@ -203,7 +203,7 @@ def main() -> None:
     # informational: the whole cascade-0 light objective (render loss + 10 x env reconstruction loss,
     # wrapperBRDFLight.py:167-207) -- fused (env image never written, sgr.light_objective) and unfused.  Single process only:
     # a leg that failed on one rank would leave the others in its barrier
-    obj_ms = obj_unfused_ms = None
+    obj_ms = obj_unfused_ms = obj_fwd_only_ms = None
     cfg3 = None
     if world == 1 and need_env and not args.layer_only:
         ind = torch.ones(bn, 1, 1, 1, device=dev)
@@ -217,6 +217,10 @@ def main() -> None:
                                       x["im"], x["seg"], x["env_gt"], ind, 1.0, 10.0)[0]
             obj.backward()
             clear()
+
+        def step_obj_forward_only():      # evaluation loops (testLight.py drives the same wrapper without a backward): no gradient kernel is launched
+            with torch.no_grad():
+                pkg.light_objective(layer, x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], x["im"], x["seg"], x["env_gt"], ind, 1.0, 10.0)
 
         def step_obj_unfused():
             env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=True)
@@ -237,8 +241,9 @@ def main() -> None:
         try:
             obj_ms = loop_ms(step_obj_fused, args.steps)
             obj_unfused_ms = loop_ms(step_obj_unfused, args.steps)
+            obj_fwd_only_ms = loop_ms(step_obj_forward_only, args.steps)
         except Exception as exc:       # informational legs: never fail the bench over them
-            obj_ms = obj_unfused_ms = None
+            obj_ms = obj_unfused_ms = obj_fwd_only_ms = None
             print(f"# light-objective legs skipped: {str(exc)[:160]}", file=sys.stderr)
 
         # BASELINE config 3: the synthetic trainLight cascade-0 step (trainLight.py:203-244 around wrapperBRDFLight.py:158-207):
@@ -300,6 +305,7 @@ def main() -> None:
                        "ms_per_step_with_render_loss": round(loss_step_ms, 4), "Mpix_per_s_with_render_loss": mpix(loss_step_ms),
                        "ms_per_step_light_objective_fused": None if obj_ms is None else round(obj_ms, 4),
                        "ms_per_step_light_objective_unfused": None if obj_unfused_ms is None else round(obj_unfused_ms, 4),
+                       "ms_per_step_light_objective_forward_only": None if obj_fwd_only_ms is None else round(obj_fwd_only_ms, 4),
                        "config3": cfg3,
                        "parallelism": f"batch-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(dom[3], 1), "peak": HBM_PEAK_GBPS,

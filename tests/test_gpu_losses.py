@@ -179,3 +179,32 @@ def test_render_loss_is_deterministic_and_its_result_may_be_modified_in_place(sg
         for x, y in zip(a, b):
             assert torch.equal(x, y)
         assert torch.equal(c[0], a[0]) and torch.equal(c[2], 2.0 * a[2]) and torch.equal(c[3], 2.0 * a[3])
+
+
+def test_last_arriving_workgroup_fold_over_many_launches(sgr):
+    """The batch totals of the render loss are folded by whichever workgroup of the third pass arrives last (release on its ticket,
+    acquire by the last arrival -- round 3 relied on gfx950's write-through stores being counted in vmcnt).  A lost or
+    stale partial would show up as a wrong total: 400 launches on fresh inputs, each checked against the totals recomputed in fp64 from
+    the pass's own outputs (rendered, pooled image, pooled mask) and against the value of the two-step route (totals, then a separate
+    sgr_loss_finalize launch)."""
+    ops = torch.ops.sgrender
+    bn, imH, imW, R, C = 16, 240, 320, 120, 160
+    g = torch.Generator(device="cuda").manual_seed(11)
+    worst = 0.0
+    for it in range(400):
+        d = torch.rand(bn, 3, R, C, device="cuda", generator=g)
+        s = torch.rand(bn, 3, R, C, device="cuda", generator=g) * 0.3
+        im = torch.rand(bn, 3, imH, imW, device="cuda", generator=g)
+        seg = (torch.rand(bn, 1, imH, imW, device="cuda", generator=g) < 0.9).float()
+        loss, scale, parts, rendered, im_s, seg_s, coef = ops.render_loss(d, s, im, seg, R, C, True)
+        num = (((rendered.double() - im_s.double()) ** 2) * seg_s.double()).sum()
+        den = seg_s.double().sum()
+        got = parts.double()
+        e = max(abs(got[0] - num).item() / num.item(), abs(got[1] - den).item() / den.item())
+        worst = max(worst, e)
+        assert e < 2e-6, (it, got.tolist(), num.item(), den.item())
+        assert abs(loss.double() - num / den.clamp_min(1e-5) / 3.0).item() < 2e-6 * loss.item(), it
+        if it % 40 == 0:      # the sharded route's totals come out of the same fold; its loss out of a separate launch
+            _, _, parts2, _, _, _, _ = ops.render_loss(d, s, im, seg, R, C, False)
+            assert torch.equal(parts2, parts), it
+    print(f"last-arriving fold: worst relative deviation of the totals over 400 launches {worst:.2e}")
