@@ -662,6 +662,54 @@ T7 render_loss_autograd(const Tensor& diffuse, const Tensor& spec, const Tensor&
   return {o[0], o[1], o[2], o[3], o[4], o[5], o[6]};
 }
 
+// render_loss_finalize(diffuse, spec, parts, im_small, seg_small, coef) -> (loss, scale): the step AFTER the all-reduce of `parts` under
+// batch sharding: loss = parts[0] / max(parts[1], 1e-5) / 3 with the rank-summed totals, one launch; the autograd node
+// sits here -- its backward is the render-loss backward kernel with the GLOBAL normaliser (scale = d loss / d numerator), so every rank
+// gets the gradient of the global loss w.r.t. its shard.  (diffuse / spec / im_small / seg_small / coef: what render_loss(total = False)
+// took and returned for this shard.)  Five launches and one collective per step, as in rounds 2-3.
+T2 render_loss_finalize_cuda(const Tensor& diffuse, const Tensor& spec, const Tensor& parts, const Tensor& im_s, const Tensor& seg_s, const Tensor& coef) {
+  const auto dev = require_hip({&diffuse, &spec, &parts, &im_s, &seg_s, &coef});
+  const c10::DeviceGuard guard(dev);
+  const Tensor p = parts.contiguous();
+  TORCH_CHECK(p.numel() == 2, "sgrender: render_loss_finalize takes the two totals [numerator, denominator]");
+  Tensor loss = at::empty({}, p.options()), scale = at::empty({1}, p.options());
+  ok(api().sgr_loss_finalize(rp(p), loss.data_ptr<float>(), wp(scale), 3.0f, stream_of(dev)), "sgr_loss_finalize");
+  return {loss, scale};
+}
+T2 render_loss_finalize_meta(const Tensor&, const Tensor&, const Tensor& parts, const Tensor&, const Tensor&, const Tensor&) {
+  return {at::empty({}, parts.options()), at::empty({1}, parts.options())};
+}
+struct RenderLossFinalizeFn : public torch::autograd::Function<RenderLossFinalizeFn> {
+  static variable_list forward(AutogradContext* ctx, const Tensor& diffuse, const Tensor& spec, const Tensor& parts, const Tensor& im_s, const Tensor& seg_s,
+                               const Tensor& coef) {
+    T2 out;
+    {
+      at::AutoDispatchBelowADInplaceOrView guard;
+      static auto op = find_op<T2(const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&)>("sgrender::render_loss_finalize");
+      out = op.call(diffuse, spec, parts, im_s, seg_s, coef);
+    }
+    ctx->save_for_backward({diffuse, spec, im_s, seg_s, coef, std::get<1>(out)});
+    ctx->mark_non_differentiable({std::get<1>(out)});
+    ctx->set_materialize_grads(false);
+    return {std::get<0>(out), std::get<1>(out)};
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list g) {
+    variable_list out(6);
+    if (!g[0].defined()) return out;
+    const auto saved = ctx->get_saved_variables();
+    static auto op = find_op<T2(const OptTensor&, double, const OptTensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&)>(
+        "sgrender::render_loss_bwd");
+    auto [gd, gs] = op.call(g[0].to(at::kFloat).reshape({-1}), 1.0, saved[5], saved[0], saved[1], saved[2], saved[3], saved[4]);
+    out[0] = gd;
+    out[1] = gs;
+    return out;
+  }
+};
+T2 render_loss_finalize_autograd(const Tensor& diffuse, const Tensor& spec, const Tensor& parts, const Tensor& im_s, const Tensor& seg_s, const Tensor& coef) {
+  auto o = RenderLossFinalizeFn::apply(diffuse, spec, parts, im_s, seg_s, coef);
+  return {o[0], o[1]};
+}
+
 // ==================================================================================================================
 // env reconstruction loss, unfused (two streaming passes over a materialised env image)      wrapperBRDFLight.py:172-188
 // ==================================================================================================================
@@ -1138,6 +1186,7 @@ TORCH_LIBRARY(sgrender, m) {
   m.def("lsregress_coef(Tensor pred, Tensor gt) -> Tensor");
   m.def("lsregress_diffspec_coef(Tensor diff, Tensor spec, Tensor im) -> Tensor");
   m.def("render_loss(Tensor diffuse, Tensor spec, Tensor im, Tensor seg, int R, int C, bool total) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
+  m.def("render_loss_finalize(Tensor diffuse, Tensor spec, Tensor parts, Tensor im_s, Tensor seg_s, Tensor coef) -> (Tensor, Tensor)");
   m.def("render_loss_bwd(Tensor? g_loss, float weight, Tensor? scale, Tensor diffuse, Tensor spec, Tensor im_s, Tensor seg_s, Tensor coef) -> (Tensor, Tensor)");
   m.def("recon_loss_parts(Tensor env, Tensor env_gt, Tensor seg_small, Tensor env_ind, float offset) -> (Tensor, Tensor, Tensor)");
   m.def("recon_loss_bwd(Tensor g_num, Tensor env, Tensor env_gt, Tensor mask, Tensor coef, float offset) -> Tensor");
@@ -1174,6 +1223,7 @@ TORCH_LIBRARY_IMPL(sgrender, CUDA, m) {
   m.impl("lsregress_diffspec_coef", &lsregress_diffspec_coef_cuda);
   m.impl("render_loss", &render_loss_cuda);
   m.impl("render_loss_bwd", &render_loss_bwd_cuda);
+  m.impl("render_loss_finalize", &render_loss_finalize_cuda);
   m.impl("recon_loss_parts", &recon_loss_parts_cuda);
   m.impl("recon_loss_bwd", &recon_loss_bwd_cuda);
   m.impl("light_heads", &light_heads_cuda);
@@ -1202,6 +1252,7 @@ TORCH_LIBRARY_IMPL(sgrender, Meta, m) {
   m.impl("lsregress_diffspec_coef", &lsregress_diffspec_coef_meta);
   m.impl("render_loss", &render_loss_meta);
   m.impl("render_loss_bwd", &render_loss_bwd_meta);
+  m.impl("render_loss_finalize", &render_loss_finalize_meta);
   m.impl("recon_loss_parts", &recon_loss_parts_meta);
   m.impl("recon_loss_bwd", &recon_loss_bwd_meta);
   m.impl("light_heads", &light_heads_meta);
@@ -1223,6 +1274,7 @@ TORCH_LIBRARY_IMPL(sgrender, Autograd, m) {
   m.impl("render_env", &render_env_autograd);
   m.impl("fused_render", &fused_render_autograd);
   m.impl("render_loss", &render_loss_autograd);
+  m.impl("render_loss_finalize", &render_loss_finalize_autograd);
   m.impl("recon_loss_parts", &recon_loss_parts_autograd);
   m.impl("light_heads", &light_heads_autograd);
   m.impl("attach_grads", &attach_grads_autograd);
@@ -1232,7 +1284,7 @@ TORCH_LIBRARY_IMPL(sgrender, Autograd, m) {
 // no CPU path: every operator raises on CPU tensors (a namespace cannot carry a backend fallback, hence one registration each)
 TORCH_LIBRARY_IMPL(sgrender, CPU, m) {
   for (const char* name : {"sg_to_env", "sg_to_env_bwd", "render_env", "render_env_bwd_env", "render_bwd_brdf", "fused_render", "fused_render_bwd_sg", "lsregress_coef",
-                           "lsregress_diffspec_coef", "render_loss", "render_loss_bwd", "recon_loss_parts", "recon_loss_bwd", "light_heads", "light_heads_bwd", "sg_shading",
+                           "lsregress_diffspec_coef", "render_loss", "render_loss_bwd", "render_loss_finalize", "recon_loss_parts", "recon_loss_bwd", "light_heads", "light_heads_bwd", "sg_shading",
                            "light_albedo_scale", "light_encoder_input", "rescale_grads_", "attach_grads", "light_objective_fwdbwd", "light_objective",
                            "light_objective_stage1", "light_objective_stage2", "light_objective_stage3"})
     m.impl(name, torch::CppFunction::makeFromBoxedFunction<&no_cpu_path>());

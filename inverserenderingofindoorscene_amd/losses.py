@@ -138,9 +138,14 @@ def render_loss(diffuse, spec, im, seg, envRow: int, envCol: int, group=None) ->
         im = F.adaptive_avg_pool2d(im, (envRow, envCol))
         seg = F.adaptive_avg_pool2d(seg, (envRow, envCol))
     if _sharded(group):
-        # this shard's [numerator, raw denominator]; their rank sums form the loss (one all-reduce of two floats, RCCL over xGMI)
-        _, _, parts, rendered, _, _, _ = _sg.render_loss(diffuse, spec, im, seg, envRow, envCol, False)
-        return combine_loss_parts(parts[0], parts[1], group, divisor=3.0), rendered
+        # this shard's [numerator, raw denominator] (three launches), their sum over the ranks (one all-reduce of two floats: RCCL over
+        # xGMI), then the loss value and its gradient scale from the GLOBAL totals (one launch; the autograd node sits on this operator:
+        # every rank gets the gradient of the global loss w.r.t. its shard).  Five launches + one collective per step, no torch glue.
+        with torch.no_grad():
+            _, _, parts, rendered, im_s, seg_s, coef = _sg.render_loss(diffuse, spec, im, seg, envRow, envCol, False)
+            dist.all_reduce(parts, op=dist.ReduceOp.SUM, group=group)
+        loss, _ = _sg.render_loss_finalize(diffuse, spec, parts, im_s, seg_s, coef)
+        return loss, rendered
     # one rank: three launches, the third pass forms the loss value itself; the backward is one more (four small launches per step
     # between the two heavy kernels of a training step, where a dozen 5-us launches would be a tenth of the step)
     loss, _, _, rendered, _, _, _ = _sg.render_loss(diffuse, spec, im, seg, envRow, envCol, True)

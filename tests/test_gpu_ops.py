@@ -45,6 +45,9 @@ def test_opcheck(sgr):
     s = torch.rand(bn, 3, R, C, device="cuda", requires_grad=True)
     torch.library.opcheck(ops.render_loss, (d, s, x["im"], x["seg"], R, C, True))
     torch.library.opcheck(ops.render_loss, (d, s, x["im"], x["seg"], R, C, False))
+    with torch.no_grad():
+        _, _, parts, _, im_s, seg_s2, coef = ops.render_loss(d, s, x["im"], x["seg"], R, C, False)
+    torch.library.opcheck(ops.render_loss_finalize, (d, s, parts, im_s, seg_s2, coef))      # the sharded route's autograd node
     xa = torch.randn(bn, 3 * K, R, C, device="cuda", requires_grad=True)
     xl = torch.randn(bn, K, R, C, device="cuda", requires_grad=True)
     xw = torch.randn(bn, 3 * K, R, C, device="cuda", requires_grad=True)
