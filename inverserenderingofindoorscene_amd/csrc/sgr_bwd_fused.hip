@@ -37,8 +37,21 @@ extern "C" int sgr_render_env_bwd_env(const float* g_diffuse, const float* g_spe
   a.dirs = reinterpret_cast<const float4*>(dirs); a.view = view; a.g_env_out = g_env;
   set_dims_b(a, bn, 0, R, C, eh, ew, imH, imW);
   a.F0 = F0;
-  const dim3 grid = wave_grid(bn, R, C), block(kWave);
   const hipStream_t st = (hipStream_t)stream;
+  // the reference's direction grids: packed half-wave kernel, whole 128-byte lines -- 88 us against the table-driven kernel's 122 (warm),
+  // 105 against 134 with cold buffers (profiles/r04f_kbench.txt); other grids (and SGR_GENERIC=1): the generic kernel below
+  if (fast_ok(a) && !sgr_generic_forced()) {
+    const dim3 grid32((unsigned)(bn * ((R * C + kPx - 1) / kPx))), block32(kWave);
+    if (ew == 16) {
+      if (imH == R) hipLaunchKernelGGL((render_genv_pk_half_kernel<1, 16, 2>), grid32, block32, 0, st, a);
+      else hipLaunchKernelGGL((render_genv_pk_half_kernel<2, 16, 2>), grid32, block32, 0, st, a);
+    } else {
+      if (imH == R) hipLaunchKernelGGL((render_genv_pk_half_kernel<1, 32, 1>), grid32, block32, 0, st, a);
+      else hipLaunchKernelGGL((render_genv_pk_half_kernel<2, 32, 1>), grid32, block32, 0, st, a);
+    }
+    return sgr_check((int)hipGetLastError(), "sgr_render_env_bwd_env");
+  }
+  const dim3 grid = wave_grid(bn, R, C), block(kWave);
   const bool vec = (a.J % 4 == 0);
   if (imH == R) {
     if (vec) hipLaunchKernelGGL((render_genv_kernel<1, true>), grid, block, 0, st, a);

@@ -909,6 +909,76 @@ __global__ __launch_bounds__(kWave, 3) void render_pk_half_kernel(const Args a) 
   }
 }
 
+// ============================== dL/dEnv of forwardEnv alone, packed half-wave (round 4) ============
+// dL/dEnv[c,j] = omega_j ndl_j (gD_c A_c/pi + gS_c spec_j) (adjoint of models.py:511-520): what the two-call drop-in sequence's backward
+// writes before sg_to_env's backward reads it.  Write-bound (1536 of 1672 B per shaded pixel go out); the generic kernel (one pixel per
+// lane, world-space terms per direction, 64-byte segments) reached 54 % of the HBM peak.  Same shape as the half-wave forward: each half
+// evaluates the BRDF terms of the half row it owns in azimuth pairs and writes them into the 32-pixel tile, which is flushed in whole
+// 128-byte lines (two table rows on the 8x16 grid, one on 16x32).
+template <int POOL, int EW, int RPF>
+__global__ __launch_bounds__(kWave, 3) void render_genv_pk_half_kernel(const Args a) {
+  constexpr int HALF = EW / 2, NQ = HALF / 4, TD = EW * RPF;
+  __shared__ __attribute__((aligned(16))) float tile[T32Out<TD>::kFloats];
+  const Pix x = locate_group32(a, (int)blockIdx.x);
+  const int lane = threadIdx.x, half = lane >> 5, pl = lane & 31;
+  const int own = 1 - half;
+  const int RC = a.R * a.C, b = x.b, p = x.p;
+  float alb[3];
+  const Frame f = load_frame<POOL>(a, x, alb);
+  PixLocal q = make_local(f, a.F0);
+  OrthoPix oq = make_ortho_pix(q);
+  const bool ortho = __all(frame_is_orthonormal(q));
+  f32x2 gds[3];                                     // (gD_c A_c / pi, gS_c)
+  {
+    const size_t o = (size_t)b * 3 * RC;
+    const unsigned up = (unsigned)p;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      gds[c] = f32x2{(a.g_diffuse + o + (size_t)c * RC)[up] * (alb[c] * kInvPi), (a.g_spec + o + (size_t)c * RC)[up]};
+  }
+  const SepTable rows = as_sep_table(a.rows);
+  const PairTable cpt = as_pair_table(a.cols, EW);
+  const XTable xt = (XTable)(a.cols + EW);
+  const size_t img = (size_t)b * 3 * RC * a.J;
+  const int eh = a.eh;
+
+  auto row_loop = [&](auto ortho_c) {
+    constexpr bool ORTHO = decltype(ortho_c)::value;
+    for (int e = 0; e < eh; ++e) {
+      if (!ORTHO) fence_row_invariants(q);
+      const RowCtx rc = make_row_ctx(q, rows[e], true);
+      OrthoRow orow = make_ortho_row(rc.ro);
+#pragma unroll 1
+      for (int aq = 0; aq < NQ; ++aq) {
+        if (ORTHO) { SGR_FENCE2(oq.vB); SGR_FENCE2(oq.ff); SGR_FENCE2(oq.vvk); SGR_FENCE2(orow.nwc); SGR_FENCE2(orow.cvc); }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) SGR_FENCE2(gds[c]);
+        const f32x4 t0 = cpt[2 * aq], t1 = cpt[2 * aq + 1];
+        const f32x2 ca[2] = {f32x2{t0[0], t0[1]}, f32x2{t1[0], t1[1]}}, sa[2] = {f32x2{t0[2], t0[3]}, f32x2{t1[2], t1[3]}};
+        f32x2 val[3][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x2 Pv = pfma(SGR_HI(oq.vB), sa[h], SGR_LO(oq.vB) * ca[h]);
+          f32x2 wt, sp;
+          shade_pair<ORTHO>(q, oq, rc, orow, own, ca[h], sa[h], Pv, xt, aq * 4 + 2 * h, wt, sp);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) val[c][h] = wt * pfma(SGR_HI(gds[c]), sp, SGR_LO(gds[c]));
+        }
+        const float e0[4] = {val[0][0].x, val[0][0].y, val[0][1].x, val[0][1].y};
+        const float e1[4] = {val[1][0].x, val[1][0].y, val[1][1].x, val[1][1].y};
+        const float e2[4] = {val[2][0].x, val[2][0].y, val[2][1].x, val[2][1].y};
+        tile32_write4<TD>(tile, pl, (e % RPF) * EW + own * HALF + aq * 4, e0, e1, e2);
+      }
+      if ((e + 1) % RPF == 0 || e + 1 == eh) {
+        __syncthreads();
+        tile32_store_global<TD>(tile, a.g_env_out + img, x.p0, RC, a.J, (e / RPF) * TD, (e % RPF + 1) * EW, lane);
+        __syncthreads();
+      }
+    }
+  };
+  if (ortho) row_loop(std::true_type{}); else row_loop(std::false_type{});
+}
+
 template <int POOL, bool HAS_GENV, bool HAS_RENDER, int EW = 16, bool HEADS = false>
 __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
   constexpr int HALF = 8, NP = 4, KPW = 6, Q = EW / 16;
