@@ -92,3 +92,29 @@ def test_torch_compile_captures_the_layer(sgr):
         env, _, lam_t, w_t = o2e.output2env(fa[3], fa[4], fa[5])
         d, s = layer.forwardEnv(fa[0], fa[1], fa[2], env)
         assert tuple(env.shape) == (bn, 3, R, C, eh, ew) and tuple(d.shape) == (bn, 3, R, C) and lam_t.shape == fa[4].shape
+
+
+def test_torch_compile_captures_layer_and_losses(sgr):
+    """Round 4: the loss / heads operators are C++ autograd nodes too -- decoder heads -> fused layer -> render loss -> unfused
+    reconstruction loss captured as ONE graph (fullgraph=True, aot_eager), values and gradients bit-identical to eager."""
+    x = _inputs(grad=False)
+    layer = sgr.renderingLayer(imWidth=C, imHeight=R)
+    g = torch.Generator().manual_seed(3)
+    raw = [(torch.randn(s, generator=g) * 0.7).cuda().requires_grad_(True) for s in ((bn, 3 * K, R, C), (bn, K, R, C), (bn, 3 * K, R, C))]
+    ind = torch.ones(bn, 1, 1, 1, device="cuda")
+
+    def objective(xa, xl, xw):
+        axis, lamb, weight, _ = sgr.light_heads(xa, xl, xw)
+        env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], axis, lamb, weight, need_env=True)
+        err, _ = sgr.render_loss(d, s, x["im"], x["seg"], R, C)
+        rec = sgr.recon_loss(env, x["env_gt"], x["seg"], ind, R, C)
+        return err + 10.0 * rec
+
+    eager = objective(*raw)
+    g_eager = torch.autograd.grad(eager, raw)
+    compiled = torch.compile(objective, fullgraph=True, backend="aot_eager")
+    out = compiled(*raw)
+    g_comp = torch.autograd.grad(out, raw)
+    assert torch.equal(out, eager)
+    for a, b in zip(g_comp, g_eager):
+        assert torch.equal(a, b)
