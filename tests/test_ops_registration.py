@@ -50,3 +50,110 @@ def test_operators_reject_cpu_tensors():
     with pytest.raises(RuntimeError, match="no CPU path"):
         torch.ops.sgrender.fused_render(z(1, 3, 2, 2), z(1, 3, 2, 2), z(1, 1, 2, 2), z(1, 2, 3, 2, 2), z(1, 2, 2, 2), z(1, 6, 2, 2),
                                         2, 4, 57.0, 0.05, [0.0, 0.0, 0.0], True, True, False)
+
+
+# --------------------------------------------------------------------------- #
+# round 4: the loss / heads / objective operators of the C++ extension          #
+# --------------------------------------------------------------------------- #
+ALL_OPS = OPS + ("lsregress_coef", "lsregress_diffspec_coef", "render_loss", "render_loss_finalize", "render_loss_bwd", "recon_loss_parts", "recon_loss_bwd",
+                 "light_heads", "light_heads_bwd", "sg_shading", "light_albedo_scale", "light_encoder_input", "rescale_grads_", "attach_grads",
+                 "light_objective_fwdbwd", "light_objective", "light_objective_stage1", "light_objective_stage2", "light_objective_stage3")
+
+
+def test_every_operator_is_registered_by_the_cpp_extension():
+    import os
+    from inverserenderingofindoorscene_amd import ops as host
+    assert os.path.basename(host.EXT_PATH) == "libsgrender_torch.so" and os.path.isfile(host.EXT_PATH)
+    for name in ALL_OPS:
+        op = getattr(torch.ops.sgrender, name).default
+        assert str(op._schema).startswith(f"sgrender::{name}("), name
+        # registered from C++ (TORCH_LIBRARY), not by a Python torch.library.custom_op
+        assert torch._C._dispatch_has_kernel_for_dispatch_key(f"sgrender::{name}", "Meta"), name
+        assert torch._C._dispatch_has_kernel_for_dispatch_key(f"sgrender::{name}", "CUDA"), name
+    assert "bool want_tan=False" in str(torch.ops.sgrender.fused_render.default._schema)      # defaulted, old call sites keep working
+
+
+def _objective_args():
+    alb, nrm, rgh = m(bn, 3, imH, imW), m(bn, 3, imH, imW), m(bn, 1, imH, imW)
+    axis, lamb, weight = m(bn, K, 3, R, C, grad=True), m(bn, K, R, C, grad=True), m(bn, 3 * K, R, C, grad=True)
+    im, seg, gt, ind = m(bn, 3, imH, imW), m(bn, 1, imH, imW), m(bn, 3, R, C, eh, ew), m(bn, 1, 1, 1)
+    return alb, nrm, rgh, axis, lamb, weight, im, seg, gt, ind
+
+
+def test_loss_and_heads_operators_fake_shapes_and_autograd():
+    ops = torch.ops.sgrender
+    d, s = m(bn, 3, R, C, grad=True), m(bn, 3, R, C, grad=True)
+    im, seg = m(bn, 3, imH, imW), m(bn, 1, imH, imW)
+    loss, scale, parts, rendered, im_s, seg_s, coef = ops.render_loss(d, s, im, seg, R, C, True)
+    assert loss.dim() == 0 and tuple(parts.shape) == (2,) and tuple(rendered.shape) == (bn, 3, R, C) and tuple(coef.shape) == (bn, 2)
+    assert loss.requires_grad and not rendered.requires_grad and not parts.requires_grad
+    gd, gs = torch.autograd.grad(loss, [d, s])
+    assert gd.shape == d.shape and gs.shape == s.shape
+    # the sharded route: totals without an autograd node, the node on the finalize operator
+    with torch.no_grad():
+        _, _, parts2, _, im_s2, seg_s2, coef2 = ops.render_loss(d, s, im, seg, R, C, False)
+    loss2, scale2 = ops.render_loss_finalize(d, s, parts2, im_s2, seg_s2, coef2)
+    assert loss2.dim() == 0 and loss2.requires_grad and not scale2.requires_grad
+    assert [t.shape for t in torch.autograd.grad(loss2, [d, s])] == [d.shape, s.shape]
+    xa, xl, xw = m(bn, 3 * K, R, C, grad=True), m(bn, K, R, C, grad=True), m(bn, 3 * K, R, C, grad=True)
+    axis, lamb, weight, packed = ops.light_heads(xa, xl, xw, True)
+    assert tuple(axis.shape) == (bn, K, 3, R, C) and tuple(packed.shape) == (bn, 7 * K, R, C)
+    g = torch.autograd.grad(axis.sum() + packed.sum(), [xa, xl, xw])
+    assert [t.shape for t in g] == [xa.shape, xl.shape, xw.shape]
+    env = m(bn, 3, R, C, eh, ew, grad=True)
+    parts3, mask, rcoef = ops.recon_loss_parts(env, m(bn, 3, R, C, eh, ew), m(bn, 1, R, C), m(bn, 1, 1, 1), 1.0)
+    assert tuple(mask.shape) == (bn, R * C) and tuple(rcoef.shape) == (bn,) and parts3.requires_grad and not mask.requires_grad
+    assert torch.autograd.grad(parts3[0], [env])[0].shape == env.shape
+    assert tuple(ops.lsregress_coef(m(bn, 3, R, C), m(bn, 3, R, C)).shape) == (bn,)
+    assert tuple(ops.lsregress_diffspec_coef(m(bn, 3, R, C), m(bn, 3, R, C), m(bn, 3, R, C)).shape) == (bn, 2)
+    assert tuple(ops.sg_shading(m(bn, K, 3, R, C), m(bn, K, R, C), m(bn, 3 * K, R, C), 16, 32, 1).shape) == (bn, 3, R, C)
+    out, alb_n, dep_n = ops.light_encoder_input(m(bn, 3, imH, imW), m(bn, 3, imH, imW), m(bn, 3, imH, imW), m(bn, 1, imH, imW), m(bn, 1, imH, imW), 48, 64)
+    assert tuple(out.shape) == (bn, 11, 48, 64) and tuple(dep_n.shape) == (bn, 1, imH, imW)
+
+
+def test_light_objective_operator_graph_and_forward_only_mode():
+    ops = torch.ops.sgrender
+    alb, nrm, rgh, axis, lamb, weight, im, seg, gt, ind = _objective_args()
+    cfg = (eh, ew, 57.0, 0.05, [0.0, 0.0, 0.0], 1.0, 10.0, 1.0, False, False)
+    obj, rerr, cerr, rendered, coef = ops.light_objective(alb, nrm, rgh, axis, lamb, weight, im, seg, gt, ind, *cfg)
+    assert obj.dim() == 0 and obj.requires_grad and not rerr.requires_grad and not cerr.requires_grad
+    assert tuple(rendered.shape) == (bn, 3, R, C) and tuple(coef.shape) == (bn,)
+    g = torch.autograd.grad(obj, [axis, lamb, weight])
+    assert [t.shape for t in g] == [axis.shape, lamb.shape, weight.shape]
+    # forward-only: no autograd node, and the gradient half of the operator is not even allocated
+    with torch.no_grad():
+        o2 = ops.light_objective(alb, nrm, rgh, axis, lamb, weight, im, seg, gt, ind, *cfg)
+    assert not o2[0].requires_grad and o2[0].grad_fn is None
+    o3 = ops.light_objective(alb, nrm, rgh, axis.detach(), lamb.detach(), weight.detach(), im, seg, gt, ind, *cfg)
+    assert not o3[0].requires_grad
+    full = ops.light_objective_fwdbwd(alb, nrm, rgh, axis.detach(), lamb.detach(), weight.detach(), im, seg, gt, ind, *cfg, False)
+    assert full[5].numel() == 0 and full[6].numel() == 0 and full[7].numel() == 0 and full[8].numel() == 0
+    full = ops.light_objective_fwdbwd(alb, nrm, rgh, axis.detach(), lamb.detach(), weight.detach(), im, seg, gt, ind, *cfg, True)
+    assert full[5].shape == axis.shape and full[6].shape == lamb.shape and full[7].shape == weight.shape and tuple(full[8].shape) == (2,)
+    # a grad-requiring BRDF map is refused at the call (trainLight mode only)
+    with pytest.raises(RuntimeError, match="SG parameters only"):
+        ops.light_objective(alb, nrm, rgh.clone().requires_grad_(True), axis, lamb, weight, im, seg, gt, ind, *cfg)
+    # the sharded route's stage operators and the node that attaches their gradients
+    st1 = ops.light_objective_stage1(alb, nrm, rgh, axis.detach(), lamb.detach(), weight.detach(), im, seg, gt, ind, eh, ew, 57.0, 0.05, [0.0, 0.0, 0.0], False, False)
+    assert len(st1) == 12 and tuple(st1[8].shape) == (4,)
+    diffuse, spec, mask, coef1, im_s, seg_s, rendered1, coef_ds, sums, ws, lam_t, w_t = st1
+    st2 = ops.light_objective_stage2(alb, nrm, rgh, axis.detach(), lamb.detach(), weight.detach(), gt, mask, coef1, diffuse, spec, im_s, seg_s, coef_ds, sums, ws,
+                                     lam_t, w_t, eh, ew, 57.0, 0.05, [0.0, 0.0, 0.0], 1.0, 10.0, 1.0, False, True)
+    assert st2[1].shape == axis.shape and tuple(st2[4].shape) == (2,)
+    objective, recon = ops.light_objective_stage3(st2[0], st2[4][0:1], sums, 1.0, 10.0, eh, ew)
+    out = ops.attach_grads(objective, axis, lamb, weight, st2[1], st2[2], st2[3], m(2))
+    assert out.requires_grad and [t.shape for t in torch.autograd.grad(out, [axis, lamb, weight])] == [axis.shape, lamb.shape, weight.shape]
+
+
+def test_every_operator_rejects_cpu_tensors():
+    z = torch.zeros
+    ops = torch.ops.sgrender
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.render_loss(z(1, 3, 2, 2), z(1, 3, 2, 2), z(1, 3, 2, 2), z(1, 1, 2, 2), 2, 2, True)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.light_heads(z(1, 6, 2, 2), z(1, 2, 2, 2), z(1, 6, 2, 2), False)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.light_objective(z(1, 3, 2, 2), z(1, 3, 2, 2), z(1, 1, 2, 2), z(1, 2, 3, 2, 2), z(1, 2, 2, 2), z(1, 6, 2, 2), z(1, 3, 2, 2), z(1, 1, 2, 2),
+                            z(1, 3, 2, 2, 8, 16), z(1, 1, 1, 1), 8, 16, 57.0, 0.05, [0.0, 0.0, 0.0], 1.0, 10.0, 1.0, False, False)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.lsregress_coef(z(1, 3, 2, 2), z(1, 3, 2, 2))
