@@ -19,6 +19,18 @@
 namespace sgr {
 
 constexpr int kRWaves = kRThreads / 64;
+#ifndef SGR_RECON_NT
+#define SGR_RECON_NT 1      // 1: the two env images are streamed with the non-temporal policy (each byte is read once per pass)
+#endif
+__device__ __forceinline__ float2 ld2(const float* p) {
+#if SGR_RECON_NT
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  const f32x2_ v = __builtin_nontemporal_load(reinterpret_cast<const f32x2_*>(p));
+  return make_float2(v.x, v.y);
+#else
+  return *reinterpret_cast<const float2*>(p);
+#endif
+}
 constexpr int kPixPerBlock = 64;
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -51,8 +63,8 @@ __global__ __launch_bounds__(kRThreads) void recon_stage0(const float* __restric
         float2 ev[3], gv[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          ev[c] = *reinterpret_cast<const float2*>(env + img + ((size_t)c * RC + p) * J + j0 + 2 * lane);
-          gv[c] = *reinterpret_cast<const float2*>(gt + img + ((size_t)c * RC + p) * J + j0 + 2 * lane);
+          ev[c] = ld2(env + img + ((size_t)c * RC + p) * J + j0 + 2 * lane);
+          gv[c] = ld2(gt + img + ((size_t)c * RC + p) * J + j0 + 2 * lane);
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -111,8 +123,8 @@ __global__ __launch_bounds__(kRThreads) void recon_stage1(const float* __restric
           float2 ev[3], gv[3];
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            ev[c] = *reinterpret_cast<const float2*>(env + img + ((size_t)c * RC + p) * J + j0 + 2 * lane);
-            gv[c] = *reinterpret_cast<const float2*>(gt + img + ((size_t)c * RC + p) * J + j0 + 2 * lane);
+            ev[c] = ld2(env + img + ((size_t)c * RC + p) * J + j0 + 2 * lane);
+            gv[c] = ld2(gt + img + ((size_t)c * RC + p) * J + j0 + 2 * lane);
           }
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
@@ -160,8 +172,8 @@ __global__ __launch_bounds__(kRThreads) void recon_bwd(const float* __restrict__
           const size_t o = img + ((size_t)c * RC + p) * J + j0 + 2 * lane;
           float2 r = make_float2(0.f, 0.f);
           if (m2 != 0.0f) {
-            const float2 ev = *reinterpret_cast<const float2*>(env + o);
-            const float2 gv = *reinterpret_cast<const float2*>(gt + o);
+            const float2 ev = ld2(env + o);
+            const float2 gv = ld2(gt + o);
             const float x0 = fmaf(cf, ev.x, offset), x1 = fmaf(cf, ev.y, offset);
             r.x = m2 * (__logf(x0) - __logf(gv.x + offset)) / x0;
             r.y = m2 * (__logf(x1) - __logf(gv.y + offset)) / x1;
