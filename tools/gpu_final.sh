@@ -12,7 +12,7 @@ echo "== kbench"; timeout 300 ./tools/kbench $LIB 16 20 > gpurun_out/kbench.txt 
 echo "== bench"; t0=$SECONDS; timeout 900 python bench.py > gpurun_out/bench.txt 2>&1; echo "bench wall $((SECONDS-t0)) s" | tee gpurun_out/bench_time.txt; tail -1 gpurun_out/bench.txt | cut -c1-2600
 echo "== bench, driver-style short warm-up"; timeout 600 python bench.py --warmup 5 --steps 20 --no-cpu-baseline --layer-only > gpurun_out/bench_warmup5.txt 2>&1; tail -1 gpurun_out/bench_warmup5.txt | cut -c1-900
 echo "== bench torchrun world=1 (RCCL init / barrier / all-reduce path)"; timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 1 --no-cpu-baseline --layer-only > gpurun_out/bench_torchrun1.txt 2>&1; tail -1 gpurun_out/bench_torchrun1.txt | cut -c1-500
-echo "== host overhead"; timeout 300 python tools/host_overhead.py 2>&1 | tail -8 | tee gpurun_out/host_overhead.txt
+echo "== host overhead"; timeout 300 python tools/host_overhead.py 2>&1 | tail -10 | tee gpurun_out/host_overhead.txt
 echo "== rocprof bench loop"; cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 20 --reps 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/rocprof.txt 2>&1; cd $GRAFT_REPO_ROOT
 for f in $(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); do cp $f gpurun_out/kernel_stats.csv; head -12 $f | cut -c1-200; done
 find gpurun_out/prof -name "*kernel_trace.csv" -size +1M -delete
