@@ -156,6 +156,9 @@ SgDims check_sg(const Tensor& axis, const Tensor& lamb, const Tensor& weight) {
   TORCH_CHECK(weight.sizes() == at::IntArrayRef({bn, 3 * k, R, C}), "sgrender: weight must be [bn,3*SGNum,envRow,envCol]=[", bn, ",", 3 * k, ",", R, ",", C,
               "], got ", weight.sizes());
   TORCH_CHECK(k <= SGR_MAX_LOBES, "sgrender: SGNum > 32 is not supported");
+  // the reference's broadcasts accept zero-sized tensors and return zero-sized ones; the kernels have no launch for them and no caller
+  // of the path produces them (dataLoader.py batches, testReal.py single images): refused here, for device and meta tensors alike
+  TORCH_CHECK(bn > 0 && k > 0 && R > 0 && C > 0, "sgrender: zero-sized SG tensors (batch, SGNum or env grid of 0) are not supported, got axis ", axis.sizes());
   return {bn, k, R, C};
 }
 struct BrdfDims { int64_t bn, h, w; };
@@ -164,6 +167,7 @@ BrdfDims check_brdf(const Tensor& albedo, const Tensor& normal, const Tensor& ro
   const int64_t bn = albedo.size(0), h = albedo.size(2), w = albedo.size(3);
   TORCH_CHECK(normal.sizes() == at::IntArrayRef({bn, 3, h, w}), "sgrender: normalPred must be [", bn, ",3,", h, ",", w, "], got ", normal.sizes());
   TORCH_CHECK(rough.sizes() == at::IntArrayRef({bn, 1, h, w}), "sgrender: roughPred must be [", bn, ",1,", h, ",", w, "], got ", rough.sizes());
+  TORCH_CHECK(bn > 0 && h > 0 && w > 0, "sgrender: zero-sized BRDF maps (batch or image of 0) are not supported, got diffusePred ", albedo.sizes());
   return {bn, h, w};
 }
 void check_cam(Cam cam) { TORCH_CHECK(cam.size() == 3, "sgrender: cameraPos must have three components"); }

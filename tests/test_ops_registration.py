@@ -52,6 +52,16 @@ def test_operators_reject_cpu_tensors():
                                         2, 4, 57.0, 0.05, [0.0, 0.0, 0.0], True, True, False)
 
 
+def test_zero_sized_inputs_are_refused_for_fake_and_device_tensors_alike():
+    """the reference's broadcasts would return zero-sized results; the kernels have no launch for them: refused with a message, and
+    by the shape function too, so that a traced graph cannot pass tracing and then fail on the device"""
+    e = lambda *s: torch.empty(*s, device="meta")
+    with pytest.raises(RuntimeError, match="zero-sized SG tensors"):
+        torch.ops.sgrender.sg_to_env(e(0, 12, 3, 4, 4), e(0, 12, 4, 4), e(0, 36, 4, 4), 8, 16, True, False)
+    with pytest.raises(RuntimeError, match="zero-sized BRDF maps"):
+        torch.ops.sgrender.render_env(e(0, 3, 8, 8), e(0, 3, 8, 8), e(0, 1, 8, 8), e(0, 3, 4, 4, 8, 16), 57.0, 0.05, [0.0, 0.0, 0.0])
+
+
 # --------------------------------------------------------------------------- #
 # round 4: the loss / heads / objective operators of the C++ extension          #
 # --------------------------------------------------------------------------- #
