@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SGR_ABI_VERSION 4
+#define SGR_ABI_VERSION 5
 #define SGR_MAX_LOBES 32
 
 #define SGR_OK 0
@@ -171,6 +171,16 @@ int sgr_render_loss_fwd_total(const float* diffuse, const float* spec, const flo
                               float* im_small, float* seg_small, float* rendered, float* coef, float* parts,
                               float* loss /* [1], nullable */, float* scale /* [1], nullable */, float divisor,
                               float* workspace, int bn, int R, int C, int imH, int imW, void* stream);
+
+/* ABI 5.  sgr_render_loss_fwd_total on one rank (loss / scale required) that also writes
+ *   g_diffuse, g_spec [bn,3,R,C] = weight * d loss / d{diffuse, spec}
+ * from its third pass -- bit-identical to sgr_render_loss_bwd_scaled(NULL, weight, scale, ...) without that fourth launch.  For callers
+ * that form their gradients ahead of the backward call (the fused light objective: wrapperBRDFLight.py:192-207 + trainLight.py:237). */
+int sgr_render_loss_fwd_total_grads(const float* diffuse, const float* spec, const float* im, const float* seg,
+                                    float* im_small, float* seg_small, float* rendered, float* coef, float* parts,
+                                    float* loss /* [1] */, float* scale /* [1] */, float divisor, float weight,
+                                    float* g_diffuse, float* g_spec,
+                                    float* workspace, int bn, int R, int C, int imH, int imW, void* stream);
 
 /* d parts[0] / d{diffuse, spec} times *g_num (a device scalar); coefficients are constants as in
  * the reference (detached, models.py:54,76; wrapperBRDFLight.py:197-201). */

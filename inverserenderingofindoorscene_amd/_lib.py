@@ -18,7 +18,7 @@ from ctypes import c_char_p, c_float, c_int, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SGR_LIB", os.path.join(_HERE, "libsgrender.so"))
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class SgrenderUnavailable(RuntimeError):
@@ -53,6 +53,7 @@ SIGNATURES = {
     "sgr_loss_workspace_floats": ([_I], c_int),
     "sgr_render_loss_fwd": ([_P] * 10 + [_I] * 5 + [_P], c_int),
     "sgr_render_loss_fwd_total": ([_P] * 11 + [_F, _P] + [_I] * 5 + [_P], c_int),
+    "sgr_render_loss_fwd_total_grads": ([_P] * 11 + [_F, _F, _P, _P, _P] + [_I] * 5 + [_P], c_int),
     "sgr_render_loss_bwd": ([_P] * 8 + [_I] * 3 + [_P], c_int),
     "sgr_loss_finalize": ([_P, _P, _P, _F, _P], c_int),
     "sgr_objective_finalize": ([_P, _P, _F, _F, _F, _P, _P, _P], c_int),

@@ -495,7 +495,7 @@ static int fused_fwd_recon_impl(const float* albedo, const float* normal, const 
   }
   hipLaunchKernelGGL(recon_fold0, dim3(bn), dim3(kRThreads), 0, st, ws0, coef, den_img, tiles);
   if (parts)      // (0, local sum of the env mask): what a sharded caller all-reduces before the backward pass; nobody else needs it
-    hipLaunchKernelGGL(recon_fold1, dim3(1), dim3(kRThreads), 0, st, ws0, den_img, parts, bn, 0, ObjectiveTail{});
+    hipLaunchKernelGGL(recon_fold1, dim3(1), dim3(kFold1Threads), 0, st, ws0, den_img, parts, bn, 0, ObjectiveTail{});
   return sgr_check((int)hipGetLastError(), "sgr_fused_fwd_recon");
 }
 
@@ -583,7 +583,7 @@ static int fused_bwd_recon_impl(const float* albedo, const float* normal, const 
     else SGR_LAUNCH_BR(32, 4);
 #undef SGR_LAUNCH_BR
   }
-  hipLaunchKernelGGL(recon_fold1, dim3(1), dim3(kRThreads), 0, st, ws1, den_img, parts, bn, tiles, tail);     // parts = (loss numerator, local sum of the env mask)
+  hipLaunchKernelGGL(recon_fold1, dim3(1), dim3(kFold1Threads), 0, st, ws1, den_img, parts, bn, tiles, tail);     // parts = (loss numerator, local sum of the env mask)
   return sgr_check((int)hipGetLastError(), "sgr_fused_bwd_recon");
 }
 

@@ -155,18 +155,43 @@ __device__ __forceinline__ void finalize_pair(const float num, const float den_r
   loss[0] = num / den / divisor;
   scale[0] = 1.0f / den / divisor;
 }
+// sum of the pooled object mask over the shard (stage A's sixth partial of every workgroup), in double, thread t adding partials
+// t, t + 256, ... and a fixed LDS tree: the same value in whichever workgroup evaluates it
+__device__ __forceinline__ double shard_mask_total(const float* __restrict__ wsA, int nparts_a, double* lds /* [kLossThreads] */) {
+  double den = 0.0;
+  for (int i = threadIdx.x; i < nparts_a; i += kLossThreads) den += (double)wsA[(size_t)i * 6 + 5];
+  lds[threadIdx.x] = den;
+  __syncthreads();
+  for (int s = kLossThreads / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) lds[threadIdx.x] += lds[threadIdx.x + s];
+    __syncthreads();
+  }
+  const double r = lds[0];
+  __syncthreads();
+  return r;
+}
 // ---- stage C: final coefficients, rendered image, masked squared error -------------------------
+// g_diffuse / g_spec (nullable; one rank, loss != NULL): weight * d loss / d{diffuse, spec} in the same pass -- what loss_bwd would
+// produce from the saved images in a fifth launch (the fused light objective asks for it: its gradients are formed ahead of the
+// backward call).  The scale 1 / max(den, 1e-5) / divisor needs the shard's mask total, which stage A left in wsA: every workgroup
+// folds it (1 024 floats at config 2) the way the last arrival does.
 __global__ __launch_bounds__(kLossThreads) void loss_stage_c(const float* __restrict__ diffuse, const float* __restrict__ spec,
                                                               const float* __restrict__ im_s, const float* __restrict__ seg_s,
                                                               const float* __restrict__ wsA, const float* __restrict__ wsB,
                                                               float* __restrict__ coef /* [bn,2] */, float* __restrict__ rendered,
                                                               float* __restrict__ wsC /* [bn,kSplit] */, int RC, unsigned* __restrict__ ticket,
                                                               float* __restrict__ parts, float* __restrict__ loss, float* __restrict__ scale,
-                                                              float divisor) {
+                                                              float divisor, float weight, float* __restrict__ g_diffuse,
+                                                              float* __restrict__ g_spec) {
   __shared__ float lds[4];
   __shared__ double fold_lds[kLossThreads * 2];
   __shared__ unsigned last;
   const int b = blockIdx.y, n = 3 * RC;
+  float gn = 0.0f;
+  if (g_diffuse) {
+    const float den = fmaxf((float)shard_mask_total(wsA, (int)gridDim.y * kSplitA, fold_lds), 1e-5f);
+    gn = weight * (1.0f / den / divisor);      // finalize_pair's scale, loss_bwd's product
+  }
   double sA[6], sB[2];
   fold_a(wsA, b, sA);
   fold<2>(wsB, b, sB);
@@ -183,10 +208,16 @@ __global__ __launch_bounds__(kLossThreads) void loss_stage_c(const float* __rest
   for (int i = blockIdx.x * kLossThreads + threadIdx.x; i < n; i += kSplit * kLossThreads) {
     const size_t o = (size_t)b * n + i;
     const int p = i % RC;
-    const float r = fminf(fmaxf(kd * diffuse[o] + ks * spec[o], 0.0f), 1.0f);
+    const float raw = kd * diffuse[o] + ks * spec[o];
+    const float r = fminf(fmaxf(raw, 0.0f), 1.0f);
     rendered[o] = r;
-    const float e = r - im_s[o];
-    acc[0] = fmaf(e * e, seg_s[(size_t)b * RC + p], acc[0]);
+    const float e = r - im_s[o], sg = seg_s[(size_t)b * RC + p];
+    acc[0] = fmaf(e * e, sg, acc[0]);
+    if (g_diffuse) {
+      const float g = (raw >= 0.0f && raw <= 1.0f) ? 2.0f * e * sg * gn : 0.0f;
+      g_diffuse[o] = g * kd;
+      g_spec[o] = g * ks;
+    }
   }
   block_reduce<1>(acc, lds);
   // The batch totals [num, den_raw] of this rank's shard, by whichever workgroup arrives last (no fourth launch): every
@@ -204,21 +235,17 @@ __global__ __launch_bounds__(kLossThreads) void loss_stage_c(const float* __rest
   }
   __syncthreads();      // workgroup-scope release / acquire: the other waves of the last workgroup inherit thread 0's view
   if (!last) return;
-  double num = 0.0, den = 0.0;
+  const double den = shard_mask_total(wsA, (int)gridDim.y * kSplitA, fold_lds);      // stage A's partials: a kernel boundary away
+  double num = 0.0;
   for (int i = threadIdx.x; i < nparts; i += kLossThreads) num += (double)__hip_atomic_load(&wsC[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  for (int i = threadIdx.x; i < (int)gridDim.y * kSplitA; i += kLossThreads) den += (double)wsA[(size_t)i * 6 + 5];      // stage A's: a kernel boundary away
-  fold_lds[threadIdx.x * 2] = num;
-  fold_lds[threadIdx.x * 2 + 1] = den;
+  fold_lds[threadIdx.x] = num;
   __syncthreads();
   for (int s = kLossThreads / 2; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) {
-      fold_lds[threadIdx.x * 2] += fold_lds[(threadIdx.x + s) * 2];
-      fold_lds[threadIdx.x * 2 + 1] += fold_lds[(threadIdx.x + s) * 2 + 1];
-    }
+    if ((int)threadIdx.x < s) fold_lds[threadIdx.x] += fold_lds[threadIdx.x + s];
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    const float fnum = (float)fold_lds[0], fden = (float)fold_lds[1];
+    const float fnum = (float)fold_lds[0], fden = (float)den;
     parts[0] = fnum;
     parts[1] = fden;
     if (loss) finalize_pair(fnum, fden, divisor, loss, scale);
@@ -335,10 +362,9 @@ using namespace sgr;
 
 extern "C" int sgr_loss_workspace_floats(int bn) { return bn * (kSplitA * 6 + kSplit * (2 + 1)) + 1; }      // + the arrival counter
 
-extern "C" int sgr_render_loss_fwd_total(const float* diffuse, const float* spec, const float* im, const float* seg,
-                                         float* im_small, float* seg_small, float* rendered, float* coef, float* parts,
-                                         float* loss, float* scale, float divisor, float* workspace, int bn, int R, int C,
-                                         int imH, int imW, void* stream) {
+static int render_loss_fwd_impl(const float* diffuse, const float* spec, const float* im, const float* seg, float* im_small, float* seg_small,
+                                float* rendered, float* coef, float* parts, float* loss, float* scale, float divisor, float weight,
+                                float* g_diffuse, float* g_spec, float* workspace, int bn, int R, int C, int imH, int imW, void* stream) {
   SGR_REQUIRE(diffuse && spec && im && seg && im_small && seg_small && rendered && coef && parts && workspace,
               "sgr_render_loss_fwd: NULL tensor");
   SGR_REQUIRE((loss == nullptr) == (scale == nullptr) && (!loss || divisor > 0.0f), "sgr_render_loss_fwd: loss / scale / divisor");
@@ -358,8 +384,25 @@ extern "C" int sgr_render_loss_fwd_total(const float* diffuse, const float* spec
     hipLaunchKernelGGL((loss_stage_a<2>), dim3(kSplitA, bn), block, 0, st, diffuse, spec, im, seg, im_small, seg_small, wsA, ticket, R, C, imH, imW);
   hipLaunchKernelGGL(loss_stage_b, grid, block, 0, st, diffuse, spec, im_small, wsA, wsB, 3 * RC);
   hipLaunchKernelGGL(loss_stage_c, grid, block, 0, st, diffuse, spec, im_small, seg_small, wsA, wsB, coef, rendered, wsC, RC, ticket, parts,
-                     loss, scale, divisor);
+                     loss, scale, divisor, weight, g_diffuse, g_spec);
   return sgr_check((int)hipGetLastError(), "sgr_render_loss_fwd");
+}
+
+extern "C" int sgr_render_loss_fwd_total(const float* diffuse, const float* spec, const float* im, const float* seg, float* im_small,
+                                         float* seg_small, float* rendered, float* coef, float* parts, float* loss, float* scale,
+                                         float divisor, float* workspace, int bn, int R, int C, int imH, int imW, void* stream) {
+  return render_loss_fwd_impl(diffuse, spec, im, seg, im_small, seg_small, rendered, coef, parts, loss, scale, divisor, 0.0f, nullptr, nullptr,
+                              workspace, bn, R, C, imH, imW, stream);
+}
+
+// one rank, loss value AND weight * d loss / d{diffuse, spec} in the three launches (ABI 5; the fused light objective)
+extern "C" int sgr_render_loss_fwd_total_grads(const float* diffuse, const float* spec, const float* im, const float* seg, float* im_small,
+                                               float* seg_small, float* rendered, float* coef, float* parts, float* loss, float* scale,
+                                               float divisor, float weight, float* g_diffuse, float* g_spec, float* workspace, int bn,
+                                               int R, int C, int imH, int imW, void* stream) {
+  SGR_REQUIRE(loss && scale && g_diffuse && g_spec, "sgr_render_loss_fwd_total_grads: NULL output (the gradient needs the one-rank loss / scale pair)");
+  return render_loss_fwd_impl(diffuse, spec, im, seg, im_small, seg_small, rendered, coef, parts, loss, scale, divisor, weight, g_diffuse, g_spec,
+                              workspace, bn, R, C, imH, imW, stream);
 }
 
 extern "C" int sgr_render_loss_fwd(const float* diffuse, const float* spec, const float* im, const float* seg,

@@ -220,7 +220,7 @@ extern "C" int sgr_recon_loss_fwd(const float* env, const float* env_gt, const f
   hipLaunchKernelGGL(recon_stage0, grid, block, 0, st, env, env_gt, seg_small, env_ind, mask, ws0, RC, J, nblk);
   hipLaunchKernelGGL(recon_fold0, dim3(bn), dim3(kRThreads), 0, st, ws0, coef, den_img, nblk);
   hipLaunchKernelGGL(recon_stage1, grid, block, 0, st, env, env_gt, mask, coef, ws1, RC, J, nblk, offset);
-  hipLaunchKernelGGL(recon_fold1, dim3(1), dim3(kRThreads), 0, st, ws1, den_img, parts, bn, nblk, ObjectiveTail{});
+  hipLaunchKernelGGL(recon_fold1, dim3(1), dim3(kFold1Threads), 0, st, ws1, den_img, parts, bn, nblk, ObjectiveTail{});
   return sgr_check((int)hipGetLastError(), "sgr_recon_loss_fwd");
 }
 

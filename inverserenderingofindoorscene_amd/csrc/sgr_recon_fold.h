@@ -30,10 +30,17 @@ static __global__ __launch_bounds__(kRThreads) void recon_fold0(const float* __r
   __shared__ double lds[kRThreads * 3];
   const int b = blockIdx.x;
   double v[3] = {0.0, 0.0, 0.0};
-  for (int i = threadIdx.x; i < nblk; i += kRThreads) {
-    v[0] += (double)ws[((size_t)b * nblk + i) * 3 + 0];
-    v[1] += (double)ws[((size_t)b * nblk + i) * 3 + 1];
-    v[2] += (double)ws[((size_t)b * nblk + i) * 3 + 2];
+  // four triples requested together per round (600 partials per image at config 2: one round), added in index order as before
+  for (int i = threadIdx.x; i < nblk; i += 4 * kRThreads) {
+    float t[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool in = i + j * kRThreads < nblk;
+      const float* q = ws + ((size_t)b * nblk + (in ? i + j * kRThreads : i)) * 3;
+      t[j][0] = in ? q[0] : 0.0f; t[j][1] = in ? q[1] : 0.0f; t[j][2] = in ? q[2] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[0] += (double)t[j][0]; v[1] += (double)t[j][1]; v[2] += (double)t[j][2]; }
   }
   block_sum_double<3>(v, lds);
   if (threadIdx.x == 0) {
@@ -46,25 +53,40 @@ static __global__ __launch_bounds__(kRThreads) void recon_fold0(const float* __r
 //   reconstErr = num / max(den, 1e-5) / divisor (wrapperBRDFLight.py:179-188), objective = ren_w renderErr + rec_w reconstErr (trainLight.py:237)
 struct ObjectiveTail { const float* render_err; float ren_w, rec_w, divisor_e; float* objective; float* recon_err; float* one; };
 
-static __global__ __launch_bounds__(kRThreads) void recon_fold1(const float* __restrict__ ws, const float* __restrict__ den_img,
-                                                          float* __restrict__ parts, int bn, int nblk, ObjectiveTail tail) {
-  __shared__ double lds[kRThreads * 2];
-  // four independent partial sums per thread (loads of one round in flight together: a single dependent chain over 9 600 partials
-  // was 13.8 us of pure latency in the training loop), combined in a fixed order
-  double v[2] = {0.0, 0.0}, w1 = 0.0, w2 = 0.0, w3 = 0.0;
+// One workgroup of 1024 threads (round 4; 256 before).  Thread t owns partials t, t + 1024, ...: eight of them requested together, each
+// added to its own double accumulator, the eight combined in a fixed order, then the fixed LDS tree -- the result depends on n alone.
+// The wave trace showed this kernel as 13 us of pure memory latency behind the objective's 320 us backward (ten dependent rounds of four
+// loads on four waves); 9 600 partials are now two rounds on sixteen waves.
+constexpr int kFold1Threads = 1024;
+static __global__ __launch_bounds__(kFold1Threads) void recon_fold1(const float* __restrict__ ws, const float* __restrict__ den_img,
+                                                              float* __restrict__ parts, int bn, int nblk, ObjectiveTail tail) {
+  __shared__ double lds[kFold1Threads * 2];
+  constexpr int kInFlight = 8;
+  double w[kInFlight];
+#pragma unroll
+  for (int j = 0; j < kInFlight; ++j) w[j] = 0.0;
   const int n = bn * nblk;
-  for (int i = threadIdx.x; i < n; i += 4 * kRThreads) {
-    const float a0 = ws[i];
-    const float a1 = i + kRThreads < n ? ws[i + kRThreads] : 0.0f;
-    const float a2 = i + 2 * kRThreads < n ? ws[i + 2 * kRThreads] : 0.0f;
-    const float a3 = i + 3 * kRThreads < n ? ws[i + 3 * kRThreads] : 0.0f;
-    v[0] += (double)a0; w1 += (double)a1; w2 += (double)a2; w3 += (double)a3;
+  for (int i = threadIdx.x; i < n; i += kInFlight * kFold1Threads) {
+    float a[kInFlight];
+#pragma unroll
+    for (int j = 0; j < kInFlight; ++j) a[j] = i + j * kFold1Threads < n ? ws[i + j * kFold1Threads] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < kInFlight; ++j) w[j] += (double)a[j];
   }
-  v[0] = (v[0] + w1) + (w2 + w3);
-  for (int i = threadIdx.x; i < bn; i += kRThreads) v[1] += (double)den_img[i];
-  block_sum_double<2>(v, lds);
+  double v[2] = {((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7])), 0.0};
+  for (int i = threadIdx.x; i < bn; i += kFold1Threads) v[1] += (double)den_img[i];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) lds[threadIdx.x * 2 + i] = v[i];
+  __syncthreads();
+  for (int s = kFold1Threads / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      lds[threadIdx.x * 2] += lds[(threadIdx.x + s) * 2];
+      lds[threadIdx.x * 2 + 1] += lds[(threadIdx.x + s) * 2 + 1];
+    }
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
-    const float num = (float)v[0], den = (float)v[1];
+    const float num = (float)lds[0], den = (float)lds[1];
     parts[0] = num;
     parts[1] = den;
     if (tail.objective) {

@@ -64,7 +64,7 @@ using Cam = at::ArrayRef<double>;
   X(sgr_abi_version) X(sgr_last_error) X(sgr_dirs_floats) X(sgr_fill_direction_table) X(sgr_fill_view_vectors)                   \
   X(sgr_sg_to_env_fwd) X(sgr_render_env_fwd) X(sgr_fused_fwd_tan) X(sgr_sg_to_env_bwd) X(sgr_fused_bwd_sg)                        \
   X(sgr_render_env_bwd_env) X(sgr_render_bwd_brdf) X(sgr_loss_workspace_floats) X(sgr_render_loss_fwd)                           \
-  X(sgr_render_loss_fwd_total) X(sgr_loss_finalize) X(sgr_objective_finalize) X(sgr_render_loss_bwd_scaled)                      \
+  X(sgr_render_loss_fwd_total) X(sgr_render_loss_fwd_total_grads) X(sgr_loss_finalize) X(sgr_objective_finalize) X(sgr_render_loss_bwd_scaled)                      \
   X(sgr_lsregress_coef) X(sgr_lsregress_diffspec_coef) X(sgr_sg_shading) X(sgr_recon_workspace_floats) X(sgr_recon_loss_fwd)     \
   X(sgr_recon_loss_bwd) X(sgr_fused_recon_supported) X(sgr_heads_prologue_supported) X(sgr_fused_recon_workspace_floats)         \
   X(sgr_fused_fwd_recon_seg) X(sgr_light_heads_fwd) X(sgr_light_heads_bwd) X(sgr_rescale_inplace_flip) X(sgr_fused_bwd_recon)    \
@@ -1012,15 +1012,18 @@ T9 light_objective_fwdbwd_cuda(const Tensor& albedo, const Tensor& normal, const
   ok(A.sgr_fused_fwd_recon_seg(rp(a), rp(n), rp(r), rp(ax), rp(la), rp(we), rp(dirs), rp(view), rp(gt), rp(sg), (int)d.imH, (int)d.imW, rp(ind), wp(lam_t), wp(w_t),
                                wp(diffuse), wp(spec), wp(mask), wp(coef), nullptr, wp(ws), bn, K, R, C, (int)eh, (int)ew, (int)d.h, (int)d.w, (float)F0, pm, st),
      "sgr_fused_fwd_recon");
-  ok(A.sgr_render_loss_fwd_total(rp(diffuse), rp(spec), rp(i), rp(sg), wp(im_s), wp(seg_s), wp(rendered), wp(coef_ds), wp(parts_r), render_err.data_ptr<float>(),
-                                 wp(scale_r), 3.0f, wp(ws_r), bn, R, C, (int)d.imH, (int)d.imW, st),
-     "sgr_render_loss_fwd");
   Tensor g_axis = none_like(a), g_lamb = none_like(a), g_weight = none_like(a), applied = none_like(a), g_d, g_s;
   if (need_grad) {
+    // ren_w * d renderErr / d{diffuse, spec} comes out of the render loss's third pass (no loss_bwd launch between the two heavy kernels)
     g_axis = at::empty_like(ax); g_lamb = at::empty_like(la); g_weight = at::empty_like(we); applied = at::empty({2}, o);
     g_d = at::empty_like(diffuse); g_s = at::empty_like(spec);
-    ok(A.sgr_render_loss_bwd_scaled(nullptr, (float)ren_w, rp(scale_r), rp(diffuse), rp(spec), rp(im_s), rp(seg_s), rp(coef_ds), wp(g_d), wp(g_s), bn, R, C, st),
-       "sgr_render_loss_bwd");
+    ok(A.sgr_render_loss_fwd_total_grads(rp(diffuse), rp(spec), rp(i), rp(sg), wp(im_s), wp(seg_s), wp(rendered), wp(coef_ds), wp(parts_r),
+                                         render_err.data_ptr<float>(), wp(scale_r), 3.0f, (float)ren_w, wp(g_d), wp(g_s), wp(ws_r), bn, R, C, (int)d.imH, (int)d.imW, st),
+       "sgr_render_loss_fwd");
+  } else {
+    ok(A.sgr_render_loss_fwd_total(rp(diffuse), rp(spec), rp(i), rp(sg), wp(im_s), wp(seg_s), wp(rendered), wp(coef_ds), wp(parts_r), render_err.data_ptr<float>(),
+                                   wp(scale_r), 3.0f, wp(ws_r), bn, R, C, (int)d.imH, (int)d.imW, st),
+       "sgr_render_loss_fwd");
   }
   ok(A.sgr_fused_bwd_recon_total(rp(a), rp(n), rp(r), rp(ax), handoff ? rp(lam_t) : rp(la), handoff ? rp(w_t) : rp(we), rp(dirs), rp(view), rp(gt), rp(mask), rp(coef),
                                  rp(g_d), rp(g_s), wp(g_axis), wp(g_lamb), wp(g_weight), wp(parts_b), wp(ws), bn, K, R, C, (int)eh, (int)ew, (int)d.h, (int)d.w,

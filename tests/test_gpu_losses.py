@@ -208,3 +208,46 @@ def test_last_arriving_workgroup_fold_over_many_launches(sgr):
             _, _, parts2, _, _, _, _ = ops.render_loss(d, s, im, seg, R, C, False)
             assert torch.equal(parts2, parts), it
     print(f"last-arriving fold: worst relative deviation of the totals over 400 launches {worst:.2e}")
+
+
+@pytest.mark.parametrize("bn,imH,imW,R,C", [(16, 240, 320, 120, 160), (3, 18, 26, 9, 13), (2, 12, 20, 12, 20)])
+def test_render_loss_third_pass_gradients_equal_the_separate_backward(sgr, bn, imH, imW, R, C):
+    """ABI 5: sgr_render_loss_fwd_total_grads writes weight * d loss / d{diffuse, spec} from its third pass (the fused light objective
+    has no loss_bwd launch between its two heavy kernels).  Bit-identical to the three passes followed by sgr_render_loss_bwd_scaled,
+    and the loss-side outputs are untouched by the extra stores."""
+    from inverserenderingofindoorscene_amd import _lib
+    from inverserenderingofindoorscene_amd.ops import _ptr, _stream
+    lib = _lib.load()
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cuda").manual_seed(5 + bn)
+    d = torch.rand(bn, 3, R, C, device=dev, generator=g) * 1.5
+    s = torch.rand(bn, 3, R, C, device=dev, generator=g) * 0.6
+    im = torch.rand(bn, 3, imH, imW, device=dev, generator=g)
+    seg = (torch.rand(bn, 1, imH, imW, device=dev, generator=g) < 0.9).float()
+    weight = 0.37
+
+    def outputs():
+        e = lambda *sh: torch.empty(*sh, device=dev)
+        return dict(im_s=e(bn, 3, R, C), seg_s=e(bn, 1, R, C), rendered=e(bn, 3, R, C), coef=e(bn, 2), parts=e(2), loss=e(1), scale=e(1),
+                    gd=e(bn, 3, R, C), gs=e(bn, 3, R, C), ws=e(lib.sgr_loss_workspace_floats(bn)))
+
+    a, b = outputs(), outputs()
+    st = _stream(dev)
+    rc = lib.sgr_render_loss_fwd_total(_ptr(d), _ptr(s), _ptr(im), _ptr(seg), _ptr(a["im_s"]), _ptr(a["seg_s"]), _ptr(a["rendered"]), _ptr(a["coef"]),
+                                       _ptr(a["parts"]), _ptr(a["loss"]), _ptr(a["scale"]), 3.0, _ptr(a["ws"]), bn, R, C, imH, imW, st)
+    assert rc == 0
+    rc = lib.sgr_render_loss_bwd_scaled(None, weight, _ptr(a["scale"]), _ptr(d), _ptr(s), _ptr(a["im_s"]), _ptr(a["seg_s"]), _ptr(a["coef"]), _ptr(a["gd"]),
+                                        _ptr(a["gs"]), bn, R, C, st)
+    assert rc == 0
+    rc = lib.sgr_render_loss_fwd_total_grads(_ptr(d), _ptr(s), _ptr(im), _ptr(seg), _ptr(b["im_s"]), _ptr(b["seg_s"]), _ptr(b["rendered"]), _ptr(b["coef"]),
+                                             _ptr(b["parts"]), _ptr(b["loss"]), _ptr(b["scale"]), 3.0, weight, _ptr(b["gd"]), _ptr(b["gs"]), _ptr(b["ws"]),
+                                             bn, R, C, imH, imW, st)
+    assert rc == 0
+    torch.cuda.synchronize()
+    for k in ("im_s", "seg_s", "rendered", "coef", "parts", "loss", "scale", "gd", "gs"):
+        assert torch.equal(a[k], b[k]), (k, (a[k] - b[k]).abs().max().item())
+    assert a["gd"].abs().max().item() > 0 and torch.isfinite(a["gd"]).all()
+    # the one-rank pair is required: NULL loss / scale is refused
+    rc = lib.sgr_render_loss_fwd_total_grads(_ptr(d), _ptr(s), _ptr(im), _ptr(seg), _ptr(b["im_s"]), _ptr(b["seg_s"]), _ptr(b["rendered"]), _ptr(b["coef"]),
+                                             _ptr(b["parts"]), None, None, 3.0, weight, _ptr(b["gd"]), _ptr(b["gs"]), _ptr(b["ws"]), bn, R, C, imH, imW, st)
+    assert rc != 0

@@ -73,6 +73,24 @@ int main(int argc, char** argv) {
   run("fwd_env", wfe, [&] { return sgr_fused_fwd_p(albedo, normal, rough, axis, lamb, weight, dirs, view, env, diffuse, spec, bn, K, R, C, eh, ew, imH, imW, 0.05f, 1, st); });
   run("fwd_noenv", w64, [&] { return sgr_fused_fwd_p(albedo, normal, rough, axis, lamb, weight, dirs, view, (float*)nullptr, diffuse, spec, bn, K, R, C, eh, ew, imH, imW, 0.05f, 1, st); });
   run("bwd_genv", w32, [&] { return sgr_fused_bwd_sg_p(g_env, g_d, g_s, albedo, normal, rough, axis, lamb, weight, dirs, view, g_axis, g_lamb, g_weight, bn, K, R, C, eh, ew, imH, imW, 0.05f, 1, st); });
+  // round 4: the fused objective's kernels (a trace build whose sgr_fused_recon.hip carries the trace points exports sgr_debug_trace_recon)
+  if (set_t set_rec = (set_t)dlsym(lib, "sgr_debug_trace_recon")) {
+    SYM(sgr_fused_fwd_recon) SYM(sgr_fused_bwd_recon) SYM(sgr_fused_recon_workspace_floats)
+    set_rec(trace);
+    float* env_gt = dev_rand(P * 3 * J, 0, 2, 21); float* seg_small = dev_rand(P, 1, 1, 22); float* env_ind = dev_rand(bn, 1, 1, 23);
+    float* mask = dev_empty(P); float* coef = dev_empty(bn); float* parts = dev_empty(8);
+    float* wsr = dev_empty((size_t)sgr_fused_recon_workspace_floats_p(bn, R, C));
+    for (int pm = 1; pm <= 3; pm += 2) {
+      char nm[64];
+      snprintf(nm, sizeof nm, "obj_fwd_premap%d", pm);
+      run(nm, pm == 3 ? w32 : w64, [&] { return sgr_fused_fwd_recon_p(albedo, normal, rough, axis, lamb, weight, dirs, view, env_gt, seg_small, env_ind, diffuse, spec, mask, coef,
+                                                                     parts, wsr, bn, K, R, C, eh, ew, imH, imW, 0.05f, pm, st); });
+      snprintf(nm, sizeof nm, "obj_bwd_premap%d", pm);
+      run(nm, w32, [&] { return sgr_fused_bwd_recon_p(albedo, normal, rough, axis, lamb, weight, dirs, view, env_gt, mask, coef, (const float*)nullptr, g_d, g_s, g_axis, g_lamb,
+                                                      g_weight, parts, wsr, bn, K, R, C, eh, ew, imH, imW, 0.05f, pm, 1.0f, 10.0f, st); });
+    }
+    set_fwd(trace);
+  }
   // inter-kernel gap: forward and backward back to back (separate trace buffers, absolute timestamps)
   TraceRec* trace2; CHECK(hipMalloc(&trace2, sizeof(TraceRec) * max_waves));
   set_fwd(trace); set_bwd(trace2);
