@@ -25,7 +25,8 @@ namespace sgr {
 // raising the priority of the data-movement phases as well (env tile flush, cotangent row requests) changed nothing; issuing every
 // prologue load before the first use (lobes, BRDF maps, cotangents in one burst) changed nothing either -- the latencies are hidden by
 // the other waves already; and in the objective's backward kernel the same priority made the step 1-2 % SLOWER, so that one stays at
-// the default.  0 = hardware default.
+// the default.  Round 4: nor do the objective's forward (statistics) kernels -- without it the objective step is 3-6 us faster in the loop
+// (profiles/r04q_prio_bench.txt) -- so the forward bodies raise the priority only when they are not the HAS_GT variant.  0 = hardware default.
 #ifndef SGR_PROLOGUE_PRIO
 #define SGR_PROLOGUE_PRIO 3
 #endif
@@ -54,6 +55,14 @@ static __device__ TraceRec* g_trace = nullptr;
 #define SGR_TRACE_BEGIN SGR_PRIO_PROLOGUE
 #define SGR_TRACE_MARK SGR_PRIO_LOOP
 #define SGR_TRACE_END
+#endif
+// the forward bodies: priority (or trace point) unless `quiet` (a compile-time constant)
+#ifdef SGR_TRACE
+#define SGR_TRACE_BEGIN_UNLESS(quiet) SGR_TRACE_BEGIN
+#define SGR_TRACE_MARK_UNLESS(quiet) SGR_TRACE_MARK
+#else
+#define SGR_TRACE_BEGIN_UNLESS(quiet) if (!(quiet)) { SGR_PRIO_PROLOGUE }
+#define SGR_TRACE_MARK_UNLESS(quiet) if (!(quiet)) { SGR_PRIO_LOOP }
 #endif
 
 __device__ __forceinline__ f32x2 splat2(float x) { return f32x2{x, x}; }
@@ -385,7 +394,7 @@ template <int KP, int POOL, bool WRITE_ENV, bool DO_RENDER, bool HAS_GT, bool HE
 __device__ __forceinline__ void fwd_pk_body(const Args& a, int unit, float* tile, float* gtile) {
   static_assert(!(HAS_GT && WRITE_ENV), "the statistics variant does not write the env image");
   constexpr int EW = 16, TJ = SGR_PK_TJ, HALF = 8, NQ = 2, RPT = TJ / EW;
-  SGR_TRACE_BEGIN
+  SGR_TRACE_BEGIN_UNLESS(HAS_GT)
 
   const Pix x = locate_unit(a, unit);
   const int lane = x.lane, b = x.b, p = x.p;
@@ -413,7 +422,7 @@ __device__ __forceinline__ void fwd_pk_body(const Args& a, int unit, float* tile
   f32x2 s_pg = splat2(0.f), s_pp = splat2(0.f), s_g = splat2(0.f);
   __amdgpu_buffer_rsrc_t gimg = env_rsrc(HAS_GT ? a.env_gt + img : a.view, RC, a.J);
   if (HAS_GT) tile_dma_issue<16>(gtile, gimg, x.p0, RC, a.J, 0, lane);
-  SGR_TRACE_MARK
+  SGR_TRACE_MARK_UNLESS(HAS_GT)
 
   auto row_loop = [&](auto ortho_c) {
     constexpr bool ORTHO = decltype(ortho_c)::value;
@@ -602,7 +611,7 @@ template <int POOL, bool WRITE_ENV, bool DO_RENDER, int KPW, int EW, int RPF = 1
 __device__ __forceinline__ void fwd_pk_half_body(const Args& a, const Pix x, float* tile, float* gtile = nullptr, int unit = 0) {
   static_assert(!(HAS_GT && WRITE_ENV), "the statistics variant does not write the env image");
   constexpr int HALF = EW / 2, NQ = HALF / 4, TD = EW * RPF, Q = EW / 16;
-  SGR_TRACE_BEGIN
+  SGR_TRACE_BEGIN_UNLESS(HAS_GT)
 
   const int lane = threadIdx.x, half = lane >> 5, pl = lane & 31;
   const int own = 1 - half;                         // the half row (sign) whose totals this half-wave ends up holding
@@ -632,7 +641,7 @@ __device__ __forceinline__ void fwd_pk_half_body(const Args& a, const Pix x, flo
   __amdgpu_buffer_rsrc_t gimg = env_rsrc(HAS_GT ? a.env_gt + img : a.view, RC, a.J);
   const int nvr = eh * Q;
   if (HAS_GT) tile32_dma_issue_vrow<SGR_DMA_AUX, EW>(gtile, gimg, x.p0, RC, a.J, 0, lane);
-  SGR_TRACE_MARK
+  SGR_TRACE_MARK_UNLESS(HAS_GT)
 
   auto row_loop = [&](auto ortho_c) {
     constexpr bool ORTHO = decltype(ortho_c)::value;
