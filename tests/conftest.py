@@ -16,6 +16,18 @@ GOLDEN_CASES = ["g1_q4_k12", "g2_q1_k5", "g3_edges"]
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+    _build_if_missing()
+
+
+def _build_if_missing():
+    """A fresh checkout has no built libraries (they are git-ignored): the test session builds them once, the way the driver does
+    (``__graft_entry__.build()``: hipcc cross-compiles gfx950 without a GPU, about a minute).  Test infrastructure only -- the package
+    itself never builds anything and raises ``SgrenderUnavailable`` when a library is missing (tests/test_abi.py)."""
+    pkg = os.path.join(ROOT, "inverserenderingofindoorscene_amd")
+    if all(os.path.isfile(os.path.join(pkg, f)) for f in ("libsgrender.so", "libsgrender_torch.so")):
+        return
+    import __graft_entry__
+    __graft_entry__.build()
 
 
 def load_golden(name):
