@@ -278,6 +278,22 @@ int sgr_fused_fwd_recon_seg(const float* albedo, const float* normal, const floa
                             int bn, int K, int R, int C, int eh, int ew, int imH, int imW, float F0, int premap,
                             void* stream);
 
+/* ABI 5.  The forward half of the light objective on ONE rank (wrapperBRDFLight.py:167-207 up to the two loss values) in four launches:
+ * sgr_fused_fwd_recon_seg's statistics kernel, then sgr_render_loss_fwd_total's three passes with (i) the per-image fold of the env
+ * statistics (coef_env, the mask sums in recon_workspace) as an extra workgroup per image of the first pass and (ii), when g_diffuse /
+ * g_spec are given, ren_weight * d renderErr / d{diffuse, spec} written by the third -- what sgr_fused_fwd_recon_seg +
+ * sgr_render_loss_fwd_total + sgr_render_loss_bwd_scaled did in six.  im [bn,3,imH,imW], seg [bn,1,imH,imW] with (imH, imW) = (R, C) or
+ * (2R, 2C); BRDF maps brdfH x brdfW as in sgr_fused_fwd; the outputs are those of the calls it replaces (render_err = *loss, scale_r =
+ * *scale with divisor 3).  Follow with sgr_fused_bwd_recon_total on the same recon_workspace. */
+int sgr_light_objective_fwd(const float* albedo, const float* normal, const float* rough, const float* axis, const float* lamb,
+                            const float* weight, const float* dirs, const float* view, const float* env_gt, const float* im,
+                            const float* seg, const float* env_ind, float* lamb_tan /* nullable */, float* weight_tan /* nullable */,
+                            float* diffuse, float* spec, float* mask, float* coef_env, float* im_small, float* seg_small,
+                            float* rendered, float* coef_ds, float* parts_r, float* render_err, float* scale_r, float ren_weight,
+                            float* g_diffuse /* nullable pair */, float* g_spec, float* recon_workspace, float* loss_workspace,
+                            int bn, int K, int R, int C, int eh, int ew, int imH, int imW, int brdfH, int brdfW, float F0, int premap,
+                            void* stream);
+
 /* Backward of  objective = (render terms, through g_diffuse / g_spec) + rec_weight * reconstErr,
  *   reconstErr = num / max(den, 1e-5) / 3 / (eh*ew),  num = sum mask (log(coef env + offset) - log(env_gt + offset))^2,
  * w.r.t. the SG parameters, with env recomputed in registers.  den = *den_global when given (the mask sum

@@ -53,6 +53,7 @@ SIGNATURES = {
     "sgr_loss_workspace_floats": ([_I], c_int),
     "sgr_render_loss_fwd": ([_P] * 10 + [_I] * 5 + [_P], c_int),
     "sgr_render_loss_fwd_total": ([_P] * 11 + [_F, _P] + [_I] * 5 + [_P], c_int),
+    "sgr_light_objective_fwd": ([_P] * 25 + [_F] + [_P] * 4 + [_I] * 10 + [_F, _I, _P], c_int),
     "sgr_render_loss_fwd_total_grads": ([_P] * 11 + [_F, _F, _P, _P, _P] + [_I] * 5 + [_P], c_int),
     "sgr_render_loss_bwd": ([_P] * 8 + [_I] * 3 + [_P], c_int),
     "sgr_loss_finalize": ([_P, _P, _P, _F, _P], c_int),

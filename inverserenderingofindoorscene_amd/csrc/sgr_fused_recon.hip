@@ -438,7 +438,8 @@ static int fused_fwd_recon_impl(const float* albedo, const float* normal, const 
                                const float* weight, const float* dirs, const float* view, const float* env_gt,
                                const float* seg_small, int seg_pool2, const float* env_ind, float* lamb_tan, float* weight_tan,
                                float* diffuse, float* spec, float* mask, float* coef, float* parts, float* workspace, int bn, int K, int R,
-                               int C, int eh, int ew, int imH, int imW, float F0, int premap, void* stream) {
+                               int C, int eh, int ew, int imH, int imW, float F0, int premap, void* stream,
+                               FoldJob* deferred = nullptr /* given: the per-image fold is not launched but described here */) {
   SGR_REQUIRE(albedo && normal && rough && axis && lamb && weight && dirs && view && env_gt && seg_small && env_ind && diffuse &&
                   spec && mask && coef && workspace,
               "sgr_fused_fwd_recon: NULL tensor");
@@ -493,6 +494,10 @@ static int fused_fwd_recon_impl(const float* albedo, const float* normal, const 
       else hipLaunchKernelGGL((fwd_pk_kernel<12, 2, false, true, true>), grid, block, 0, st, a);
     }
   }
+  if (deferred) {
+    *deferred = FoldJob{ws0, coef, den_img, tiles};
+    return sgr_check((int)hipGetLastError(), "sgr_fused_fwd_recon");
+  }
   hipLaunchKernelGGL(recon_fold0, dim3(bn), dim3(kRThreads), 0, st, ws0, coef, den_img, tiles);
   if (parts)      // (0, local sum of the env mask): what a sharded caller all-reduces before the backward pass; nobody else needs it
     hipLaunchKernelGGL(recon_fold1, dim3(1), dim3(kFold1Threads), 0, st, ws0, den_img, parts, bn, 0, ObjectiveTail{});
@@ -529,6 +534,30 @@ extern "C" int sgr_fused_fwd_recon_seg(const float* albedo, const float* normal,
   SGR_SUPPORTED(same || twice, "sgr_fused_fwd_recon_seg: object mask / env-grid ratio must be 1 or 2 (pool first)");
   return fused_fwd_recon_impl(albedo, normal, rough, axis, lamb, weight, dirs, view, env_gt, seg, twice ? 1 : 0, env_ind, lamb_tan, weight_tan,
                               diffuse, spec, mask, coef, parts, workspace, bn, K, R, C, eh, ew, imH, imW, F0, premap, stream);
+}
+
+// The forward half of the light objective on ONE rank in four launches (ABI 5): the statistics kernel, then the render loss's three passes
+// with (i) the per-image fold of the env statistics as an extra workgroup per image of the first pass -- nothing between the two reads
+// it -- and (ii) ren_weight * d renderErr / d{diffuse, spec} written by the third (g_diffuse / g_spec given) -- what
+// sgr_fused_fwd_recon_seg + sgr_render_loss_fwd_total + sgr_render_loss_bwd_scaled did in six.  seg [bn,1,imH,imW] or [bn,1,R,C].
+extern "C" int sgr_light_objective_fwd(const float* albedo, const float* normal, const float* rough, const float* axis, const float* lamb,
+                                       const float* weight, const float* dirs, const float* view, const float* env_gt, const float* im,
+                                       const float* seg, const float* env_ind, float* lamb_tan, float* weight_tan, float* diffuse, float* spec,
+                                       float* mask, float* coef_env, float* im_small, float* seg_small, float* rendered, float* coef_ds,
+                                       float* parts_r, float* render_err, float* scale_r, float ren_weight, float* g_diffuse, float* g_spec,
+                                       float* recon_workspace, float* loss_workspace, int bn, int K, int R, int C, int eh, int ew, int imH,
+                                       int imW, int brdfH, int brdfW, float F0, int premap, void* stream) {
+  SGR_REQUIRE(im && seg && im_small && seg_small && rendered && coef_ds && parts_r && render_err && scale_r && loss_workspace,
+              "sgr_light_objective_fwd: NULL tensor");
+  SGR_REQUIRE((g_diffuse == nullptr) == (g_spec == nullptr), "sgr_light_objective_fwd: g_diffuse / g_spec come together");
+  const bool same = imH == R && imW == C, twice = imH == 2 * R && imW == 2 * C;
+  SGR_SUPPORTED(same || twice, "sgr_light_objective_fwd: image / env-grid ratio must be 1 or 2 (pool first)");
+  FoldJob job{};
+  if (int rc = fused_fwd_recon_impl(albedo, normal, rough, axis, lamb, weight, dirs, view, env_gt, seg, twice ? 1 : 0, env_ind, lamb_tan, weight_tan,
+                                    diffuse, spec, mask, coef_env, nullptr, recon_workspace, bn, K, R, C, eh, ew, brdfH, brdfW, F0, premap, stream, &job))
+    return rc;
+  return render_loss_fwd_launch(diffuse, spec, im, seg, im_small, seg_small, rendered, coef_ds, parts_r, render_err, scale_r, 3.0f, ren_weight,
+                                g_diffuse, g_spec, loss_workspace, bn, R, C, imH, imW, job, stream);
 }
 
 static int fused_bwd_recon_impl(const float* albedo, const float* normal, const float* rough, const float* axis, const float* lamb,

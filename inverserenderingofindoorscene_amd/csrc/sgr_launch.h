@@ -9,6 +9,14 @@ namespace sgr {
 void set_error(const char* msg);
 int sgr_check(int hip_rc, const char* who);
 void note_pending_error();
+
+// The env-statistics fold of the fused light objective (recon_fold0_image, sgr_recon_fold.h) as a side job of the render loss's first pass:
+// one extra workgroup per image.  ws == nullptr: no job.
+struct FoldJob { const float* ws; float* coef; float* den_img; int nblk; };
+// the three render-loss passes (sgr_loss.hip), shared by sgr_render_loss_fwd_total(_grads) and sgr_light_objective_fwd (sgr_fused_recon.hip)
+int render_loss_fwd_launch(const float* diffuse, const float* spec, const float* im, const float* seg, float* im_small, float* seg_small,
+                           float* rendered, float* coef, float* parts, float* loss, float* scale, float divisor, float weight,
+                           float* g_diffuse, float* g_spec, float* workspace, int bn, int R, int C, int imH, int imW, FoldJob job, void* stream);
 }  // namespace sgr
 
 // Every entry point starts with SGR_REQUIRE.  Its first act is note_pending_error(): a (non-sticky) HIP error some earlier

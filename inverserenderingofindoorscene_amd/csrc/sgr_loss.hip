@@ -10,10 +10,12 @@
 // in double) -- no atomics, bit-reproducible, no host synchronisation (the reference's
 // `.item()` on pixelNum, wrapperBRDFLight.py:192, stays on the device).
 #include "sgr_launch.h"
+#include "sgr_recon_fold.h"
 
 namespace sgr {
 
 constexpr int kLossThreads = 256;
+static_assert(kLossThreads == kRThreads, "the fold side job of stage A runs on a stage-A workgroup");
 constexpr int kSplit = 16;           // blocks per image (passes over data the previous pass left in cache; 32: no change in the loop)
 constexpr int kSplitA = 64;          // blocks per image of the FIRST pass (stage A / diffspec_partial_a): it reads the full-resolution
                                      // image and mask cold from HBM, and a quarter of the blocks left it latency-bound (16.7 us in the
@@ -95,8 +97,13 @@ __global__ __launch_bounds__(kLossThreads) void loss_stage_a(const float* __rest
                                                               const float* __restrict__ im, const float* __restrict__ seg,
                                                               float* __restrict__ im_s, float* __restrict__ seg_s,
                                                               float* __restrict__ wsA /* [bn,kSplit,6] */, unsigned* __restrict__ ticket,
-                                                              int R, int C, int imH, int imW) {
+                                                              int R, int C, int imH, int imW, FoldJob job) {
   __shared__ float lds[4 * 6];
+  if (blockIdx.x == kSplitA) {      // the side job's workgroup of this image (launched only when there is one)
+    __shared__ double fold_lds[kRThreads * 3];
+    recon_fold0_image(job.ws, job.coef, job.den_img, job.nblk, (int)blockIdx.y, fold_lds);
+    return;
+  }
   const int b = blockIdx.y, RC = R * C, n = 3 * RC;
   if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) ticket[0] = 0u;      // stage C's arrival counter (two kernel boundaries ahead of its use)
   float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -362,9 +369,11 @@ using namespace sgr;
 
 extern "C" int sgr_loss_workspace_floats(int bn) { return bn * (kSplitA * 6 + kSplit * (2 + 1)) + 1; }      // + the arrival counter
 
-static int render_loss_fwd_impl(const float* diffuse, const float* spec, const float* im, const float* seg, float* im_small, float* seg_small,
+// the three passes; shared with sgr_light_objective_fwd (sgr_fused_recon.hip), which hands the env-statistics fold to the first one
+int sgr::render_loss_fwd_launch(const float* diffuse, const float* spec, const float* im, const float* seg, float* im_small, float* seg_small,
                                 float* rendered, float* coef, float* parts, float* loss, float* scale, float divisor, float weight,
-                                float* g_diffuse, float* g_spec, float* workspace, int bn, int R, int C, int imH, int imW, void* stream) {
+                                float* g_diffuse, float* g_spec, float* workspace, int bn, int R, int C, int imH, int imW, FoldJob job,
+                                void* stream) {
   SGR_REQUIRE(diffuse && spec && im && seg && im_small && seg_small && rendered && coef && parts && workspace,
               "sgr_render_loss_fwd: NULL tensor");
   SGR_REQUIRE((loss == nullptr) == (scale == nullptr) && (!loss || divisor > 0.0f), "sgr_render_loss_fwd: loss / scale / divisor");
@@ -378,10 +387,11 @@ static int render_loss_fwd_impl(const float* diffuse, const float* spec, const f
   unsigned* ticket = reinterpret_cast<unsigned*>(wsC + (size_t)bn * kSplit);
   const dim3 grid(kSplit, bn), block(kLossThreads);
   const int RC = R * C;
+  const dim3 grid_a(kSplitA + (job.ws ? 1 : 0), bn);
   if (imH == R)
-    hipLaunchKernelGGL((loss_stage_a<1>), dim3(kSplitA, bn), block, 0, st, diffuse, spec, im, seg, im_small, seg_small, wsA, ticket, R, C, imH, imW);
+    hipLaunchKernelGGL((loss_stage_a<1>), grid_a, block, 0, st, diffuse, spec, im, seg, im_small, seg_small, wsA, ticket, R, C, imH, imW, job);
   else
-    hipLaunchKernelGGL((loss_stage_a<2>), dim3(kSplitA, bn), block, 0, st, diffuse, spec, im, seg, im_small, seg_small, wsA, ticket, R, C, imH, imW);
+    hipLaunchKernelGGL((loss_stage_a<2>), grid_a, block, 0, st, diffuse, spec, im, seg, im_small, seg_small, wsA, ticket, R, C, imH, imW, job);
   hipLaunchKernelGGL(loss_stage_b, grid, block, 0, st, diffuse, spec, im_small, wsA, wsB, 3 * RC);
   hipLaunchKernelGGL(loss_stage_c, grid, block, 0, st, diffuse, spec, im_small, seg_small, wsA, wsB, coef, rendered, wsC, RC, ticket, parts,
                      loss, scale, divisor, weight, g_diffuse, g_spec);
@@ -391,8 +401,8 @@ static int render_loss_fwd_impl(const float* diffuse, const float* spec, const f
 extern "C" int sgr_render_loss_fwd_total(const float* diffuse, const float* spec, const float* im, const float* seg, float* im_small,
                                          float* seg_small, float* rendered, float* coef, float* parts, float* loss, float* scale,
                                          float divisor, float* workspace, int bn, int R, int C, int imH, int imW, void* stream) {
-  return render_loss_fwd_impl(diffuse, spec, im, seg, im_small, seg_small, rendered, coef, parts, loss, scale, divisor, 0.0f, nullptr, nullptr,
-                              workspace, bn, R, C, imH, imW, stream);
+  return render_loss_fwd_launch(diffuse, spec, im, seg, im_small, seg_small, rendered, coef, parts, loss, scale, divisor, 0.0f, nullptr, nullptr,
+                                workspace, bn, R, C, imH, imW, FoldJob{}, stream);
 }
 
 // one rank, loss value AND weight * d loss / d{diffuse, spec} in the three launches (ABI 5; the fused light objective)
@@ -401,8 +411,8 @@ extern "C" int sgr_render_loss_fwd_total_grads(const float* diffuse, const float
                                                float divisor, float weight, float* g_diffuse, float* g_spec, float* workspace, int bn,
                                                int R, int C, int imH, int imW, void* stream) {
   SGR_REQUIRE(loss && scale && g_diffuse && g_spec, "sgr_render_loss_fwd_total_grads: NULL output (the gradient needs the one-rank loss / scale pair)");
-  return render_loss_fwd_impl(diffuse, spec, im, seg, im_small, seg_small, rendered, coef, parts, loss, scale, divisor, weight, g_diffuse, g_spec,
-                              workspace, bn, R, C, imH, imW, stream);
+  return render_loss_fwd_launch(diffuse, spec, im, seg, im_small, seg_small, rendered, coef, parts, loss, scale, divisor, weight, g_diffuse, g_spec,
+                                workspace, bn, R, C, imH, imW, FoldJob{}, stream);
 }
 
 extern "C" int sgr_render_loss_fwd(const float* diffuse, const float* spec, const float* im, const float* seg,

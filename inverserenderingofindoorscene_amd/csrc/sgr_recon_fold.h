@@ -24,11 +24,9 @@ __device__ __forceinline__ void block_sum_double(double (&v)[N], double* lds /* 
   for (int i = 0; i < N; ++i) v[i] = lds[i];
 }
 
-// fold stage-0 partials: coef[b], den partial per image   (one block per image)
-static __global__ __launch_bounds__(kRThreads) void recon_fold0(const float* __restrict__ ws, float* __restrict__ coef,
-                                                          float* __restrict__ den_img, int nblk) {
-  __shared__ double lds[kRThreads * 3];
-  const int b = blockIdx.x;
+// fold stage-0 partials of image b: coef[b] (LSregress scale, models.py:7-21), den partial per image.  One workgroup of kRThreads.
+__device__ __forceinline__ void recon_fold0_image(const float* __restrict__ ws, float* __restrict__ coef, float* __restrict__ den_img, int nblk, int b,
+                                                  double* lds /* [kRThreads * 3] */) {
   double v[3] = {0.0, 0.0, 0.0};
   // four triples requested together per round (600 partials per image at config 2: one round), added in index order as before
   for (int i = threadIdx.x; i < nblk; i += 4 * kRThreads) {
@@ -47,6 +45,13 @@ static __global__ __launch_bounds__(kRThreads) void recon_fold0(const float* __r
     coef[b] = fminf(fmaxf((float)v[0] / fmaxf((float)v[1], 1e-5f), 0.001f), 1000.0f);
     den_img[b] = (float)v[2];
   }
+}
+// (one block per image; the fused light objective on one rank runs the same fold as an extra workgroup per image of the render loss's first
+// pass instead -- sgr_light_objective_fwd, FoldJob in sgr_launch.h -- and saves this launch)
+static __global__ __launch_bounds__(kRThreads) void recon_fold0(const float* __restrict__ ws, float* __restrict__ coef,
+                                                          float* __restrict__ den_img, int nblk) {
+  __shared__ double lds[kRThreads * 3];
+  recon_fold0_image(ws, coef, den_img, nblk, (int)blockIdx.x, lds);
 }
 
 // The tail of the light objective when the batch is not sharded (otherwise sgr_objective_finalize after the all-reduce):

@@ -67,7 +67,7 @@ using Cam = at::ArrayRef<double>;
   X(sgr_render_loss_fwd_total) X(sgr_render_loss_fwd_total_grads) X(sgr_loss_finalize) X(sgr_objective_finalize) X(sgr_render_loss_bwd_scaled)                      \
   X(sgr_lsregress_coef) X(sgr_lsregress_diffspec_coef) X(sgr_sg_shading) X(sgr_recon_workspace_floats) X(sgr_recon_loss_fwd)     \
   X(sgr_recon_loss_bwd) X(sgr_fused_recon_supported) X(sgr_heads_prologue_supported) X(sgr_fused_recon_workspace_floats)         \
-  X(sgr_fused_fwd_recon_seg) X(sgr_light_heads_fwd) X(sgr_light_heads_bwd) X(sgr_rescale_inplace_flip) X(sgr_fused_bwd_recon)    \
+  X(sgr_fused_fwd_recon_seg) X(sgr_light_objective_fwd) X(sgr_light_heads_fwd) X(sgr_light_heads_bwd) X(sgr_rescale_inplace_flip) X(sgr_fused_bwd_recon)    \
   X(sgr_fused_bwd_recon_total) X(sgr_glue_workspace_floats) X(sgr_light_albedo_scale) X(sgr_light_input_fwd)
 
 struct Api {
@@ -1008,23 +1008,18 @@ T9 light_objective_fwdbwd_cuda(const Tensor& albedo, const Tensor& normal, const
   const int pm = heads ? 3 : 1;      // 3: axis / lamb / weight are the decoders' last-convolution outputs (heads as the kernels' prologue)
   Tensor lam_t = handoff ? at::empty_like(la) : Tensor(), w_t = handoff ? at::empty_like(we) : Tensor();      // post-tan values: forward writes, backward reads (premap 2)
   const Tensor dirs = dirs_table(dev, eh, ew), view = view_table(dev, d.R, d.C, fov, cam);
-  // the env mask needs the pooled object mask before the render-loss pass produces it: the kernel pools 2x2 itself
-  ok(A.sgr_fused_fwd_recon_seg(rp(a), rp(n), rp(r), rp(ax), rp(la), rp(we), rp(dirs), rp(view), rp(gt), rp(sg), (int)d.imH, (int)d.imW, rp(ind), wp(lam_t), wp(w_t),
-                               wp(diffuse), wp(spec), wp(mask), wp(coef), nullptr, wp(ws), bn, K, R, C, (int)eh, (int)ew, (int)d.h, (int)d.w, (float)F0, pm, st),
-     "sgr_fused_fwd_recon");
+  // forward half in four launches (ABI 5): the statistics kernel (it pools the object mask itself: the env mask needs it before the render-loss
+  // pass produces it), then the render loss's three passes -- the first also folds the env statistics per image, the third also writes
+  // ren_w * d renderErr / d{diffuse, spec} when gradients are wanted (no fold launch, no loss_bwd launch between the two heavy kernels)
   Tensor g_axis = none_like(a), g_lamb = none_like(a), g_weight = none_like(a), applied = none_like(a), g_d, g_s;
   if (need_grad) {
-    // ren_w * d renderErr / d{diffuse, spec} comes out of the render loss's third pass (no loss_bwd launch between the two heavy kernels)
     g_axis = at::empty_like(ax); g_lamb = at::empty_like(la); g_weight = at::empty_like(we); applied = at::empty({2}, o);
     g_d = at::empty_like(diffuse); g_s = at::empty_like(spec);
-    ok(A.sgr_render_loss_fwd_total_grads(rp(diffuse), rp(spec), rp(i), rp(sg), wp(im_s), wp(seg_s), wp(rendered), wp(coef_ds), wp(parts_r),
-                                         render_err.data_ptr<float>(), wp(scale_r), 3.0f, (float)ren_w, wp(g_d), wp(g_s), wp(ws_r), bn, R, C, (int)d.imH, (int)d.imW, st),
-       "sgr_render_loss_fwd");
-  } else {
-    ok(A.sgr_render_loss_fwd_total(rp(diffuse), rp(spec), rp(i), rp(sg), wp(im_s), wp(seg_s), wp(rendered), wp(coef_ds), wp(parts_r), render_err.data_ptr<float>(),
-                                   wp(scale_r), 3.0f, wp(ws_r), bn, R, C, (int)d.imH, (int)d.imW, st),
-       "sgr_render_loss_fwd");
   }
+  ok(A.sgr_light_objective_fwd(rp(a), rp(n), rp(r), rp(ax), rp(la), rp(we), rp(dirs), rp(view), rp(gt), rp(i), rp(sg), rp(ind), wp(lam_t), wp(w_t), wp(diffuse), wp(spec),
+                               wp(mask), wp(coef), wp(im_s), wp(seg_s), wp(rendered), wp(coef_ds), wp(parts_r), render_err.data_ptr<float>(), wp(scale_r), (float)ren_w,
+                               wp(g_d), wp(g_s), wp(ws), wp(ws_r), bn, K, R, C, (int)eh, (int)ew, (int)d.imH, (int)d.imW, (int)d.h, (int)d.w, (float)F0, pm, st),
+     "sgr_light_objective_fwd");
   ok(A.sgr_fused_bwd_recon_total(rp(a), rp(n), rp(r), rp(ax), handoff ? rp(lam_t) : rp(la), handoff ? rp(w_t) : rp(we), rp(dirs), rp(view), rp(gt), rp(mask), rp(coef),
                                  rp(g_d), rp(g_s), wp(g_axis), wp(g_lamb), wp(g_weight), wp(parts_b), wp(ws), bn, K, R, C, (int)eh, (int)ew, (int)d.h, (int)d.w,
                                  (float)F0, handoff ? 2 : pm, (float)offset, (float)rec_w, rp(render_err), (float)ren_w, objective.data_ptr<float>(),

@@ -330,3 +330,51 @@ def test_forward_only_objective_launches_no_gradient_kernel(sgr):
             assert not any("loss_bwd" in n for n in names), names
             lossonly = [n for n in names if "sg_bwd_recon_pk_kernel" in n]
             assert lossonly and all(n not in grad_kernel for n in lossonly), (lossonly, grad_kernel)      # the GRADS = false instantiation
+
+
+@pytest.mark.parametrize("bn,imH,imW,R,C,K,eh,ew,premap", [
+    (16, 240, 320, 120, 160, 12, 8, 16, 1),      # config 2: one pixel per lane statistics kernel, 600 (64-pixel) partials per image
+    (2, 24, 32, 12, 16, 12, 8, 16, 3),           # decoder heads as the prologue: half-wave statistics kernel
+    (3, 18, 26, 9, 13, 9, 8, 16, 1),             # ragged tiles
+    (2, 12, 20, 6, 10, 24, 16, 32, 1),           # config-5 grid, 24 lobes
+])
+def test_objective_forward_half_in_four_launches_equals_the_separate_calls(sgr, bn, imH, imW, R, C, K, eh, ew, premap):
+    """ABI 5: sgr_light_objective_fwd (statistics kernel + the render loss's three passes, the first folding the env statistics per image
+    as an extra workgroup, the third writing the render-loss gradient) against the calls it replaces -- sgr_fused_fwd_recon_seg (own fold
+    launch) + sgr_render_loss_fwd_total_grads: every output bit-identical, incl. the per-image mask sums left in the workspace."""
+    from oracle import sg_oracle as O
+    from inverserenderingofindoorscene_amd import _lib
+    from inverserenderingofindoorscene_amd.ops import _dirs, _ptr, _stream, _view
+    lib = _lib.load()
+    dev = torch.device("cuda")
+    x = {k: v.to(dev) for k, v in O.synthetic_inputs(bn, imH, imW, R, C, K, eh=eh, ew=ew, seed=77 + bn).items()}
+    ind = torch.ones(bn, device=dev)
+    dirs, view = _dirs(dev, eh, ew), _view(dev, R, C, 57.0)
+    st = _stream(dev)
+    ren_w = 0.8
+
+    def buffers():
+        e = lambda *sh: torch.empty(*sh, device=dev)
+        return dict(diffuse=e(bn, 3, R, C), spec=e(bn, 3, R, C), mask=e(bn, R * C), coef_env=e(bn), im_s=e(bn, 3, R, C), seg_s=e(bn, 1, R, C),
+                    rendered=e(bn, 3, R, C), coef_ds=e(bn, 2), parts=e(2), loss=e(1), scale=e(1), gd=e(bn, 3, R, C), gs=e(bn, 3, R, C),
+                    ws=torch.zeros(lib.sgr_fused_recon_workspace_floats(bn, R, C), device=dev), wsl=e(lib.sgr_loss_workspace_floats(bn)))
+
+    a, b = buffers(), buffers()
+    sg = [_ptr(x[k]) for k in ("albedo", "normal", "rough", "axis", "lamb", "weight")]
+    rc = lib.sgr_fused_fwd_recon_seg(*sg, _ptr(dirs), _ptr(view), _ptr(x["env_gt"]), _ptr(x["seg"]), imH, imW, _ptr(ind), None, None, _ptr(a["diffuse"]),
+                                     _ptr(a["spec"]), _ptr(a["mask"]), _ptr(a["coef_env"]), None, _ptr(a["ws"]), bn, K, R, C, eh, ew, imH, imW, 0.05, premap, st)
+    assert rc == 0, lib.sgr_last_error()
+    rc = lib.sgr_render_loss_fwd_total_grads(_ptr(a["diffuse"]), _ptr(a["spec"]), _ptr(x["im"]), _ptr(x["seg"]), _ptr(a["im_s"]), _ptr(a["seg_s"]), _ptr(a["rendered"]),
+                                             _ptr(a["coef_ds"]), _ptr(a["parts"]), _ptr(a["loss"]), _ptr(a["scale"]), 3.0, ren_w, _ptr(a["gd"]), _ptr(a["gs"]),
+                                             _ptr(a["wsl"]), bn, R, C, imH, imW, st)
+    assert rc == 0, lib.sgr_last_error()
+    rc = lib.sgr_light_objective_fwd(*sg, _ptr(dirs), _ptr(view), _ptr(x["env_gt"]), _ptr(x["im"]), _ptr(x["seg"]), _ptr(ind), None, None, _ptr(b["diffuse"]),
+                                     _ptr(b["spec"]), _ptr(b["mask"]), _ptr(b["coef_env"]), _ptr(b["im_s"]), _ptr(b["seg_s"]), _ptr(b["rendered"]), _ptr(b["coef_ds"]),
+                                     _ptr(b["parts"]), _ptr(b["loss"]), _ptr(b["scale"]), ren_w, _ptr(b["gd"]), _ptr(b["gs"]), _ptr(b["ws"]), _ptr(b["wsl"]),
+                                     bn, K, R, C, eh, ew, imH, imW, imH, imW, 0.05, premap, st)
+    assert rc == 0, lib.sgr_last_error()
+    torch.cuda.synchronize()
+    for k in ("diffuse", "spec", "mask", "coef_env", "im_s", "seg_s", "rendered", "coef_ds", "parts", "loss", "scale", "gd", "gs"):
+        assert torch.equal(a[k], b[k]), (k, (a[k] - b[k]).abs().max().item())
+    assert torch.equal(a["ws"][:bn], b["ws"][:bn])      # the per-image mask sums the backward entry point reads
+    assert torch.isfinite(b["coef_env"]).all() and b["ws"][:bn].min().item() > 0
