@@ -17,6 +17,7 @@ namespace sgr {
 constexpr int kLossThreads = 256;
 static_assert(kLossThreads == kRThreads, "the fold side job of stage A runs on a stage-A workgroup");
 constexpr int kSplit = 16;           // blocks per image (passes over data the previous pass left in cache; 32: no change in the loop)
+constexpr int kStreamUnroll = 4;      // elements per thread and round of the streaming passes, all loads issued before the first use
 constexpr int kSplitA = 64;          // blocks per image of the FIRST pass (stage A / diffspec_partial_a): it reads the full-resolution
                                      // image and mask cold from HBM, and a quarter of the blocks left it latency-bound (16.7 us in the
                                      // training loop for 32 MB); = lanes of a wave, see fold_a
@@ -108,18 +109,36 @@ __global__ __launch_bounds__(kLossThreads) void loss_stage_a(const float* __rest
   if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) ticket[0] = 0u;      // stage C's arrival counter (two kernel boundaries ahead of its use)
   float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const size_t plane = (size_t)imH * imW;
-  for (int i = blockIdx.x * kLossThreads + threadIdx.x; i < n; i += kSplitA * kLossThreads) {
-    const int ch = i / RC, p = i - ch * RC, r = p / C, c = p - r * C;
-    const float v = pool_at<POOL>(im + ((size_t)b * 3 + ch) * plane, r, c, imW);
-    im_s[(size_t)b * n + i] = v;
-    const float m = v < 0.9f ? 1.0f : 0.0f;
-    const float d = diffuse[(size_t)b * n + i] * m, s = spec[(size_t)b * n + i] * m, vm = v * m;
-    acc[0] = fmaf(d, d, acc[0]); acc[1] = fmaf(s, s, acc[1]); acc[2] = fmaf(d, s, acc[2]);
-    acc[3] = fmaf(d, vm, acc[3]); acc[4] = fmaf(s, vm, acc[4]);
-    if (ch == 0) {
-      const float sg = pool_at<POOL>(seg + (size_t)b * plane, r, c, imW);
-      seg_s[(size_t)b * RC + p] = sg;
-      acc[5] += sg;
+  // kStreamUnroll elements per round with every load issued before the first use: the plain grid-stride loop compiles to one memory round
+  // trip per element (rocprof: 14 dependent rounds in the third pass = 15 of its 17 us).  Same elements per thread in the same order: same sums.
+  constexpr int stride = kSplitA * kLossThreads;
+  for (int i0 = blockIdx.x * kLossThreads + threadIdx.x; i0 < n; i0 += kStreamUnroll * stride) {
+    float v[kStreamUnroll], dv[kStreamUnroll], sv[kStreamUnroll], sg[kStreamUnroll];
+    int pp[kStreamUnroll];
+#pragma unroll
+    for (int u = 0; u < kStreamUnroll; ++u) {
+      const int i = i0 + u * stride < n ? i0 + u * stride : i0;      // lanes past the end re-read their first element (unused)
+      const int ch = i / RC, p = i - ch * RC, r = p / C, c = p - r * C;
+      pp[u] = ch == 0 ? p : -1;
+      v[u] = pool_at<POOL>(im + ((size_t)b * 3 + ch) * plane, r, c, imW);
+      dv[u] = diffuse[(size_t)b * n + i];
+      sv[u] = spec[(size_t)b * n + i];
+      sg[u] = ch == 0 ? pool_at<POOL>(seg + (size_t)b * plane, r, c, imW) : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < kStreamUnroll; ++u) {
+      const int i = i0 + u * stride;
+      if (i < n) {
+        im_s[(size_t)b * n + i] = v[u];
+        const float m = v[u] < 0.9f ? 1.0f : 0.0f;
+        const float d = dv[u] * m, s = sv[u] * m, vm = v[u] * m;
+        acc[0] = fmaf(d, d, acc[0]); acc[1] = fmaf(s, s, acc[1]); acc[2] = fmaf(d, s, acc[2]);
+        acc[3] = fmaf(d, vm, acc[3]); acc[4] = fmaf(s, vm, acc[4]);
+        if (pp[u] >= 0) {
+          seg_s[(size_t)b * RC + pp[u]] = sg[u];
+          acc[5] += sg[u];
+        }
+      }
     }
   }
   block_reduce<6>(acc, lds);
@@ -141,11 +160,22 @@ __global__ __launch_bounds__(kLossThreads) void loss_stage_b(const float* __rest
   float cd, cs;
   diffspec_coefs(s5, (float)n, cd, cs);
   float acc[2] = {0.f, 0.f};
-  for (int i = blockIdx.x * kLossThreads + threadIdx.x; i < n; i += kSplit * kLossThreads) {
-    const size_t o = (size_t)b * n + i;
-    const float r = fminf(fmaxf(cd * diffuse[o] + cs * spec[o], 0.0f), 1.0f);
-    acc[0] = fmaf(r, im_s[o], acc[0]);
-    acc[1] = fmaf(r, r, acc[1]);
+  constexpr int stride = kSplit * kLossThreads;
+  for (int i0 = blockIdx.x * kLossThreads + threadIdx.x; i0 < n; i0 += kStreamUnroll * stride) {      // loads of a round in flight together (see stage A)
+    float dv[kStreamUnroll], sv[kStreamUnroll], iv[kStreamUnroll];
+#pragma unroll
+    for (int u = 0; u < kStreamUnroll; ++u) {
+      const size_t o = (size_t)b * n + (i0 + u * stride < n ? i0 + u * stride : i0);
+      dv[u] = diffuse[o]; sv[u] = spec[o]; iv[u] = im_s[o];
+    }
+#pragma unroll
+    for (int u = 0; u < kStreamUnroll; ++u) {
+      if (i0 + u * stride < n) {
+        const float r = fminf(fmaxf(cd * dv[u] + cs * sv[u], 0.0f), 1.0f);
+        acc[0] = fmaf(r, iv[u], acc[0]);
+        acc[1] = fmaf(r, r, acc[1]);
+      }
+    }
   }
   block_reduce<2>(acc, lds);
   if (threadIdx.x == 0) {
@@ -166,7 +196,13 @@ __device__ __forceinline__ void finalize_pair(const float num, const float den_r
 // t, t + 256, ... and a fixed LDS tree: the same value in whichever workgroup evaluates it
 __device__ __forceinline__ double shard_mask_total(const float* __restrict__ wsA, int nparts_a, double* lds /* [kLossThreads] */) {
   double den = 0.0;
-  for (int i = threadIdx.x; i < nparts_a; i += kLossThreads) den += (double)wsA[(size_t)i * 6 + 5];
+  for (int i0 = threadIdx.x; i0 < nparts_a; i0 += kStreamUnroll * kLossThreads) {
+    float t[kStreamUnroll];
+#pragma unroll
+    for (int u = 0; u < kStreamUnroll; ++u) t[u] = i0 + u * kLossThreads < nparts_a ? wsA[(size_t)(i0 + u * kLossThreads) * 6 + 5] : 0.0f;
+#pragma unroll
+    for (int u = 0; u < kStreamUnroll; ++u) den += (double)t[u];
+  }
   lds[threadIdx.x] = den;
   __syncthreads();
   for (int s = kLossThreads / 2; s > 0; s >>= 1) {
@@ -212,18 +248,30 @@ __global__ __launch_bounds__(kLossThreads) void loss_stage_c(const float* __rest
     coef[2 * b + 1] = ks;
   }
   float acc[1] = {0.f};
-  for (int i = blockIdx.x * kLossThreads + threadIdx.x; i < n; i += kSplit * kLossThreads) {
-    const size_t o = (size_t)b * n + i;
-    const int p = i % RC;
-    const float raw = kd * diffuse[o] + ks * spec[o];
-    const float r = fminf(fmaxf(raw, 0.0f), 1.0f);
-    rendered[o] = r;
-    const float e = r - im_s[o], sg = seg_s[(size_t)b * RC + p];
-    acc[0] = fmaf(e * e, sg, acc[0]);
-    if (g_diffuse) {
-      const float g = (raw >= 0.0f && raw <= 1.0f) ? 2.0f * e * sg * gn : 0.0f;
-      g_diffuse[o] = g * kd;
-      g_spec[o] = g * ks;
+  constexpr int stride = kSplit * kLossThreads;
+  for (int i0 = blockIdx.x * kLossThreads + threadIdx.x; i0 < n; i0 += kStreamUnroll * stride) {      // loads of a round in flight together (see stage A)
+    float dv[kStreamUnroll], sv[kStreamUnroll], iv[kStreamUnroll], gv[kStreamUnroll];
+#pragma unroll
+    for (int u = 0; u < kStreamUnroll; ++u) {
+      const int i = i0 + u * stride < n ? i0 + u * stride : i0;
+      const size_t o = (size_t)b * n + i;
+      dv[u] = diffuse[o]; sv[u] = spec[o]; iv[u] = im_s[o]; gv[u] = seg_s[(size_t)b * RC + i % RC];
+    }
+#pragma unroll
+    for (int u = 0; u < kStreamUnroll; ++u) {
+      if (i0 + u * stride < n) {
+        const size_t o = (size_t)b * n + i0 + u * stride;
+        const float raw = kd * dv[u] + ks * sv[u];
+        const float r = fminf(fmaxf(raw, 0.0f), 1.0f);
+        rendered[o] = r;
+        const float e = r - iv[u], sg = gv[u];
+        acc[0] = fmaf(e * e, sg, acc[0]);
+        if (g_diffuse) {
+          const float g = (raw >= 0.0f && raw <= 1.0f) ? 2.0f * e * sg * gn : 0.0f;
+          g_diffuse[o] = g * kd;
+          g_spec[o] = g * ks;
+        }
+      }
     }
   }
   block_reduce<1>(acc, lds);
