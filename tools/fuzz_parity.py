@@ -24,8 +24,8 @@ def main():
     bad = 0
     for case in range(n):
         bn, R, C, q = ri(1, 3), ri(3, 13), ri(3, 17), (1, 2)[ri(0, 1)]
-        K, eh = ri(1, 12), ri(1, 9)
-        ew = 16
+        ew = (16, 32)[ri(0, 1)]
+        K, eh = ri(1, 24 if ri(0, 2) == 0 else 12), ri(1, 9 if ew == 16 else 16)
         imH, imW = R * q, C * q
         inp = O.synthetic_inputs(bn, imH, imW, R, C, K, eh, ew, seed=1000 + case, benign=bool(ri(0, 1)))
         ind = (torch.rand(bn, 1, 1, 1, generator=g) < 0.8).float()
@@ -47,12 +47,30 @@ def main():
         ro, _, _, _ = O.render_loss(do, so, xo["im"], xo["seg"], R, C)
         co, _, _, _ = O.recon_loss(eo, xo["env_gt"], xo["seg"], ind.double(), R, C)
         g3 = torch.autograd.grad(ro + 10.0 * co, [xo["axis"], xo["lamb"], xo["weight"]])
-        errs.update(render=abs(obj[1].item() - ro.item()) / max(1.0, ro.item()), recon=abs(obj[2].item() - co.item()) / max(1.0, co.item()),
+        errs.update(render=abs(obj[1].item() - ro.item()) / max(1e-12, abs(ro.item())), recon=abs(obj[2].item() - co.item()) / max(1e-12, abs(co.item())),
                     **{f"o{i}": rel(a, b) for i, (a, b) in enumerate(zip(go2, g3))})
+        # forward-only route (no gradient kernel) returns the same values
+        with torch.no_grad():
+            obj_ng = sgr.light_objective(layer, x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], x["im"], x["seg"],
+                                         x["env_gt"], ind.cuda(), 1.0, 10.0)
+        errs.update(ng=abs(obj_ng[0].item() - obj[0].item()) / max(1e-12, abs(obj[0].item())))
         worst = max(errs.values())
+        if str(case) in os.environ.get("FUZZ_VERBOSE", "").split(","):      # every quantity, and the fp32 oracle's own error as the yardstick
+            x32 = {k: v.float() for k, v in inp.items()}
+            for k in ("axis", "lamb", "weight"):
+                x32[k] = x32[k].clone().requires_grad_(True)
+            e3, d3, s3 = O.render_from_sg(x32["albedo"], x32["normal"], x32["rough"], x32["axis"], x32["lamb"], x32["weight"], eh, ew)
+            g32 = torch.autograd.grad([e3, d3, s3], [x32["axis"], x32["lamb"], x32["weight"]], grad_outputs=ct, retain_graph=True)
+            r3, _, _, _ = O.render_loss(d3, s3, x32["im"], x32["seg"], R, C)
+            c3, _, _, _ = O.recon_loss(e3, x32["env_gt"], x32["seg"], ind.float(), R, C)
+            o32 = torch.autograd.grad(r3 + 10.0 * c3, [x32["axis"], x32["lamb"], x32["weight"]])
+            y = dict(env=rel(e3, eo), d=rel(d3, do), s=rel(s3, so), **{f"g{i}": rel(a, b) for i, (a, b) in enumerate(zip(g32, go))},
+                     render=abs(r3.item() - ro.item()) / abs(ro.item()), recon=abs(c3.item() - co.item()) / abs(co.item()),
+                     **{f"o{i}": rel(a, b) for i, (a, b) in enumerate(zip(o32, g3))})
+            print(f"   case {case}: " + "  ".join(f"{k} {v:.1e} (fp32 oracle {y.get(k, float('nan')):.1e})" for k, v in errs.items()))
         ok = worst < 5e-4 and all(torch.isfinite(t).all() for t in list(gr) + list(go2))
         bad += not ok
-        print(f"case {case:2d} bn={bn} R={R} C={C} q={q * q} K={K} eh={eh}  worst {worst:.2e} {'ok' if ok else 'FAIL ' + str(errs)}")
+        print(f"case {case:3d} bn={bn} R={R} C={C} q={q * q} K={K} eh={eh} ew={ew} fused={bool(sgr.light_objective_supported(K, R, C, eh, ew))}  worst {worst:.2e} {'ok' if ok else 'FAIL ' + str(errs)}")
     print(f"{n - bad}/{n} cases within 5e-4")
     sys.exit(1 if bad else 0)
 
