@@ -139,6 +139,24 @@ int main(int argc, char** argv) {
     bench("sgr_fused_bwd_recon (premap 2)", Bbrdf + Bsg + Bout + Benv + Bsg, [&] { return sgr_fused_bwd_recon_p(albedo, normal, rough, axis, lam_t, w_t, dirs, view, env_gt, mask, rcoef, (float*)nullptr, g_d, g_s, g_axis, g_lamb, g_weight, rparts, fws, bn, K, R, C, eh, ew, imH, imW, F0d, 2, 1.0f, 10.0f, st); });
   }
   bench("sgr_fused_bwd_recon", Bbrdf + Bsg + Bout + Benv + Bsg, [&] { return sgr_fused_bwd_recon_p(albedo, normal, rough, axis, lamb, weight, dirs, view, env_gt, mask, rcoef, (float*)nullptr, g_d, g_s, g_axis, g_lamb, g_weight, rparts, fws, bn, K, R, C, eh, ew, imH, imW, F0d, 1, 1.0f, 10.0f, st); });
+  // the objective's forward half: round 3's six launches (statistics kernel + fold, three loss passes, loss backward) against ABI 5's four
+  {
+    auto obj_fwd_p = (decltype(&sgr_light_objective_fwd))dlsym(lib, "sgr_light_objective_fwd");
+    auto seg_p = (decltype(&sgr_fused_fwd_recon_seg))dlsym(lib, "sgr_fused_fwd_recon_seg");
+    auto bwd_scaled_p = (decltype(&sgr_render_loss_bwd_scaled))dlsym(lib, "sgr_render_loss_bwd_scaled");
+    const double bytes = Bbrdf + Bsg + Benv + Bout + 3 * 4 * q + 4 * q + 24 + 12 + 4 + 12 + 36 + 24;
+    if (seg_p && bwd_scaled_p)
+      bench("objective fwd half, separate calls (6 k.)", bytes, [&] {
+        int rc = seg_p(albedo, normal, rough, axis, lamb, weight, dirs, view, env_gt, seg, imH, imW, ind, (float*)nullptr, (float*)nullptr, diffuse, spec, mask, rcoef,
+                       (float*)nullptr, fws, bn, K, R, C, eh, ew, imH, imW, F0d, 1, st);
+        rc |= sgr_render_loss_fwd_total_p(diffuse, spec, im, seg, im_s, seg_s, rendered, coef, parts, lossv, lossv + 1, 3.0f, ws, bn, R, C, imH, imW, st);
+        rc |= bwd_scaled_p((const float*)nullptr, 1.0f, lossv + 1, diffuse, spec, im_s, seg_s, coef, g_d, g_s, bn, R, C, st);
+        return rc; });
+    if (obj_fwd_p)
+      bench("sgr_light_objective_fwd (4 k.)", bytes, [&] {
+        return obj_fwd_p(albedo, normal, rough, axis, lamb, weight, dirs, view, env_gt, im, seg, ind, (float*)nullptr, (float*)nullptr, diffuse, spec, mask, rcoef, im_s, seg_s,
+                         rendered, coef, parts, lossv, lossv + 1, 1.0f, g_d, g_s, fws, ws, bn, K, R, C, eh, ew, imH, imW, imH, imW, F0d, 1, st); });
+  }
   // decoder heads: standalone passes vs the prologue / epilogue of the fused kernels (premap 3)
   auto heads_fwd_p = (decltype(&sgr_light_heads_fwd))dlsym(lib, "sgr_light_heads_fwd");
   auto heads_bwd_p = (decltype(&sgr_light_heads_bwd))dlsym(lib, "sgr_light_heads_bwd");
