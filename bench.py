@@ -274,7 +274,9 @@ def main() -> None:
             dom_name = ("sg_bwd" if dom[0] == "bwd" else "fwd") + " kernel (no PMC record for this workload)"
         # the resource that actually binds the fused kernels: VALU issue.  SQ counters of the same workload (tools/pmc_sq.sh ->
         # profiles/sq.json): SQ_ACTIVE_INST_VALU counts, per SIMD quad, the cycles a VALU instruction is in flight; x 4 / SIMDs
-        # against the kernel's duration in shader-clock cycles (GRBM_GUI_ACTIVE / XCDs) is the fraction of issue cycles used.
+        # against the kernel's duration in shader-clock cycles is the fraction of issue cycles used.  Round 5: the duration is the
+        # per-shader-engine SQ_BUSY_CYCLES (capped at kernel_ms x 2.4 GHz), not GRBM_GUI_ACTIVE / XCDs, which under the counter mode
+        # also counts the launch's pre- and post-amble and implied clocks above the part's maximum (tools/parse_sq.py).
         # Both records are OFFLINE (counter passes cannot run inside the timed loop) and stamped with the hash of the kernel sources
         # they were measured on: a record from other sources is reported as stale and does not decide `limited_by`
         valu = valu_roofline(tkey, want, dom[1])
@@ -385,8 +387,10 @@ def valu_roofline(tkey, patterns, live_ms):
         r = recs[n]
         busy, total = r["valu_busy_cycles_per_simd"], r["kernel_cycles"]
         return {"bound": "valu_issue", "kernel": n.split("::")[-1], "achieved": round(busy), "peak": round(total),
-                "unit": "SIMD issue cycles per launch (SQ_ACTIVE_INST_VALU x 4 / SIMDs vs GRBM_GUI_ACTIVE / XCDs)",
-                "frac": round(busy / total, 4), "valu_instructions_per_wave": r.get("valu_insts_per_wave"),
+                "unit": "SIMD issue cycles per launch (SQ_ACTIVE_INST_VALU x 4 / SIMDs vs " + r.get("kernel_cycles_source", "GRBM_GUI_ACTIVE / XCDs") + ")",
+                "frac": round(busy / total, 4), "frac_at_max_clock": r.get("frac_at_max_clock"), "effective_clock_GHz": r.get("effective_clock_GHz"),
+                "issue_rate_busy_cycles_per_us": r.get("issue_rate_per_us"), "per_wave_cycle_shares": r.get("per_wave_cycle_shares"),
+                "valu_instructions_per_wave": r.get("valu_insts_per_wave"),
                 "transcendental_share": r.get("trans_share"), "pmc_kernel_ms": r.get("kernel_ms"), "live_kernel_ms": round(live_ms, 4),
                 "record": "offline", "record_stale": stale,
                 "source": "profiles/sq.json (tools/pmc_sq.sh on this workload; counters are per launch, not re-measured live; "

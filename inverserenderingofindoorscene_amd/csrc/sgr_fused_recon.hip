@@ -23,6 +23,7 @@
 //   each half evaluates loss, reconstruction and render cotangent for the half row it now holds (6 values)
 //   swap(D = g, S = g):  D = cotangent of half row 1 in all lanes, S = cotangent of half row 0 in all lanes
 // 12 VALU swaps + 6 adds per chunk; no LDS traffic, no barrier, no duplicated transcendental.
+#include <stdlib.h>
 #include <string.h>
 #include "sgr_forward.inl"
 #include "sgr_recon_fold.h"
@@ -77,9 +78,11 @@ template <> __device__ __forceinline__ void wait_vmcnt<3>() { asm volatile("s_wa
 // GRADS = false (round 4): the same pass without its gradient half -- the reconstruction-loss VALUE alone, for forward-only callers
 // of the objective (torch.no_grad(): testLight.py-style evaluation): lobes -> exponentials -> radiance of the azimuth pair -> the
 // log-L2 term.  No shading frame, no cotangents, no accumulators, no all-gather; the first 6 (+3) swaps stay.
-template <int POOL, int EW = 16, int NG = 2, bool HEADS = false, bool GRADS = true>
-__global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a) {
-  constexpr int HALF = 8, NP = 4, KPW = 6, Q = EW / 16, PXW = kWave / NG;       // PXW pixels per wave
+// KPW lobes per lane group (round 5: NG = 4 x KPW = 3 carries the reference's 12 lobes at a quarter of the accumulators per lane -- the
+// review's candidate for more resident waves; see SGR_RECON_K12_NG4 at the launch), OCC = resident waves per SIMD asked of the compiler
+template <int POOL, int EW = 16, int NG = 2, bool HEADS = false, bool GRADS = true, int KPW = 6, int OCC = 2>
+__global__ __launch_bounds__(kWave, OCC) void sg_bwd_recon_pk_kernel(const Args a) {
+  constexpr int HALF = 8, NP = 4, KH = (KPW + 1) / 2, Q = EW / 16, PXW = kWave / NG;       // PXW pixels per wave
   constexpr int kTile = 3 * PXW * 16;                                           // floats per ground-truth virtual-row tile
   // ground-truth rows: double-buffered one-row tiles, row vr+1 requested while row vr is consumed.  PMC (round 4, profiles/r04b_pmc_traffic_
   // config2_batch16_objective.txt): 826 MB fetched where ~610 MB are read -- a row is one 64-byte half of each 128-byte line, and the other
@@ -172,9 +175,9 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
       if (GRADS && !ORTHO) fence_row_invariants(q);
       const f32x8 row = rows[e];
       const float sr = row[0], cr = row[1];
-      f32x2 czr[KPW / 2];
+      f32x2 czr[KH];
 #pragma unroll
-      for (int mm = 0; mm < KPW / 2; ++mm) czr[mm] = pfma(P.azp[mm], splat2(cr), -P.lpp[mm]);      // lp (az c_e - 1)
+      for (int mm = 0; mm < KH; ++mm) czr[mm] = pfma(P.azp[mm], splat2(cr), -P.lpp[mm]);      // lp (az c_e - 1)
       const RowCtx rc = make_row_ctx(q, row, GRADS);
       OrthoRow orow = make_ortho_row(rc.ro);
 
@@ -183,11 +186,11 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
 #if SGR_RECON_FENCES >= 1
         fence_lobes<KPW>(P);
 #pragma unroll
-        for (int mm = 0; mm < KPW / 2; ++mm) { SGR_FENCE2(czr[mm]); }
+        for (int mm = 0; mm < KH; ++mm) { SGR_FENCE2(czr[mm]); }
 #endif
 #if SGR_RECON_FENCES >= 2
 #pragma unroll
-        for (int mm = 0; mm < KPW / 2; ++mm) { SGR_FENCE2(P.lpp[mm]); }
+        for (int mm = 0; mm < KH; ++mm) { SGR_FENCE2(P.lpp[mm]); }
 #pragma unroll
         for (int c = 0; c < 3; ++c) SGR_FENCE2(gds[c]);
         SGR_FENCE2(grec);
@@ -584,7 +587,12 @@ static int fused_bwd_recon_impl(const float* albedo, const float* normal, const 
   set_dims(a, bn, K, R, C, eh, ew, imH, imW);
   a.F0 = F0; a.premap = premap;
   const int tiles32 = recon_tiles32(R * C);
-  const bool four = K > 12;                          // four lane groups of six lobes per pixel: 16 pixels per wave
+  // round 5 experiment: 7..12 lobes on the 8x16 grid as four lane groups of THREE lobes -- a quarter of the
+  // accumulators per lane, three or four resident waves per SIMD.  SGR_RECON_K12 = 1: asked for four waves, 2: three; unset / 0: the
+  // two-group kernel.  Read once.
+  static const int k12_mode = [] { const char* e = getenv("SGR_RECON_K12"); return e ? atoi(e) : 0; }();
+  const bool four3 = k12_mode > 0 && K > 6 && K <= 12 && ew == 16;
+  const bool four = K > 12 || four3;                 // four lane groups per pixel: 16 pixels per wave
   const int tiles = four ? recon_tiles16(R * C) : tiles32;
   float* den_img = workspace;
   float* ws1 = workspace + bn + 4 + (size_t)bn * tiles32 * 3;
@@ -606,11 +614,27 @@ static int fused_bwd_recon_impl(const float* albedo, const float* normal, const 
         else hipLaunchKernelGGL((sg_bwd_recon_pk_kernel<2, EW_, NG_>), grid, block, 0, st, a);               \
       }                                                                                                      \
     } while (0)
-    if (!four && ew == 16) SGR_LAUNCH_BR(16, 2);
+#define SGR_LAUNCH_BR3(OCC_)                                                                                 \
+    do {                                                                                                     \
+      if (!grads) {                                                                                          \
+        if (premap == 3) hipLaunchKernelGGL((sg_bwd_recon_pk_kernel<1, 16, 4, true, false, 3, OCC_>), grid, block, 0, st, a);   \
+        else hipLaunchKernelGGL((sg_bwd_recon_pk_kernel<1, 16, 4, false, false, 3, OCC_>), grid, block, 0, st, a);              \
+      } else if (premap == 3) {                                                                              \
+        if (p1) hipLaunchKernelGGL((sg_bwd_recon_pk_kernel<1, 16, 4, true, true, 3, OCC_>), grid, block, 0, st, a);      \
+        else hipLaunchKernelGGL((sg_bwd_recon_pk_kernel<2, 16, 4, true, true, 3, OCC_>), grid, block, 0, st, a);         \
+      } else {                                                                                               \
+        if (p1) hipLaunchKernelGGL((sg_bwd_recon_pk_kernel<1, 16, 4, false, true, 3, OCC_>), grid, block, 0, st, a);     \
+        else hipLaunchKernelGGL((sg_bwd_recon_pk_kernel<2, 16, 4, false, true, 3, OCC_>), grid, block, 0, st, a);        \
+      }                                                                                                      \
+    } while (0)
+    if (four3 && k12_mode == 1) SGR_LAUNCH_BR3(4);
+    else if (four3) SGR_LAUNCH_BR3(3);
+    else if (!four && ew == 16) SGR_LAUNCH_BR(16, 2);
     else if (!four) SGR_LAUNCH_BR(32, 2);
     else if (ew == 16) SGR_LAUNCH_BR(16, 4);
     else SGR_LAUNCH_BR(32, 4);
 #undef SGR_LAUNCH_BR
+#undef SGR_LAUNCH_BR3
   }
   hipLaunchKernelGGL(recon_fold1, dim3(1), dim3(kFold1Threads), 0, st, ws1, den_img, parts, bn, tiles, tail);     // parts = (loss numerator, local sum of the env mask)
   return sgr_check((int)hipGetLastError(), "sgr_fused_bwd_recon");

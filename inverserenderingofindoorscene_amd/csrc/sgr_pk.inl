@@ -39,16 +39,17 @@ namespace sgr {
 #endif
 // -DSGR_TRACE (development builds only, tools/wavetrace): every wave of the packed kernels records when and where it ran
 #ifdef SGR_TRACE
-struct TraceRec { unsigned long long t0, t1, tp; unsigned hw, xcc; };
+// t*: s_memrealtime (100 MHz, wall); c*: s_memtime (shader-clock cycles) -- round 5: (c1 - c0) / (t1 - t0) is the clock the wave actually ran at
+struct TraceRec { unsigned long long t0, t1, tp, c0, c1; unsigned hw, xcc; };
 static __device__ TraceRec* g_trace = nullptr;
-#define SGR_TRACE_BEGIN const unsigned long long trace_t0_ = __builtin_amdgcn_s_memrealtime(); unsigned long long trace_tp_ = 0;
+#define SGR_TRACE_BEGIN const unsigned long long trace_t0_ = __builtin_amdgcn_s_memrealtime(), trace_c0_ = __builtin_amdgcn_s_memtime(); unsigned long long trace_tp_ = 0;
 #define SGR_TRACE_MARK trace_tp_ = __builtin_amdgcn_s_memrealtime();
 #define SGR_TRACE_END                                                                                  \
   if (threadIdx.x == 0 && g_trace) {                                                                   \
     unsigned hw_, xcc_;                                                                                \
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                                  \
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                                \
-    TraceRec r_; r_.t0 = trace_t0_; r_.t1 = __builtin_amdgcn_s_memrealtime(); r_.tp = trace_tp_; r_.hw = hw_; r_.xcc = xcc_; \
+    TraceRec r_; r_.t0 = trace_t0_; r_.t1 = __builtin_amdgcn_s_memrealtime(); r_.tp = trace_tp_; r_.c0 = trace_c0_; r_.c1 = __builtin_amdgcn_s_memtime(); r_.hw = hw_; r_.xcc = xcc_; \
     g_trace[blockIdx.x] = r_;                                                                          \
   }
 #else
@@ -107,11 +108,12 @@ __device__ __forceinline__ Pix locate_unit(const Args& a, int u) {
 // what the decoders' clamp produces -- is replaced by the floor: exp2(2^-40 t) is exactly 1, like exp2(0 t).
 template <int KP>
 struct LobesPk {
+  static constexpr int KH = (KP + 1) / 2;      // lobe pairs; an odd KP (round 5: three lobes per lane group) leaves the last pair's second half unused
   f32x2 axy[KP];        // (ax, ay)
   f32x2 w01[KP];        // (w0, w1)
-  f32x2 w2p[KP / 2];    // (w2 of lobe 2m, w2 of lobe 2m+1)
-  f32x2 azp[KP / 2];    // (az, az)  likewise
-  f32x2 lpp[KP / 2];    // (lp, lp)  likewise
+  f32x2 w2p[KH];        // (w2 of lobe 2m, w2 of lobe 2m+1)
+  f32x2 azp[KH];        // (az, az)  likewise
+  f32x2 lpp[KH];        // (lp, lp)  likewise
 };
 // Two pre-maps at a time (round 3): tan(fl(fl(0.999 x) pi/2)) with the argument products, the Cody-Waite reduction and the
 // polynomial of sgr_math.h's tan_f32 issued as v_pk_mul / v_pk_fma_f32 over a register pair; only the parity select and
@@ -229,12 +231,12 @@ constexpr float kLpFloor = 9.094947017729282e-13f;
 // to 5 % (objective backward) through register allocation alone (measured, round 3).
 template <int KP, bool FOLD, bool HEADS = false>
 __device__ __forceinline__ void load_lobes_pk(const Args& a, int b, unsigned up, bool active, int kg, LobesPk<KP>& P, bool write_tan) {
-  static_assert(KP % 2 == 0, "lobes are packed in pairs");
+  constexpr int KH = (KP + 1) / 2, KE = 2 * KH;      // KE: KP rounded up to whole pairs (the pad slot mirrors lobe KP - 1, never stored)
   const int RC = a.R * a.C, K = a.K;
   const float* axis_b = a.axis + (size_t)b * K * 3 * RC;
   const float* lamb_b = a.lamb + (size_t)b * K * RC;
   const float* weight_b = a.weight + (size_t)b * K * 3 * RC;
-  float ax[KP], ay[KP], az[KP], lp[KP], w0[KP], w1[KP], w2[KP];
+  float ax[KE], ay[KE], az[KE], lp[KE], w0[KE], w1[KE], w2[KE];
   // addresses: wave-uniform plane base (SGPR pair, scalar arithmetic) + one 32-bit per-lane BYTE offset -> the
   // `global_load_dword v, v_off, s[base:base+1]` form with no per-load vector arithmetic (indexing a float* with a 32-bit
   // element index costs a 64-bit shift + add per load: the scaled index may not fit 32 bits as far as the compiler knows).
@@ -257,9 +259,10 @@ __device__ __forceinline__ void load_lobes_pk(const Args& a, int b, unsigned up,
     w1[k] = *reinterpret_cast<const float*>(pw + (size_t)RC * 4 + v3);
     w2[k] = *reinterpret_cast<const float*>(pw + (size_t)RC * 8 + v3);
   }
+  if (KE != KP) { ax[KP] = ax[KP - 1]; ay[KP] = ay[KP - 1]; az[KP] = az[KP - 1]; lp[KP] = lp[KP - 1]; w0[KP] = w0[KP - 1]; w1[KP] = w1[KP - 1]; w2[KP] = w2[KP - 1]; }
   if (HEADS) {
 #pragma unroll
-    for (int m = 0; m < KP / 2; ++m) {
+    for (int m = 0; m < KH; ++m) {
       float hx[2] = {ax[2 * m], ax[2 * m + 1]}, hy[2] = {ay[2 * m], ay[2 * m + 1]}, hz[2] = {az[2 * m], az[2 * m + 1]};
       float hl[2] = {lp[2 * m], lp[2 * m + 1]}, h0[2] = {w0[2 * m], w0[2 * m + 1]}, h1[2] = {w1[2 * m], w1[2 * m + 1]};
       float h2[2] = {w2[2 * m], w2[2 * m + 1]};
@@ -309,8 +312,9 @@ __device__ __forceinline__ void load_lobes_pk(const Args& a, int b, unsigned up,
     P.axy[k] = f32x2{ax[k], ay[k]};
     P.w01[k] = f32x2{w0[k], w1[k]};
   }
+  if (KE != KP) { w2[KP] = 0.0f; az[KP] = az[KP - 1]; lp[KP] = lp[KP - 1]; }
 #pragma unroll
-  for (int m = 0; m < KP / 2; ++m) {
+  for (int m = 0; m < KH; ++m) {
     P.w2p[m] = f32x2{w2[2 * m], w2[2 * m + 1]};
     P.azp[m] = f32x2{az[2 * m], az[2 * m + 1]};
     P.lpp[m] = f32x2{lp[2 * m], lp[2 * m + 1]};
@@ -321,7 +325,7 @@ __device__ __forceinline__ void fence_lobes(LobesPk<KP>& P) {
 #pragma unroll
   for (int k = 0; k < KP; ++k) { SGR_FENCE2(P.axy[k]); SGR_FENCE2(P.w01[k]); }
 #pragma unroll
-  for (int m = 0; m < KP / 2; ++m) SGR_FENCE2(P.w2p[m]);
+  for (int m = 0; m < (KP + 1) / 2; ++m) SGR_FENCE2(P.w2p[m]);
 }
 
 // Per-pixel and per-(pixel, table row) constants of the orthonormal microfacet path, in pairs (see brdf_ortho_dir)

@@ -53,3 +53,24 @@ def test_sq_records_feed_the_valu_roofline():
         f = b.valu_roofline(key, [r"fwd_pk_half_kernel<"], 0.15)
         assert f is not None and 0.3 < f["frac"] < 1.0, f
     assert b.valu_roofline("no_such_workload", [r"sg_bwd_pk_kernel<"], 0.25) is None
+
+
+def test_sq_records_imply_physical_clocks():
+    """Every record of profiles/sq.json: the kernel's cycle count over its traced duration must not exceed the part's maximum clock
+    (2.4 GHz, MI355X_MICROARCH.md) -- rounds 3-4 divided by GRBM_GUI_ACTIVE / XCDs, which implied 2.65-10 GHz and under-stated every
+    VALU-busy fraction (tools/parse_sq.py) -- and the busy fraction stays inside its two bounds."""
+    recs = json.load(open(os.path.join(ROOT, "profiles", "sq.json")))
+    n = 0
+    for tag, per_kernel in recs.items():
+        if tag.startswith("_"):
+            continue
+        for k, r in per_kernel.items():
+            if k.startswith("_"):
+                continue
+            # (no lower bound: a kernel of one workgroup keeps one shader engine of 32 busy, and the per-engine average says so)
+            assert r["effective_clock_GHz"] is None or 0.0 < r["effective_clock_GHz"] <= 2.45, (tag, k, r["effective_clock_GHz"])
+            assert 0.0 < r["frac"] <= 1.0, (tag, k, r["frac"])
+            if r.get("frac_at_max_clock") is not None:
+                assert r["frac_at_max_clock"] <= r["frac"] + 1e-3, (tag, k)
+            n += 1
+    assert n >= 10

@@ -86,7 +86,9 @@ int main(int argc, char** argv) {
   const bool cold = getenv("KBENCH_COLD") && atoi(getenv("KBENCH_COLD")) != 0;
   float* scratch = nullptr; const size_t scratch_bytes = (size_t)1 << 30;
   if (cold) CHECK(hipMalloc(&scratch, scratch_bytes));
+  const char* only = getenv("KBENCH_ONLY");      // substring filter on the entry names (A/B sessions time a few kernels, many times)
   auto bench = [&](const char* name, double bytes_per_px, std::function<int()> fn) {
+    if (only && !strstr(name, only)) return;
     int rc = fn(); if (rc) { printf("%-34s FAILED rc=%d\n", name, rc); return; }
     CHECK(hipStreamSynchronize(st));
     for (int i = 0; i < 2; ++i) fn();

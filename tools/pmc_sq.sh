@@ -12,6 +12,8 @@ mkdir -p $OUT
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/a -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --reps 1 --no-cpu-baseline --layer-only "$@" > $OUT/a.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_ANY --output-format csv -d $OUT/b -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --reps 1 --no-cpu-baseline --layer-only "$@" > $OUT/b.log 2>&1
+# round 5: where a wave's resident cycles go (quad-cycles summed over waves): issuing by instruction class / waiting
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS --output-format csv -d $OUT/c -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --reps 1 --no-cpu-baseline --layer-only "$@" > $OUT/c.log 2>&1
 cd $GRAFT_REPO_ROOT
 python tools/parse_sq.py $OUT $TAG gpurun_out/sq.json > $OUT/summary.txt 2>&1; cat $OUT/summary.txt
 find $OUT -name "*.csv" -size +2M -delete

@@ -1,7 +1,8 @@
 // Per-wave schedule trace of the packed forward / backward kernels (development tool; needs a -DSGR_TRACE build of the library:
 //   make -C inverserenderingofindoorscene_amd/csrc OBJDIR=build_trace OUT=../variants/libsgrender_trace.so EXTRA=-DSGR_TRACE).
 //   hipcc -O2 tools/wavetrace.cpp -o tools/wavetrace -ldl ;  tools/wavetrace variants/libsgrender_trace.so [bn] > trace.txt
-// Output: one line per wave "kernel wave_id t0 t1 xcc se sh cu simd" (t in 10 ns ticks of s_memrealtime, relative to the first wave).
+// Output: one line per wave "kernel wave_id t0 t1 xcc se sh cu simd prologue_ticks shader_cycles" (t in 10 ns ticks of s_memrealtime, relative to the
+// first wave; shader_cycles = s_memtime over the same interval: cycles / ticks / 10 ns = the clock the wave ran at).
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -10,7 +11,7 @@
 #include <vector>
 #include "../include/sgrender.h"
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
-struct TraceRec { unsigned long long t0, t1, tp; unsigned hw, xcc; };
+struct TraceRec { unsigned long long t0, t1, tp, c0, c1; unsigned hw, xcc; };
 static float* dev_rand(size_t n, float lo, float hi, unsigned seed) {
   std::vector<float> h(n); unsigned s = seed * 2654435761u + 12345u;
   for (size_t i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; h[i] = lo + (hi - lo) * ((s >> 8) * (1.0f / 16777216.0f)); }
@@ -65,8 +66,8 @@ int main(int argc, char** argv) {
     unsigned long long tmin = ~0ull; for (size_t i = 0; i < waves; ++i) if (h[i].t0 && h[i].t0 < tmin) tmin = h[i].t0;
     printf("# %s waves=%zu event_us=%.1f\n", name, waves, ms * 1e3);
     for (size_t i = 0; i < waves; ++i)
-      printf("%s %zu %llu %llu %u %u %u %u %u %llu\n", name, i, h[i].t0 - tmin, h[i].t1 - tmin, h[i].xcc & 0xf, (h[i].hw >> 13) & 7, (h[i].hw >> 12) & 1,
-             (h[i].hw >> 8) & 15, (h[i].hw >> 4) & 3, h[i].tp - h[i].t0);
+      printf("%s %zu %llu %llu %u %u %u %u %u %llu %llu\n", name, i, h[i].t0 - tmin, h[i].t1 - tmin, h[i].xcc & 0xf, (h[i].hw >> 13) & 7, (h[i].hw >> 12) & 1,
+             (h[i].hw >> 8) & 15, (h[i].hw >> 4) & 3, h[i].tp - h[i].t0, h[i].c1 - h[i].c0);
   };
   const size_t w64 = (size_t)bn * ((RC + 63) / 64), w32 = (size_t)bn * ((RC + 31) / 32);
   const size_t wfe = w32;      // the forward that writes the env image: half-wave kernel, one workgroup per 32 pixels (round 3)
@@ -118,8 +119,8 @@ int main(int argc, char** argv) {
     if (rep == 2) {
       printf("# fwd_env_after_bwd waves=%zu\n", wfe);
       for (size_t i = 0; i < wfe; ++i)
-        printf("fwd_env_after_bwd %zu %llu %llu %u %u %u %u %u %llu\n", i, h[i].t0 - f0, h[i].t1 - f0, h[i].xcc & 0xf, (h[i].hw >> 13) & 7, (h[i].hw >> 12) & 1,
-               (h[i].hw >> 8) & 15, (h[i].hw >> 4) & 3, h[i].tp - h[i].t0);
+        printf("fwd_env_after_bwd %zu %llu %llu %u %u %u %u %u %llu %llu\n", i, h[i].t0 - f0, h[i].t1 - f0, h[i].xcc & 0xf, (h[i].hw >> 13) & 7, (h[i].hw >> 12) & 1,
+               (h[i].hw >> 8) & 15, (h[i].hw >> 4) & 3, h[i].tp - h[i].t0, h[i].c1 - h[i].c0);
     }
   }
   return 0;

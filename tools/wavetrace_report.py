@@ -9,12 +9,17 @@ for line in open(sys.argv[1]):
     f = line.split()
     k, i, t0, t1, xcc, se, sh, cu, simd = f[:9]
     tp = int(f[9]) if len(f) > 9 else 0
-    runs.setdefault(k, []).append((int(t0), int(t1), (int(xcc), int(se), int(sh), int(cu), int(simd)), tp))
+    cyc = int(f[10]) if len(f) > 10 else 0
+    runs.setdefault(k, []).append((int(t0), int(t1), (int(xcc), int(se), int(sh), int(cu), int(simd)), tp, cyc))
 for k, ws in runs.items():
     span = max(w[1] for w in ws)
     dur = sorted(w[1] - w[0] for w in ws)
     simds = collections.defaultdict(list)
-    for t0, t1, s, tp in ws: simds[s].append((t0, t1))
+    for t0, t1, s, tp, cyc in ws: simds[s].append((t0, t1))
+    if any(w[4] for w in ws):      # round 5: shader clock under load = s_memtime cycles / s_memrealtime ticks (10 ns), per wave
+        clk = sorted(w[4] / max(w[1] - w[0], 1) / 10.0 for w in ws)
+        tot = sum(w[4] for w in ws) / max(sum(w[1] - w[0] for w in ws), 1) / 10.0
+        print(f"   shader clock over the waves' lifetimes (GHz): mean {tot:.3f}  min/10%/med/90%/max {clk[0]:.3f}/{clk[len(clk)//10]:.3f}/{clk[len(clk)//2]:.3f}/{clk[9*len(clk)//10]:.3f}/{clk[-1]:.3f}")
     pro = sorted(w[3] for w in ws)
     print(f"   prologue (loads + pre-map + frame) min/med/90%/max {pro[0]/100:.1f}/{pro[len(pro)//2]/100:.1f}/{pro[9*len(pro)//10]/100:.1f}/{pro[-1]/100:.1f} us")
     n = len(simds)
