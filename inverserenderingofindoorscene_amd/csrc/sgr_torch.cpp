@@ -30,6 +30,7 @@
 #include <dlfcn.h>
 
 #include <cstdlib>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <string>
@@ -186,19 +187,36 @@ struct TableKey {
 };
 std::mutex g_tables_mutex;
 std::map<TableKey, Tensor> g_tables;
-constexpr size_t kMaxTables = 64;      // testReal.py builds a layer per image size: keep the cache bounded
+std::deque<TableKey> g_view_order;     // view-vector tables (kind 1) in insertion order
+constexpr size_t kMaxViewTables = 64;  // testReal.py builds a layer per image size: keep the cache bounded
 
+// The bound applies to the view-vector tables only, oldest first (erasing the smallest key evicted the per-device direction
+// table -- kind 0 sorts first -- on every view-table miss once the cache was full: two rebuilds and two synchronous uploads per call).
+// The direction tables (one per device and direction grid: a handful) are never evicted.
 template <typename Fill>
 Tensor table(const TableKey& key, const c10::Device& dev, int64_t n, Fill fill) {
   std::lock_guard<std::mutex> lock(g_tables_mutex);
   auto it = g_tables.find(key);
   if (it != g_tables.end()) return it->second;
-  if (g_tables.size() >= kMaxTables) g_tables.erase(g_tables.begin());
+  if (key.kind == 1) {
+    if (g_view_order.size() >= kMaxViewTables) {
+      g_tables.erase(g_view_order.front());
+      g_view_order.pop_front();
+    }
+    g_view_order.push_back(key);
+  }
   Tensor host = at::empty({n}, at::TensorOptions().dtype(at::kFloat));
   fill(host.data_ptr<float>());
   Tensor t = host.to(dev);
   g_tables.emplace(key, t);
   return t;
+}
+// test hook (tests/test_gpu_ops.py): number of cached tables of a kind (0 direction tables, 1 view-vector tables)
+int64_t table_cache_count(int64_t kind) {
+  std::lock_guard<std::mutex> lock(g_tables_mutex);
+  int64_t n = 0;
+  for (const auto& kv : g_tables) n += kv.first.kind == (int)kind;
+  return n;
 }
 Tensor dirs_table(const c10::Device& dev, int64_t eh, int64_t ew) {
   TORCH_CHECK(eh > 0 && ew > 0, "sgrender: envHeight / envWidth must be positive");
@@ -1066,6 +1084,28 @@ T5 light_objective_autograd(const Tensor& albedo, const Tensor& normal, const Te
   return {objective, std::get<1>(o), std::get<2>(o), std::get<3>(o), std::get<4>(o)};
 }
 
+// floats of the fused objective's workspace: sgr_fused_recon_workspace_floats (csrc/sgr_fused_recon.hip) restated as host arithmetic, so that
+// the Meta kernels report the real size without loading the kernel library (tests/test_ops_registration.py holds the two together)
+int64_t recon_workspace_floats(int64_t bn, int64_t R, int64_t C) {
+  const int64_t rc = R * C, tiles32 = (rc + 31) / 32, tiles16 = (rc + 15) / 16;
+  return bn + 4 + bn * tiles32 * 3 + bn * tiles16;
+}
+// stage 2 takes stage 1's tensors as they are: sizes implied by (bn, R, C), checked for device and meta tensors alike (a
+// tensor of another shard or shape made the kernels read and write out of bounds instead of raising)
+void check_stage1_tensors(int64_t bn, int64_t R, int64_t C, const Tensor& mask, const Tensor& coef, const Tensor& diffuse, const Tensor& spec, const Tensor& im_s,
+                          const Tensor& seg_s, const Tensor& coef_ds, const Tensor& sums, const Tensor& ws) {
+  const int64_t px = bn * R * C;
+  TORCH_CHECK(mask.numel() == px, "sgrender: light_objective_stage2: mask must have bn*R*C = ", px, " elements, got ", mask.sizes());
+  TORCH_CHECK(coef.numel() == bn, "sgrender: light_objective_stage2: coef must have bn = ", bn, " elements, got ", coef.sizes());
+  TORCH_CHECK(diffuse.numel() == 3 * px && spec.numel() == 3 * px && im_s.numel() == 3 * px,
+              "sgrender: light_objective_stage2: diffuse / spec / im_s must be [bn,3,R,C] = ", 3 * px, " elements, got ", diffuse.sizes(), " ", spec.sizes(), " ", im_s.sizes());
+  TORCH_CHECK(seg_s.numel() == px, "sgrender: light_objective_stage2: seg_s must be [bn,1,R,C], got ", seg_s.sizes());
+  TORCH_CHECK(coef_ds.numel() == 2 * bn, "sgrender: light_objective_stage2: coef_ds must be [bn,2], got ", coef_ds.sizes());
+  TORCH_CHECK(sums.numel() == 4, "sgrender: light_objective_stage2: sums must have 4 elements, got ", sums.sizes());
+  TORCH_CHECK(ws.numel() == recon_workspace_floats(bn, R, C), "sgrender: light_objective_stage2: ws must be stage 1's workspace of ",
+              recon_workspace_floats(bn, R, C), " floats, got ", ws.sizes());
+}
+
 // ---- the same objective under batch sharding: three stage operators with the two collectives between them ----
 // stage 1: forward statistics pass + render-loss passes -> sums = [num_r, den_r, 0, den_e] for ONE all-reduce before the backward pass
 using T12 = std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor>;
@@ -1084,7 +1124,8 @@ T12 light_objective_stage1_cuda(const Tensor& albedo, const Tensor& normal, cons
   Tensor diffuse = at::empty({d.bn, 3, d.R, d.C}, o), spec = at::empty({d.bn, 3, d.R, d.C}, o), im_s = at::empty({d.bn, 3, d.R, d.C}, o);
   Tensor seg_s = at::empty({d.bn, 1, d.R, d.C}, o), rendered = at::empty({d.bn, 3, d.R, d.C}, o), mask = at::empty({d.bn, d.R * d.C}, o), coef = at::empty({d.bn}, o);
   Tensor coef_ds = at::empty({d.bn, 2}, o), sums = at::empty({4}, o);
-  Tensor ws = at::empty({A.sgr_fused_recon_workspace_floats(bn, R, C)}, o), ws_r = loss_workspace(d.bn, a);
+  TORCH_CHECK(A.sgr_fused_recon_workspace_floats(bn, R, C) == recon_workspace_floats(d.bn, d.R, d.C), "sgrender: workspace size disagrees with the kernel library");
+  Tensor ws = at::empty({recon_workspace_floats(d.bn, d.R, d.C)}, o), ws_r = loss_workspace(d.bn, a);
   handoff = handoff && !heads;
   Tensor lam_t = handoff ? at::empty_like(la) : none_like(a), w_t = handoff ? at::empty_like(we) : none_like(a);
   const Tensor dirs = dirs_table(dev, eh, ew), view = view_table(dev, d.R, d.C, fov, cam);
@@ -1106,13 +1147,13 @@ T12 light_objective_stage1_meta(const Tensor& albedo, const Tensor& normal, cons
   const bool h = handoff && !heads;
   auto img = [&] { return at::empty({d.bn, 3, d.R, d.C}, o); };
   return {img(), img(), at::empty({d.bn, d.R * d.C}, o), at::empty({d.bn}, o), img(), at::empty({d.bn, 1, d.R, d.C}, o), img(), at::empty({d.bn, 2}, o), at::empty({4}, o),
-          at::empty({1}, o), h ? at::empty(lamb.sizes(), o) : none_like(albedo), h ? at::empty(weight.sizes(), o) : none_like(albedo)};
+          at::empty({recon_workspace_floats(d.bn, d.R, d.C)}, o), h ? at::empty(lamb.sizes(), o) : none_like(albedo), h ? at::empty(weight.sizes(), o) : none_like(albedo)};
 }
 // stage 2 (sums = the rank-summed vector): render-loss value + backward with the global normaliser, the objective's backward pass
 // with the global env-mask sum -> (render_err, g_axis, g_lamb, g_weight, parts_b = (num_e of this shard, its mask sum))
 T5 light_objective_stage2_cuda(const Tensor& albedo, const Tensor& normal, const Tensor& rough, const Tensor& axis, const Tensor& lamb, const Tensor& weight,
                                const Tensor& env_gt, const Tensor& mask, const Tensor& coef, const Tensor& diffuse, const Tensor& spec, const Tensor& im_s,
-                               const Tensor& seg_s, const Tensor& coef_ds, const Tensor& sums, const Tensor& ws, const Tensor& lam_t, const Tensor& w_t, int64_t eh,
+                               const Tensor& seg_s, const Tensor& coef_ds, const Tensor& sums, Tensor& ws /* written: schema Tensor(a!) */, const Tensor& lam_t, const Tensor& w_t, int64_t eh,
                                int64_t ew, double fov, double F0, Cam cam, double ren_w, double rec_w, double offset, bool heads, bool need_grad) {
   const auto dev = require_hip({&albedo, &normal, &rough, &axis, &lamb, &weight, &env_gt, &mask, &coef, &diffuse, &spec, &im_s, &seg_s, &coef_ds, &sums, &ws});
   const c10::DeviceGuard guard(dev);
@@ -1122,6 +1163,8 @@ T5 light_objective_stage2_cuda(const Tensor& albedo, const Tensor& normal, const
   const auto b = check_brdf(a, n, r);
   TORCH_CHECK(sums.is_contiguous() && sums.numel() == 4 && mask.is_contiguous() && coef.is_contiguous() && diffuse.is_contiguous() && spec.is_contiguous() &&
                   im_s.is_contiguous() && seg_s.is_contiguous() && coef_ds.is_contiguous() && ws.is_contiguous(), "sgrender: light_objective_stage2 takes stage 1's tensors as they are");
+  check_stage1_tensors(d.bn, d.R, d.C, mask, coef, diffuse, spec, im_s, seg_s, coef_ds, sums, ws);
+  TORCH_CHECK(gt.numel() == d.bn * 3 * d.R * d.C * eh * ew, "sgrender: light_objective_stage2: env_gt must be [bn,3,R,C,eh,ew], got ", gt.sizes());
   const auto o = a.options();
   const Api& A = api();
   void* st = stream_of(dev);
@@ -1139,14 +1182,17 @@ T5 light_objective_stage2_cuda(const Tensor& albedo, const Tensor& normal, const
   }
   const Tensor dirs = dirs_table(dev, eh, ew), view = view_table(dev, d.R, d.C, fov, cam);
   ok(A.sgr_fused_bwd_recon(rp(a), rp(n), rp(r), rp(ax), handoff ? rp(lam_t) : rp(la), handoff ? rp(w_t) : rp(we), rp(dirs), rp(view), rp(gt), rp(mask), rp(coef),
-                           sp + 3 /* the global env-mask sum */, rp(g_d), rp(g_s), wp(g_axis), wp(g_lamb), wp(g_weight), wp(parts_b), const_cast<float*>(rp(ws)), bn, K, R,
+                           sp + 3 /* the global env-mask sum */, rp(g_d), rp(g_s), wp(g_axis), wp(g_lamb), wp(g_weight), wp(parts_b), ws.mutable_data_ptr<float>(), bn, K, R,
                            C, (int)eh, (int)ew, (int)b.h, (int)b.w, (float)F0, handoff ? 2 : (heads ? 3 : 1), (float)offset, (float)rec_w, st),
      "sgr_fused_bwd_recon");
   return {render_err, g_axis, g_lamb, g_weight, parts_b};
 }
-T5 light_objective_stage2_meta(const Tensor& albedo, const Tensor&, const Tensor&, const Tensor& axis, const Tensor& lamb, const Tensor& weight, const Tensor&, const Tensor&,
-                               const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&,
-                               const Tensor&, int64_t, int64_t, double, double, Cam, double, double, double, bool, bool need_grad) {
+T5 light_objective_stage2_meta(const Tensor& albedo, const Tensor& normal, const Tensor& rough, const Tensor& axis, const Tensor& lamb, const Tensor& weight, const Tensor&,
+                               const Tensor& mask, const Tensor& coef, const Tensor& diffuse, const Tensor& spec, const Tensor& im_s, const Tensor& seg_s, const Tensor& coef_ds,
+                               const Tensor& sums, Tensor& ws, const Tensor&, const Tensor&, int64_t, int64_t, double, double, Cam, double, double, double, bool, bool need_grad) {
+  const auto d = check_sg(axis, lamb, weight);
+  check_brdf(albedo, normal, rough);
+  check_stage1_tensors(d.bn, d.R, d.C, mask, coef, diffuse, spec, im_s, seg_s, coef_ds, sums, ws);
   const auto o = albedo.options();
   auto g = [&](const Tensor& t) { return need_grad ? at::empty(t.sizes(), o) : none_like(albedo); };
   return {at::empty({}, o), g(axis), g(lamb), g(weight), at::empty({2}, o)};
@@ -1208,9 +1254,12 @@ TORCH_LIBRARY(sgrender, m) {
         "int eh, int ew, float fov, float F0, float[] cam, bool heads, bool handoff) -> "
         "(Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
   m.def("light_objective_stage2(Tensor albedo, Tensor normal, Tensor rough, Tensor axis, Tensor lamb, Tensor weight, Tensor env_gt, Tensor mask, Tensor coef, "
-        "Tensor diffuse, Tensor spec, Tensor im_s, Tensor seg_s, Tensor coef_ds, Tensor sums, Tensor ws, Tensor lam_t, Tensor w_t, int eh, int ew, float fov, float F0, "
+        "Tensor diffuse, Tensor spec, Tensor im_s, Tensor seg_s, Tensor coef_ds, Tensor sums, Tensor(a!) ws, Tensor lam_t, Tensor w_t, int eh, int ew, float fov, float F0, "
         "float[] cam, float ren_w, float rec_w, float offset, bool heads, bool need_grad) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
   m.def("light_objective_stage3(Tensor render_err, Tensor num_e, Tensor sums, float ren_w, float rec_w, int eh, int ew) -> (Tensor, Tensor)");
+  // host-side queries (no tensors, no dispatch key): cached constant tables of a kind (test hook), the objective's workspace size
+  m.def("table_cache_count(int kind) -> int", &table_cache_count);
+  m.def("recon_workspace_floats(int bn, int R, int C) -> int", &recon_workspace_floats);
 }
 
 TORCH_LIBRARY_IMPL(sgrender, CUDA, m) {

@@ -245,6 +245,15 @@ def light_objective(renderLayer, albedoPred, normalPred, roughPred, axisPred, la
         seg = F.adaptive_avg_pool2d(seg, (R, C))
     eh, ew, fov, F0, cam = impl.envHeight, impl.envWidth, impl.fov_deg, float(impl.F0), impl._cam
     handoff = _ops.tan_handoff() and not heads
+    # differentiable w.r.t. the SG parameters only -- on BOTH routes (the one-rank operator raised, the sharded route ran its
+    # stage operators under no_grad and silently returned no gradient for a BRDF map that still carried one)
+    if torch.is_grad_enabled():
+        for name, t in (("albedoPred", albedoPred), ("normalPred", normalPred), ("roughPred", roughPred), ("imBatch", imBatch), ("segBRDFBatch", segBRDFBatch),
+                        ("envmapsBatch", envmapsBatch), ("envmapsIndBatch", envmapsIndBatch)):
+            if t.requires_grad:
+                raise RuntimeError(f"sgrender: light_objective is differentiable with respect to the SG parameters only; {name} requires grad -- "
+                                   "detach it (wrapperBRDFLight.py:194 detaches albedoPred; the other maps come from frozen networks), or use "
+                                   "forwardSG + render_loss + recon_loss for gradients with respect to the BRDF maps")
     if not _sharded(group):
         # one operator: forward statistics pass -> render loss -> [render-loss backward -> the objective's backward pass, which also
         # yields the reconstruction loss value and the scalar tail]; under torch.no_grad() / without a grad-requiring SG input the

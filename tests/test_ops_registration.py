@@ -155,6 +155,54 @@ def test_light_objective_operator_graph_and_forward_only_mode():
     assert out.requires_grad and [t.shape for t in torch.autograd.grad(out, [axis, lamb, weight])] == [axis.shape, lamb.shape, weight.shape]
 
 
+def test_stage_operators_report_real_sizes_and_check_their_inputs():
+    """stage 1's Meta kernel reports the workspace at its real size (the C ABI's sgr_fused_recon_workspace_floats, restated as
+    host arithmetic in the extension), stage 2 declares that it writes it (`Tensor(a!) ws`) and refuses stage-1 tensors of another shape --
+    for meta tensors exactly as for device tensors."""
+    from inverserenderingofindoorscene_amd import _lib
+    ops = torch.ops.sgrender
+    L = _lib.load()
+    for b_, r_, c_ in ((1, 1, 1), (2, 6, 8), (16, 120, 160), (4, 240, 320), (3, 7, 5)):
+        assert ops.recon_workspace_floats(b_, r_, c_) == L.sgr_fused_recon_workspace_floats(b_, r_, c_), (b_, r_, c_)
+    alb, nrm, rgh, axis, lamb, weight, im, seg, gt, ind = _objective_args()
+    a_, l_, w_ = axis.detach(), lamb.detach(), weight.detach()
+    st1 = ops.light_objective_stage1(alb, nrm, rgh, a_, l_, w_, im, seg, gt, ind, eh, ew, 57.0, 0.05, [0.0, 0.0, 0.0], False, False)
+    diffuse, spec, mask, coef1, im_s, seg_s, rendered1, coef_ds, sums, ws, lam_t, w_t = st1
+    assert ws.numel() == L.sgr_fused_recon_workspace_floats(bn, R, C)
+    assert "Tensor(a!) ws" in str(ops.light_objective_stage2.default._schema)
+    tail = (eh, ew, 57.0, 0.05, [0.0, 0.0, 0.0], 1.0, 10.0, 1.0, False, True)
+    ops.light_objective_stage2(alb, nrm, rgh, a_, l_, w_, gt, mask, coef1, diffuse, spec, im_s, seg_s, coef_ds, sums, ws, lam_t, w_t, *tail)
+    bad = dict(mask=m(bn, R * C + 1), coef=m(bn + 1), diffuse=m(bn, 3, R, C + 1), im_s=m(bn + 1, 3, R, C), seg_s=m(bn, 1, R + 1, C), coef_ds=m(bn, 3), sums=m(5),
+               ws=m(ws.numel() - 1))
+    for name, t in bad.items():
+        args = dict(mask=mask, coef=coef1, diffuse=diffuse, spec=spec, im_s=im_s, seg_s=seg_s, coef_ds=coef_ds, sums=sums, ws=ws)
+        args[name] = t
+        with pytest.raises(RuntimeError, match="light_objective_stage2"):
+            ops.light_objective_stage2(alb, nrm, rgh, a_, l_, w_, gt, args["mask"], args["coef"], args["diffuse"], args["spec"], args["im_s"], args["seg_s"],
+                                       args["coef_ds"], args["sums"], args["ws"], lam_t, w_t, *tail)
+
+
+def test_light_objective_refuses_grad_requiring_maps_on_both_routes():
+    """the one-rank operator raised for a BRDF map / image that requires grad, the sharded route (stage operators under no_grad)
+    silently returned no gradient for it.  The check now sits in front of the branch."""
+    import torch.distributed as dist
+    from inverserenderingofindoorscene_amd import losses
+    alb, nrm, rgh, axis, lamb, weight, im, seg, gt, ind = _objective_args()
+    layer = sgr.renderingLayer(imWidth=C, imHeight=R, isCuda=False)
+
+    class _Group:      # any explicit group selects the sharded route (losses._sharded); the check must fire before any collective
+        pass
+    for group in (None, _Group()):
+        for k in range(3):
+            maps = [alb, nrm, rgh]
+            maps[k] = maps[k].clone().requires_grad_(True)
+            with pytest.raises(RuntimeError, match="SG parameters only"):
+                losses.light_objective(layer, maps[0], maps[1], maps[2], axis, lamb, weight, im, seg, gt, ind, group=group)
+        with pytest.raises(RuntimeError, match="SG parameters only"):
+            losses.light_objective(layer, alb, nrm, rgh, axis, lamb, weight, im.clone().requires_grad_(True), seg, gt, ind, group=group)
+    assert not dist.is_initialized()
+
+
 def test_every_operator_rejects_cpu_tensors():
     z = torch.zeros
     ops = torch.ops.sgrender
