@@ -71,6 +71,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layer-only", action="store_true", help="skip the informational legs (two streams, HIP graph, light objective, baselines): profiling runs")
     ap.add_argument("--no-env", action="store_true", help="render-only variant (env image never materialised)")
+    ap.add_argument("--graph-leg", action="store_true", help="with --layer-only: still time the with-render-loss step replayed from a HIP graph (sgr.capture_step) -- the batch sweep's launch-bound sizes")
+    ap.add_argument("--no-config5", action="store_true", help="skip the compact BASELINE configs[4] leg of the default run")
     ap.add_argument("--pmc-workload", default="layer", choices=("layer", "objective", "objective_heads"),
                     help="counter-collection runs (tools/pmc_traffic.sh, tools/pmc_sq.sh): 'objective' / 'objective_heads' run ONLY the fused light objective "
                          "+ its backward (the trainLight step's kernels: fwd_pk*gt* and sg_bwd_recon_pk_kernel; _heads: decoder outputs in, premap 3) "
@@ -253,6 +255,45 @@ def main() -> None:
         except Exception as exc:
             cfg3 = {"error": str(exc)[:200]}
 
+    # informational: the with-render-loss step replayed from a HIP graph (sgr.capture_step): what a launch-bound caller -- the reference's
+    # default batch of 5, trainLight.py:28 -- gets by capturing its step
+    graph_loss_ms = None
+    if world == 1 and (args.graph_leg or not args.layer_only):
+        try:
+            captured = pkg.capture_step(step_with_loss)
+            captured.replay()
+            barrier()
+            t2 = time.perf_counter()
+            for _ in range(args.steps):
+                captured.replay()
+            barrier()
+            graph_loss_ms = (time.perf_counter() - t2) / args.steps * 1e3
+            del captured
+        except Exception as exc:
+            print(f"# graph-replay leg skipped: {str(exc)[:160]}", file=sys.stderr)
+
+    # informational, LAST (it creates and destroys a process group): the same with-loss step and the fused objective through RCCL with a
+    # world of one rank -- init_process_group("nccl"), the all-reduces of the device-resident [num, den] vectors between the loss passes
+    # (wrapperBRDFLight.py:192,205-207 under batch sharding) -- so the collectives' latency on the step is a measured number.
+    # N > 1 is the driver's to run.
+    rccl1 = None
+    if world == 1 and need_env and not args.layer_only and args.config == 2:
+        try:
+            rccl1 = rccl_world1_legs(pkg, layer, x, ct_env, R, C, args.steps, dev)
+        except Exception as exc:
+            rccl1 = {"error": str(exc)[:200]}
+
+    cfg5 = None
+    if world == 1 and need_env and not args.layer_only and args.config == 2 and not args.no_config5:
+        try:
+            for k in list(x):
+                x[k] = None      # config 2's inputs are done with: 1.2 GB back to the allocator before config 5's 6 GB
+            ct_env = None
+            torch.cuda.empty_cache()
+            cfg5 = config5_leg(pkg, dev)
+        except Exception as exc:
+            cfg5 = {"error": str(exc)[:200]}
+
     if rank == 0:
         P = bn * R * C                      # shaded (env-grid) pixels per GPU per step
         img_px = bn * imH * imW
@@ -305,6 +346,10 @@ def main() -> None:
                        "ms_per_step_repetitions": [round(t / args.steps * 1e3, 4) for t in headline_dts],
                        "ms_per_step_layer_only": round(plain_ms, 4), "Mpix_per_s_layer_only": mpix(plain_ms),
                        "ms_per_step_with_render_loss": round(loss_step_ms, 4), "Mpix_per_s_with_render_loss": mpix(loss_step_ms),
+                       "ms_per_step_with_render_loss_graph_replay": None if graph_loss_ms is None else round(graph_loss_ms, 4),
+                       "Mpix_per_s_with_render_loss_graph_replay": None if graph_loss_ms is None else mpix(graph_loss_ms),
+                       "rccl_world1": rccl1,
+                       "config5": cfg5,
                        "ms_per_step_light_objective_fused": None if obj_ms is None else round(obj_ms, 4),
                        "ms_per_step_light_objective_unfused": None if obj_unfused_ms is None else round(obj_unfused_ms, 4),
                        "ms_per_step_light_objective_forward_only": None if obj_fwd_only_ms is None else round(obj_fwd_only_ms, 4),
@@ -336,6 +381,120 @@ def main() -> None:
 
     if world > 1:
         dist.destroy_process_group()
+
+
+def rccl_world1_legs(pkg, layer, x, ct_env, R, C, steps, dev) -> dict:
+    """The sharded code path over RCCL with ONE rank (single-process bench only): `render_loss(group=WORLD)` between the layer's forward and
+    backward, and `light_objective(group=WORLD)` (three stage operators, two all-reduces) -- against the same steps without a group, timed
+    back to back.  What it measures is the collectives' enqueue + latency on the critical path; the wire (xGMI) is not involved."""
+    import socket
+    created = False
+    if not dist.is_initialized():
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        created = True
+    try:
+        sg = [x["axis"], x["lamb"], x["weight"]]
+        ind = torch.ones(x["albedo"].shape[0], 1, 1, 1, device=dev)
+
+        def with_loss(group):
+            env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], sg[0], sg[1], sg[2], need_env=True)
+            err, _ = pkg.render_loss(d, s, x["im"], x["seg"], R, C, group=group)
+            torch.autograd.grad([err, env], sg, grad_outputs=[None, ct_env])
+
+        def objective(group):
+            obj = pkg.light_objective(layer, x["albedo"], x["normal"], x["rough"], sg[0], sg[1], sg[2], x["im"], x["seg"], x["env_gt"], ind, 1.0, 10.0, group=group)[0]
+            torch.autograd.grad(obj, sg)
+
+        def loop_ms(fn, group):
+            for _ in range(5):
+                fn(group)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn(group)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / steps * 1e3
+
+        W = dist.group.WORLD
+        out = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
+        # alternate the two routes so that both see the same clocks
+        a = [loop_ms(with_loss, None), loop_ms(with_loss, W), loop_ms(with_loss, None), loop_ms(with_loss, W)]
+        b = [loop_ms(objective, None), loop_ms(objective, W), loop_ms(objective, None), loop_ms(objective, W)]
+        out["ms_per_step_with_render_loss"] = round(min(a[0], a[2]), 4)
+        out["ms_per_step_with_render_loss_sharded_world1"] = round(min(a[1], a[3]), 4)
+        out["ms_per_step_light_objective"] = round(min(b[0], b[2]), 4)
+        out["ms_per_step_light_objective_sharded_world1"] = round(min(b[1], b[3]), 4)
+        out["note"] = ("one rank over the nccl (= RCCL) backend: one all-reduce of [num, den] per render loss, two per light objective, on device tensors; "
+                       "N > 1 has never been timed by the builder (one GPU per box) -- the scaling curve is the driver's")
+        return out
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+def config5_leg(pkg, dev, steps=25, warmup=8, reps=3) -> dict:
+    """BASELINE configs[4] (480x640 -> 240x320 env grid assumed, SGNum 24, 16x32 directions, batch 4) as a compact leg of the default run:
+    the layer's forward + backward with per-kernel HBM rooflines from events on the launch stream, plus the offline counter records of
+    that workload (profiles/traffic.json / sq.json, stamped with the kernel sources they were measured on).  Inputs come from the device
+    generator (same distributions as SURVEY.md 8d; the parity of config 5 is tests/test_gpu_fullsize.py's business, not this leg's)."""
+    bn, imH, imW, R, C, K, eh, ew = 4, 480, 640, 240, 320, 24, 16, 32
+    J, q = eh * ew, 4
+    g = torch.Generator(device=dev).manual_seed(20205)
+    rnd = lambda *s: torch.rand(*s, device=dev, generator=g)
+    rn = lambda *s: torch.randn(*s, device=dev, generator=g)
+    albedo, rough = rnd(bn, 3, imH, imW), rnd(bn, 1, imH, imW) * 2.0 - 1.0
+    n = rn(bn, 3, imH, imW)
+    n[:, 2] = n[:, 2].abs() + 0.5
+    normal = n / n.norm(dim=1, keepdim=True)
+    a = rn(bn, K, 3, R, C)
+    sg = [(a / a.norm(dim=2, keepdim=True)).requires_grad_(True), rnd(bn, K, R, C).requires_grad_(True), rnd(bn, 3 * K, R, C).requires_grad_(True)]
+    cts = [rn(bn, 3, R, C, eh, ew) * 1e-3, rn(bn, 3, R, C), rn(bn, 3, R, C)]
+    del n, a
+    layer = pkg.renderingLayer(imWidth=C, imHeight=R, envWidth=ew, envHeight=eh)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+
+    def step(i=None):
+        if i is not None:
+            ev[i][0].record()
+        outs = layer.forwardSG(albedo, normal, rough, sg[0], sg[1], sg[2], need_env=True)
+        if i is not None:
+            ev[i][1].record()
+        torch.autograd.grad(list(outs), sg, grad_outputs=cts)
+        if i is not None:
+            ev[i][2].record()
+
+    for _ in range(warmup):
+        step()
+    dts, fwd, bwd = [], 0.0, 0.0
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        torch.cuda.synchronize()
+        dts.append((time.perf_counter() - t0) / steps)
+        fwd += sum(e[0].elapsed_time(e[1]) for e in ev) / steps / reps
+        bwd += sum(e[1].elapsed_time(e[2]) for e in ev) / steps / reps
+    dt = sorted(dts)[len(dts) // 2]
+    P, bpp = bn * R * C, algorithmic_bytes_per_shaded_px(K, J, q)
+    tkey = f"config5_batch{bn}_env"
+    out = {"workload": f"BASELINE configs[4]: batch {bn} x {imH}x{imW} -> {R}x{C} env grid (assumed, SURVEY.md 8d), SGNum={K}, {eh}x{ew} directions; fused fwd (env written) + fused bwd (SG grads)",
+           "value": round(bn * imH * imW / dt / 1e6, 1), "unit": "Mpix/s", "ms_per_step": round(dt * 1e3, 4), "steps": steps, "warmup": warmup, "repetitions": reps,
+           "data": "synthetic (device generator)", "kernels": {}}
+    for tag, ms, nbytes, pats in (("forward (sgr_fused_fwd)", fwd, P * bpp["fwd_env"], [r"fwd_pk_half_kernel<"]), ("backward (sgr_fused_bwd_sg)", bwd, P * bpp["bwd_sg"], [r"sg_bwd_pk_kernel<"])):
+        gbps = nbytes / (ms * 1e-3) / 1e9
+        traffic, name, t_stale = pmc_traffic(tkey, pats)
+        valu = valu_roofline(tkey, pats, ms)
+        out["kernels"][tag] = {"roofline": {"bound": "hbm", "kernel": name, "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
+                                            "traffic": traffic, "traffic_record_stale": t_stale, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": round(ms, 4),
+                                            "limited_by": limited(valu, gbps / HBM_PEAK_GBPS)},
+                               "roofline_valu": valu}
+    return out
 
 
 def csrc_sha16() -> str:
@@ -524,11 +683,57 @@ def config3_legs(pkg, layer, x, ind, bn, R, C, K, steps, barrier) -> dict:
     return out
 
 
+MODES = ("forward_only", "fwd_bwd_sg", "fwd_bwd_all_grads")      # the three timings asked of every baseline
+
+
+def _baseline_runner(fwd, x, cts):
+    """`fwd(x) -> (env, diffuse, spec)`; returns {mode: callable} for the three modes (models.py:371-389 + 461-522 forward under no_grad;
+    + autograd backward w.r.t. the SG parameters -- trainLight mode, the metric's; + w.r.t. the BRDF maps as well)."""
+    sg = [x["axis"], x["lamb"], x["weight"]]
+    brdf = [x["albedo"], x["normal"], x["rough"]]
+
+    def forward_only():
+        with torch.no_grad():
+            fwd(x)
+
+    def fwd_bwd_sg():
+        for t in brdf:
+            t.requires_grad_(False)
+        torch.autograd.grad(list(fwd(x)), sg, grad_outputs=cts)
+
+    def fwd_bwd_all():
+        for t in brdf:
+            t.requires_grad_(True)
+        torch.autograd.grad(list(fwd(x)), sg + brdf, grad_outputs=cts)
+        for t in brdf:
+            t.requires_grad_(False)
+
+    return dict(zip(MODES, (forward_only, fwd_bwd_sg, fwd_bwd_all)))
+
+
+def _time_modes(runners, sync, budget_s, max_reps):
+    """Best-of timing of each mode inside a wall-clock budget per mode (one warm-up; at least one timed run)."""
+    out = {}
+    for mode in MODES:
+        fn = runners[mode]
+        t0 = time.perf_counter()
+        fn(); sync()
+        warm = time.perf_counter() - t0
+        times = [warm] if warm > 0.5 * budget_s else []      # pathological host: the warm-up is the sample
+        t_end = time.perf_counter() + budget_s
+        while len(times) < 1 or (time.perf_counter() < t_end and len(times) < max_reps):
+            t0 = time.perf_counter()
+            fn(); sync()
+            times.append(time.perf_counter() - t0)
+        out[mode] = (min(times), len(times))
+    return out
+
+
 def eager_gpu_baseline(O, dev, imH, imW, R, C, K, eh, ew) -> dict:
     """The torch port of the reference algorithm in the reference's own tensor formulation (whole-batch broadcast
     temporaries, oracle.render_from_sg_broadcast) run eagerly ON THE GPU through PyTorch-ROCm's aten kernels: the
     GPU-vs-GPU baseline BASELINE.md asks for (the reference itself cannot travel to the GPU box).  Bounded sample:
-    four images, forward + backward (SG grads), best of 3."""
+    four images; forward only, forward + backward (SG grads: the metric's mode, `value`), forward + backward (all six gradients)."""
     n = 4
     inp = O.synthetic_inputs(n, imH, imW, R, C, K, eh, ew, seed=20202)
     names = ("albedo", "normal", "rough", "axis", "lamb", "weight")
@@ -538,32 +743,25 @@ def eager_gpu_baseline(O, dev, imH, imW, R, C, K, eh, ew) -> dict:
     g = torch.Generator().manual_seed(99)
     cts = [(torch.randn((n, 3, R, C, eh, ew), generator=g) * 1e-3).to(dev), torch.randn((n, 3, R, C), generator=g).to(dev),
            torch.randn((n, 3, R, C), generator=g).to(dev)]
-
-    def one():
-        env, d, s = O.render_from_sg_broadcast(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], eh, ew)
-        torch.autograd.grad([env, d, s], [x["axis"], x["lamb"], x["weight"]], grad_outputs=cts)
-        torch.cuda.synchronize()
-
-    one()
-    times = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        one()
-        times.append(time.perf_counter() - t0)
-    best = min(times)
-    return {"value": round(n * imH * imW / best / 1e6, 2), "unit": "Mpix/s", "kind": "port",
-            "sample": f"{n} images of the same workload, fwd+bwd (SG grads), eager PyTorch-ROCm on this GPU running the torch port "
-                      f"of the reference algorithm in its broadcast formulation (oracle.render_from_sg_broadcast), best of 3; "
-                      f"{best / n * 1e3:.2f} ms per image"}
+    fwd = lambda x_: O.render_from_sg_broadcast(x_["albedo"], x_["normal"], x_["rough"], x_["axis"], x_["lamb"], x_["weight"], eh, ew)
+    res = _time_modes(_baseline_runner(fwd, x, cts), torch.cuda.synchronize, budget_s=2.0, max_reps=3)
+    mp = lambda t: round(n * imH * imW / t / 1e6, 2)
+    best = res["fwd_bwd_sg"][0]
+    return {"value": mp(best), "unit": "Mpix/s", "kind": "port",
+            "modes": {m: {"Mpix_per_s": mp(res[m][0]), "ms_per_image": round(res[m][0] / n * 1e3, 2), "runs": res[m][1]} for m in MODES},
+            "sample": f"{n} images of the same workload, eager PyTorch-ROCm on this GPU running the torch port "
+                      f"of the reference algorithm in its broadcast formulation (oracle.render_from_sg_broadcast), best of <= 3 per mode; "
+                      f"value = fwd+bwd (SG grads), {best / n * 1e3:.2f} ms per image"}
 
 
 def cpu_baseline(O, imH, imW, R, C, K, eh, ew) -> dict:
     """The reference's CPU path for the same step, timed on this box's host cores on a bounded sample: ONE image of the
-    workload (1/16 of a step), forward + backward (SG grads), fp32.  Where the reference checkout is mounted (the authoring
+    workload (1/16 of a step), fp32, in the three modes BASELINE.md section 3 names -- forward only, forward + backward (SG grads: the
+    metric's mode, `value`), forward + backward (all six gradients).  Where the reference checkout is mounted (the authoring
     container) that is the UNMODIFIED models.output2env.output2env + models.renderingLayer.forwardEnv (kind "reference");
     on the GPU box, where it is not, the torch port in the reference's OWN tensor formulation -- whole-image broadcast
-    temporaries, oracle.render_from_sg_broadcast (kind "port"; profiles/cpu_calibration.json: 0.95x the reference's speed
-    on the same cores; the bounded-memory per-lobe formulation the parity tests use is 1.5x slower and is not timed here)."""
+    temporaries, oracle.render_from_sg_broadcast (kind "port"; profiles/cpu_calibration.json: its speed against the reference's on the
+    same cores, per mode; the bounded-memory per-lobe formulation the parity tests use is 1.5x slower and is not timed here)."""
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -576,9 +774,7 @@ def cpu_baseline(O, imH, imW, R, C, K, eh, ew) -> dict:
     for k in ("axis", "lamb", "weight"):
         x[k].requires_grad_(True)
     g = torch.Generator().manual_seed(99)
-    ct_env = torch.randn((1, 3, R, C, eh, ew), generator=g) * 1e-3
-    ct_d = torch.randn((1, 3, R, C), generator=g)
-    ct_s = torch.randn((1, 3, R, C), generator=g)
+    cts = [torch.randn((1, 3, R, C, eh, ew), generator=g) * 1e-3, torch.randn((1, 3, R, C), generator=g), torch.randn((1, 3, R, C), generator=g)]
 
     kind, what = "port", "torch fp32 CPU port of the reference algorithm in its broadcast formulation (oracle.render_from_sg_broadcast)"
     ref_layers = None
@@ -590,24 +786,15 @@ def cpu_baseline(O, imH, imW, R, C, K, eh, ew) -> dict:
     except Exception:
         ref_layers = None
 
-    def one():
+    def fwd(x_):
         if ref_layers is not None:
-            env, _, _, _ = ref_layers[0].output2env(x["axis"], x["lamb"], x["weight"])
-            d, s = ref_layers[1].forwardEnv(x["albedo"], x["normal"], x["rough"], env)
-        else:
-            env, d, s = O.render_from_sg_broadcast(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], eh, ew)
-        torch.autograd.grad([env, d, s], [x["axis"], x["lamb"], x["weight"]], grad_outputs=[ct_env, ct_d, ct_s])
+            env, _, _, _ = ref_layers[0].output2env(x_["axis"], x_["lamb"], x_["weight"])
+            d, s = ref_layers[1].forwardEnv(x_["albedo"], x_["normal"], x_["rough"], env)
+            return env, d, s
+        return O.render_from_sg_broadcast(x_["albedo"], x_["normal"], x_["rough"], x_["axis"], x_["lamb"], x_["weight"], eh, ew)
 
-    t0 = time.perf_counter()
-    one()                                   # warm-up
-    warm = time.perf_counter() - t0
-    times = [warm] if warm > 15.0 else []   # pathological host: keep the bench bounded
-    t_end = time.perf_counter() + 20.0
-    while len(times) < (1 if warm > 15.0 else 3) or (time.perf_counter() < t_end and len(times) < 5):
-        t0 = time.perf_counter()
-        one()
-        times.append(time.perf_counter() - t0)
-    best = min(times)
+    res = _time_modes(_baseline_runner(fwd, x, cts), lambda: None, budget_s=8.0, max_reps=4)      # <= ~30 s of CPU work in all
+    best, runs = res["fwd_bwd_sg"]
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -616,8 +803,10 @@ def cpu_baseline(O, imH, imW, R, C, K, eh, ew) -> dict:
                 break
     except OSError:
         pass
-    return {"value": round(imH * imW / best / 1e6, 4), "unit": "Mpix/s", "cores": torch.get_num_threads(), "kind": kind,
-            "sample": f"1 image (1/16 of a step) of the same workload, fwd+bwd (SG grads), {what}, best of {len(times)}; {best:.3f} s per image",
+    mp = lambda t: round(imH * imW / t / 1e6, 4)
+    return {"value": mp(best), "unit": "Mpix/s", "cores": torch.get_num_threads(), "kind": kind,
+            "modes": {m: {"Mpix_per_s": mp(res[m][0]), "seconds_per_image": round(res[m][0], 3), "runs": res[m][1]} for m in MODES},
+            "sample": f"1 image (1/16 of a step) of the same workload, {what}, best of <= 4 per mode; value = fwd+bwd (SG grads), best of {runs}; {best:.3f} s per image",
             "cpu": model}
 
 

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kWave, OCC) void sg_bwd_recon_pk_kernel(const Args 
     if constexpr (NG == 2) tile32_dma_issue_vrow<SGR_DMA_AUX, EW>(dst, gimg, x.p0, RC, a.J, vr, lane);
     else tile16_dma_issue_vrow<SGR_DMA_AUX, EW>(dst, gimg, x.p0, RC, a.J, vr, lane);
   };
-  issue(tile, 0);
+  if (!(SGR_ABLATE & 1)) issue(tile, 0);
 
   PixLocal q{};
   OrthoPix oq{};
@@ -166,7 +166,9 @@ __global__ __launch_bounds__(kWave, OCC) void sg_bwd_recon_pk_kernel(const Args 
       const int e = Q == 1 ? vr : (vr >> 1), aoff = Q == 1 ? 0 : (vr & 1) * NP;      // table row; first azimuth pair of this virtual row
       constexpr int kRow = NG == 2 ? 6 : 3;      // LDS-DMA instructions per virtual-row tile
       const float* cur = tile + (vr & 1) * kTile;
-      if (vr + 1 < nvr) {
+      if (SGR_ABLATE & 1) {
+        // ablation: no ground-truth rows requested or waited for
+      } else if (vr + 1 < nvr) {
         issue(tile + ((vr + 1) & 1) * kTile, vr + 1);
         wait_vmcnt<kRow>();      // this virtual row has landed; the next stays in flight
       } else {
@@ -231,7 +233,12 @@ __global__ __launch_bounds__(kWave, OCC) void sg_bwd_recon_pk_kernel(const Args 
         if constexpr (NG == 2) {
           // ---- 3. its cotangent: reconstruction term (and loss) + render term --------------------------------
           float gt[3][2];
+#if SGR_ABLATE & 2
+          for (int c = 0; c < 3; ++c) { gt[c][0] = 0.5f + 1e-3f * (float)(ap + c + lane); gt[c][1] = 0.7f; }
+          (void)cur;
+#else
           tile32_read_pair(cur, pl, own * HALF + ap * 2, gt);
+#endif
           f32x2 wt = splat2(0.f), sp = splat2(0.f);
           if constexpr (GRADS) {
             const f32x2 Pv = pfma(SGR_HI(oq.vB), sa, SGR_LO(oq.vB) * ca);
@@ -255,8 +262,10 @@ __global__ __launch_bounds__(kWave, OCC) void sg_bwd_recon_pk_kernel(const Args 
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
               float dx = go[c].x, sx = go[c].x, dy = go[c].y, sy = go[c].y;
+#if !(SGR_ABLATE & 4)
               swap32(dx, sx);
               swap32(dy, sy);
+#endif
               g[1][c] = f32x2{dx, dy};     // from lanes 0..31
               g[0][c] = f32x2{sx, sy};     // from lanes 32..63
             }
@@ -462,7 +471,8 @@ static int fused_fwd_recon_impl(const float* albedo, const float* normal, const 
   // the 16x32 grid, and premap == 3 -- the packed half-wave statistics kernel: at three waves per SIMD the 42 tanh per lane of
   // the decoder heads disappear behind the other waves' row loops (165 us with or without them at config 2), where the
   // one-pixel-per-lane kernel's 84 per lane at two waves per SIMD cost 22-32 us
-  const bool wide = K > 12 || ew == 32 || premap == 3;
+  static const int fwd_half = [] { const char* e = getenv("SGR_OBJ_FWD_HALF"); return e ? atoi(e) : 0; }();      // round-5 A/B: 7..12 lobes, premap <= 2 through the half-wave kernel too
+  const bool wide = K > 12 || ew == 32 || premap == 3 || (fwd_half && K > 6);
   const int tiles = wide ? recon_tiles32(R * C) : recon_tiles(R * C);
   float* den_img = workspace;
   float* ws0 = workspace + bn + 4;
@@ -587,12 +597,14 @@ static int fused_bwd_recon_impl(const float* albedo, const float* normal, const 
   set_dims(a, bn, K, R, C, eh, ew, imH, imW);
   a.F0 = F0; a.premap = premap;
   const int tiles32 = recon_tiles32(R * C);
-  // round 5 experiment: 7..12 lobes on the 8x16 grid as four lane groups of THREE lobes -- a quarter of the
-  // accumulators per lane, three or four resident waves per SIMD.  SGR_RECON_K12 = 1: asked for four waves, 2: three; unset / 0: the
-  // two-group kernel.  Read once.
-  static const int k12_mode = [] { const char* e = getenv("SGR_RECON_K12"); return e ? atoi(e) : 0; }();
-  const bool four3 = k12_mode > 0 && K > 6 && K <= 12 && ew == 16;
-  const bool four = K > 12 || four3;                 // four lane groups per pixel: 16 pixels per wave
+  // Round 5, measured and NOT adopted (profiles/r05a_objective_bwd_lane_groups_kbench.txt, r05a_sq_config2_batch16_objective_k12ng4.txt; one box,
+  // three alternations): 7..12 lobes on the 8x16 grid as FOUR lane groups of THREE lobes (sg_bwd_recon_pk_kernel<POOL, 16, 4, HEADS, GRADS, 3, OCC>:
+  // a quarter of the accumulators per lane).  Asked for three waves per SIMD: 168 VGPRs, 56 B of scratch outside the hot loop, 2.78 resident
+  // waves per SIMD, VALU-busy 0.92 at 2.05 GHz (1888 busy cycles per SIMD and microsecond against 1544) -- and 356-364 us against 324-328, because
+  // the wave now covers 16 pixels: per azimuth pair 213 VALU instructions per 16 pixels against 311 per 32 (+37 %: the microfacet terms and the
+  // loss / cotangent of a direction are scalar, one direction per lane group, and the exchange is 18 swaps per 16 pixels instead of 12 per 32).
+  // Asked for four waves (128 VGPRs): 220 B of scratch, 5 scratch loads in the hot loop, 464-467 us.  Both pass the objective's parity tests.
+  const bool four = K > 12;                          // four lane groups of six lobes per pixel: 16 pixels per wave
   const int tiles = four ? recon_tiles16(R * C) : tiles32;
   float* den_img = workspace;
   float* ws1 = workspace + bn + 4 + (size_t)bn * tiles32 * 3;
@@ -614,27 +626,11 @@ static int fused_bwd_recon_impl(const float* albedo, const float* normal, const 
         else hipLaunchKernelGGL((sg_bwd_recon_pk_kernel<2, EW_, NG_>), grid, block, 0, st, a);               \
       }                                                                                                      \
     } while (0)
-#define SGR_LAUNCH_BR3(OCC_)                                                                                 \
-    do {                                                                                                     \
-      if (!grads) {                                                                                          \
-        if (premap == 3) hipLaunchKernelGGL((sg_bwd_recon_pk_kernel<1, 16, 4, true, false, 3, OCC_>), grid, block, 0, st, a);   \
-        else hipLaunchKernelGGL((sg_bwd_recon_pk_kernel<1, 16, 4, false, false, 3, OCC_>), grid, block, 0, st, a);              \
-      } else if (premap == 3) {                                                                              \
-        if (p1) hipLaunchKernelGGL((sg_bwd_recon_pk_kernel<1, 16, 4, true, true, 3, OCC_>), grid, block, 0, st, a);      \
-        else hipLaunchKernelGGL((sg_bwd_recon_pk_kernel<2, 16, 4, true, true, 3, OCC_>), grid, block, 0, st, a);         \
-      } else {                                                                                               \
-        if (p1) hipLaunchKernelGGL((sg_bwd_recon_pk_kernel<1, 16, 4, false, true, 3, OCC_>), grid, block, 0, st, a);     \
-        else hipLaunchKernelGGL((sg_bwd_recon_pk_kernel<2, 16, 4, false, true, 3, OCC_>), grid, block, 0, st, a);        \
-      }                                                                                                      \
-    } while (0)
-    if (four3 && k12_mode == 1) SGR_LAUNCH_BR3(4);
-    else if (four3) SGR_LAUNCH_BR3(3);
-    else if (!four && ew == 16) SGR_LAUNCH_BR(16, 2);
+    if (!four && ew == 16) SGR_LAUNCH_BR(16, 2);
     else if (!four) SGR_LAUNCH_BR(32, 2);
     else if (ew == 16) SGR_LAUNCH_BR(16, 4);
     else SGR_LAUNCH_BR(32, 4);
 #undef SGR_LAUNCH_BR
-#undef SGR_LAUNCH_BR3
   }
   hipLaunchKernelGGL(recon_fold1, dim3(1), dim3(kFold1Threads), 0, st, ws1, den_img, parts, bn, tiles, tail);     // parts = (loss numerator, local sum of the env mask)
   return sgr_check((int)hipGetLastError(), "sgr_fused_bwd_recon");

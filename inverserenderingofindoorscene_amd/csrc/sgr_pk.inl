@@ -27,6 +27,13 @@ namespace sgr {
 // the other waves already; and in the objective's backward kernel the same priority made the step 1-2 % SLOWER, so that one stays at
 // the default.  Round 4: nor do the objective's forward (statistics) kernels -- without it the objective step is 3-6 us faster in the loop
 // (profiles/r04q_prio_bench.txt) -- so the forward bodies raise the priority only when they are not the HAS_GT variant.  0 = hardware default.
+// -DSGR_ABLATE=<bits> (development builds only, tools/ablate.sh): time a kernel with one of its data-movement components REMOVED -- results are
+// wrong, the timing difference is that component's cost (an upper bound on what hiding it better could buy).  1: no LDS-DMA row requests / waits
+// (cotangent rows, ground-truth rows); 2: no LDS tile reads; 4: no cotangent all-gather (objective backward); 8: lobe parameters synthesised in
+// registers instead of loaded (the prologue's 42 / 84 loads per lane); 16: no env-image tile writes / stores (forward).
+#ifndef SGR_ABLATE
+#define SGR_ABLATE 0
+#endif
 #ifndef SGR_PROLOGUE_PRIO
 #define SGR_PROLOGUE_PRIO 3
 #endif
@@ -251,6 +258,11 @@ __device__ __forceinline__ void load_lobes_pk(const Args& a, int b, unsigned up,
     const char* pa = reinterpret_cast<const char*>(axis_b + (size_t)ku * 3 * RC);
     const char* pw = reinterpret_cast<const char*>(weight_b + (size_t)ku * 3 * RC);
     const char* pl = reinterpret_cast<const char*>(lamb_b + (size_t)ku * RC);
+#if SGR_ABLATE & 8
+    { const float t_ = (float)((v3 >> 2) & 63) * (1.0f / 64.0f) + (float)k * 0.01f;
+      ax[k] = 0.6f - 0.3f * t_; ay[k] = 0.5f * t_; az[k] = 0.7f; lp[k] = 0.2f + 0.5f * t_; w0[k] = 0.3f + 0.4f * t_; w1[k] = 0.5f; w2[k] = 0.9f - 0.5f * t_;
+      (void)pa; (void)pw; (void)pl; (void)v1; }
+#else
     ax[k] = *reinterpret_cast<const float*>(pa + v3);
     ay[k] = *reinterpret_cast<const float*>(pa + (size_t)RC * 4 + v3);
     az[k] = *reinterpret_cast<const float*>(pa + (size_t)RC * 8 + v3);
@@ -258,6 +270,7 @@ __device__ __forceinline__ void load_lobes_pk(const Args& a, int b, unsigned up,
     w0[k] = *reinterpret_cast<const float*>(pw + v3);
     w1[k] = *reinterpret_cast<const float*>(pw + (size_t)RC * 4 + v3);
     w2[k] = *reinterpret_cast<const float*>(pw + (size_t)RC * 8 + v3);
+#endif
   }
   if (KE != KP) { ax[KP] = ax[KP - 1]; ay[KP] = ay[KP - 1]; az[KP] = az[KP - 1]; lp[KP] = lp[KP - 1]; w0[KP] = w0[KP - 1]; w1[KP] = w1[KP - 1]; w2[KP] = w2[KP - 1]; }
   if (HEADS) {
@@ -725,6 +738,9 @@ __device__ __forceinline__ void fwd_pk_half_body(const Args& a, const Pix x, flo
             }
           }
         }
+#if SGR_ABLATE & 16
+        if (WRITE_ENV && !DO_RENDER) { dacc[0] += tot[0][0] + tot[0][1]; dacc[1] += tot[1][0] + tot[1][1]; dacc[2] += tot[2][0] + tot[2][1]; }
+#endif
         if (HAS_GT) {
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
@@ -739,14 +755,14 @@ __device__ __forceinline__ void fwd_pk_half_body(const Args& a, const Pix x, flo
             }
           }
         }
-        if (WRITE_ENV) {
+        if (WRITE_ENV && !(SGR_ABLATE & 16)) {
           const float e0[4] = {tot[0][0].x, tot[0][0].y, tot[0][1].x, tot[0][1].y};
           const float e1[4] = {tot[1][0].x, tot[1][0].y, tot[1][1].x, tot[1][1].y};
           const float e2[4] = {tot[2][0].x, tot[2][0].y, tot[2][1].x, tot[2][1].y};
           tile32_write4<TD>(tile, pl, (e % RPF) * EW + own * HALF + aq * 4, e0, e1, e2);
         }
       }
-      if (WRITE_ENV && ((e + 1) % RPF == 0 || e + 1 == eh)) {
+      if (WRITE_ENV && !(SGR_ABLATE & 16) && ((e + 1) % RPF == 0 || e + 1 == eh)) {
         __syncthreads();
         tile32_store_global<TD>(tile, a.env_out + img, x.p0, RC, a.J, (e / RPF) * TD, (e % RPF + 1) * EW, lane);
         __syncthreads();
@@ -1015,7 +1031,7 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
   const int nvr = a.eh * Q;                         // virtual rows
 
   __amdgpu_buffer_rsrc_t gimg = env_rsrc(HAS_GENV ? a.g_env + (size_t)b * 3 * RC * a.J : a.view, RC, a.J);
-  if (HAS_GENV) {
+  if (HAS_GENV && !(SGR_ABLATE & 1)) {
     tile32_dma_issue_vrow<SGR_PK_BWD_AUX, EW>(tile, gimg, x.p0, RC, a.J, 0, lane);
     if (nvr > 1) tile32_dma_issue_vrow<SGR_PK_BWD_AUX, EW>(tile + kT32Floats, gimg, x.p0, RC, a.J, 1, lane);
   }
@@ -1057,7 +1073,7 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
     for (int vr = 0; vr < nvr; ++vr) {
       const int e = Q == 1 ? vr : (vr >> 1), aoff = Q == 1 ? 0 : (vr & 1) * NP;      // table row; first azimuth pair of this virtual row
       const float* cur = tile + (HAS_GENV ? (vr % 3) * kT32Floats : 0);
-      if (HAS_GENV) {
+      if (HAS_GENV && !(SGR_ABLATE & 1)) {
         // rows vr+1, vr+2 (vr odd) were requested when row vr-1 was done; up to two rows (12 instructions) may stay in flight
         if ((vr & 1) == 0) {
           if (vr + 1 < nvr) wait_vmcnt<6>(); else wait_vmcnt<0>();          // in flight at most: row vr+1
@@ -1094,8 +1110,12 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
         const f32x4 cs = cpt[aoff + ap];
         const f32x2 ca = {cs[0], cs[1]}, sa = {cs[2], cs[3]};
         f32x2 g[2][3];            // [sign][colour], the azimuth pair (2 ap, 2 ap + 1) of this virtual row
-        if (HAS_GENV) {
+        if (HAS_GENV && !(SGR_ABLATE & 2)) {
           tile32_read_two_pairs2(cur, pl, ap * 2, HALF + ap * 2, g[0], g[1]);
+        } else if (HAS_GENV) {      // ablation: cotangents that are neither loaded nor constant-foldable
+#pragma unroll
+          for (int c = 0; c < 3; ++c) g[0][c] = g[1][c] = splat2(1e-3f * (float)(ap + c + lane));
+          (void)cur;
         } else {
 #pragma unroll
           for (int c = 0; c < 3; ++c) g[0][c] = g[1][c] = splat2(0.f);
@@ -1145,7 +1165,7 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
           gy[k] = pfma(ssa, Td, gy[k]);
         }
       }
-      if (HAS_GENV && (vr & 1) == 0) {
+      if (HAS_GENV && !(SGR_ABLATE & 1) && (vr & 1) == 0) {
         // row vr is consumed: its buffer and the one of row vr-1 are free -> request rows vr+2 and vr+3 back to back
         if (vr + 2 < nvr) tile32_dma_issue_vrow<SGR_PK_BWD_AUX, EW>(tile + ((vr + 2) % 3) * kT32Floats, gimg, x.p0, RC, a.J, vr + 2, lane);
         if (vr + 3 < nvr) tile32_dma_issue_vrow<SGR_PK_BWD_AUX, EW>(tile + ((vr + 3) % 3) * kT32Floats, gimg, x.p0, RC, a.J, vr + 3, lane);

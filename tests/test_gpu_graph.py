@@ -105,3 +105,37 @@ def test_light_objective_step_replays(sgr, decoder_outputs):
         return [obj, rerr, cerr, ren, coef, *g]
 
     _check_replays(step, bn, imH, imW, R, C, K)
+
+
+def test_capture_step_helper_at_the_reference_batch(sgr):
+    """sgr.capture_step (the packaged recipe): layer + render loss + backward at the reference's default batch of 5
+    (trainLight.py:28), replayed after the static inputs are overwritten -- bit-identical to the eager step on the same values."""
+    bn, imH, imW, R, C, K = 5, 48, 64, 24, 32, 12
+    static = _inputs(bn, imH, imW, R, C, K, seed=21)
+    for k in SG:
+        static[k].requires_grad_(True)
+    layer = sgr.renderingLayer(imWidth=C, imHeight=R)
+
+    def step(x):
+        env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=True)
+        err, rendered = sgr.render_loss(d, s, x["im"], x["seg"], R, C)
+        g = torch.autograd.grad([err, env], [x[k] for k in SG], grad_outputs=[None, torch.full_like(env, 1e-3)])
+        return (err, rendered) + tuple(g)
+
+    captured = sgr.capture_step(lambda: step(static))
+    assert isinstance(captured, sgr.CapturedStep)
+    for seed in (21, 22, 23):
+        fresh = _inputs(bn, imH, imW, R, C, K, seed=seed)
+        with torch.no_grad():
+            for k, v in fresh.items():
+                static[k].copy_(v)
+        got = [o.clone() for o in captured()]
+        torch.cuda.synchronize()
+        eager_in = {k: v.clone() for k, v in fresh.items()}
+        for k in SG:
+            eager_in[k].requires_grad_(True)
+        want = step(eager_in)
+        torch.cuda.synchronize()
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+    assert captured.replays == 3
