@@ -61,7 +61,22 @@ def algorithmic_bytes_per_shaded_px(K: int, J: int, q: int) -> dict:
                 )
 
 
+def _claim_stdout():
+    """The contract: rank 0 prints ONE JSON line.  RCCL prints a five-line banner ("RCCL version ... Librccl path ...") to the C-level stdout
+    when its first communicator is created -- buffered, so it lands AFTER the line at exit -- and other native libraries may print as well.
+    Everything this process writes to file descriptor 1 from here on goes to stderr; the returned function writes to the real stdout."""
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line: str) -> None:
+        sys.stdout.flush()
+        os.write(real, (line + "\n").encode())
+    return emit
+
+
 def main() -> None:
+    emit = _claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -134,7 +149,7 @@ def main() -> None:
                                       decoder_outputs=heads)[0]
             torch.autograd.grad(obj, sg)
         torch.cuda.synchronize()
-        print(json.dumps({"pmc_workload": args.pmc_workload, "config": args.config, "batch": bn, "iterations": args.warmup + args.steps}), flush=True)
+        emit(json.dumps({"pmc_workload": args.pmc_workload, "config": args.config, "batch": bn, "iterations": args.warmup + args.steps}))
         return
 
     def step(i=None):
@@ -377,7 +392,7 @@ def main() -> None:
                 out["eager_gpu_baseline"] = eager_gpu_baseline(O, dev, 240, 320, 120, 160, 12, 8, 16)
             except Exception as exc:       # informational leg: never fail the bench over it
                 out["eager_gpu_baseline"] = {"error": str(exc)[:200]}
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
 
     if world > 1:
         dist.destroy_process_group()

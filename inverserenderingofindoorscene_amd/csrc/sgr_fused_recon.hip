@@ -90,6 +90,10 @@ __global__ __launch_bounds__(kWave, OCC) void sg_bwd_recon_pk_kernel(const Args 
   // time (sg_bwd_pk_kernel's scheme: both halves of a line back to back) brought the fetch down to 671 MB but cost 18 KB of LDS and ran
   // SLOWER, 342 vs 321 us (r04c_kbench.txt): this kernel moves 3 TB/s and is bound by VALU issue, the re-fetches come out of the Infinity
   // Cache, and the 12-instruction DMA bursts sit in front of the loads the next row's arithmetic is waiting for.  Not adopted.
+  // Round 5 (profiles/r05c_objective_bwd_gt_stream.txt, one box, three alternations; kbench = the bench loop for this kernel): what the stream
+  // costs is not the WAIT -- with the requests issued and never waited for (tools/ablate.sh 32) 316 us against 321-325 -- but the requests
+  // themselves: without them (ablation 1) 268-271 us.  So nothing that hides latency better can pay: a ring of three one-row tiles with row
+  // vr+2 requested (twice the latency tolerance) 333-336 us, the non-temporal policy on the rows 335-337, both 347-352.
   __shared__ __attribute__((aligned(16))) float tile[2 * kTile];
   static_assert(NG == 2 || NG == 4, "two or four lane groups per pixel");
 
@@ -170,9 +174,9 @@ __global__ __launch_bounds__(kWave, OCC) void sg_bwd_recon_pk_kernel(const Args 
         // ablation: no ground-truth rows requested or waited for
       } else if (vr + 1 < nvr) {
         issue(tile + ((vr + 1) & 1) * kTile, vr + 1);
-        wait_vmcnt<kRow>();      // this virtual row has landed; the next stays in flight
+        if (!(SGR_ABLATE & 32)) wait_vmcnt<kRow>();      // this virtual row has landed; the next stays in flight
       } else {
-        wait_vmcnt<0>();
+        if (!(SGR_ABLATE & 32)) wait_vmcnt<0>();
       }
       if (GRADS && !ORTHO) fence_row_invariants(q);
       const f32x8 row = rows[e];
@@ -467,12 +471,13 @@ static int fused_fwd_recon_impl(const float* albedo, const float* normal, const 
   a.F0 = F0; a.premap = premap == 1 ? 1 : (premap == 3 ? 3 : 0);
   SGR_REQUIRE(premap >= 0 && premap <= 3, "sgr_fused_fwd_recon: premap must be 0..3");
   SGR_SUPPORTED(premap != 3 || K > 6, "sgr_fused_fwd_recon: premap 3 (decoder heads as a prologue) needs 6 < SGNum <= 24");
-  // 7..12 lobes on the 8x16 grid with pre-mapped or post-tan inputs: packed, one pixel per lane.  Everything else -- more lobes,
-  // the 16x32 grid, and premap == 3 -- the packed half-wave statistics kernel: at three waves per SIMD the 42 tanh per lane of
-  // the decoder heads disappear behind the other waves' row loops (165 us with or without them at config 2), where the
-  // one-pixel-per-lane kernel's 84 per lane at two waves per SIMD cost 22-32 us
-  static const int fwd_half = [] { const char* e = getenv("SGR_OBJ_FWD_HALF"); return e ? atoi(e) : 0; }();      // round-5 A/B: 7..12 lobes, premap <= 2 through the half-wave kernel too
-  const bool wide = K > 12 || ew == 32 || premap == 3 || (fwd_half && K > 6);
+  // More than six lobes, or the 16x32 grid: the packed half-wave statistics kernel, whatever the pre-map -- at three waves per SIMD the 42
+  // tanh per lane of the decoder heads disappear behind the other waves' row loops (165 us with or without them at config 2).  Rounds 2-4 ran
+  // 7..12 lobes with premap <= 2 through the one-pixel-per-lane form (fwd_pk_kernel<12, .., HAS_GT>: single-buffered ground-truth tile, 893 MB
+  // fetched per launch for 617 algorithmic, 88 B of scratch -- the round-4 review's finding); same-box A/B in the bench loop, round 5
+  // (profiles/r05c_bench_ab.txt): objective step 0.500-0.513 vs 0.503-0.504 ms, with standalone heads 0.776 vs 0.781-0.782 -- a tie on warm
+  // data, at 1.04-1.1x the algorithmic traffic instead of 1.46x, so the instantiation is gone.  Up to six lobes: one pixel per lane.
+  const bool wide = K > 6 || ew == 32;
   const int tiles = wide ? recon_tiles32(R * C) : recon_tiles(R * C);
   float* den_img = workspace;
   float* ws0 = workspace + bn + 4;
@@ -499,13 +504,8 @@ static int fused_fwd_recon_impl(const float* albedo, const float* normal, const 
 #undef SGR_LAUNCH_GT
   } else {
     const dim3 grid = wave_grid(bn, R, C), block(kWave);
-    if (K <= 6) {
-      if (p1) hipLaunchKernelGGL((fwd_pk_kernel<6, 1, false, true, true>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((fwd_pk_kernel<6, 2, false, true, true>), grid, block, 0, st, a);
-    } else {
-      if (p1) hipLaunchKernelGGL((fwd_pk_kernel<12, 1, false, true, true>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((fwd_pk_kernel<12, 2, false, true, true>), grid, block, 0, st, a);
-    }
+    if (p1) hipLaunchKernelGGL((fwd_pk_kernel<6, 1, false, true, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((fwd_pk_kernel<6, 2, false, true, true>), grid, block, 0, st, a);
   }
   if (deferred) {
     *deferred = FoldJob{ws0, coef, den_img, tiles};

@@ -17,7 +17,7 @@ from oracle import make_golden as MG
 from oracle import ref_import as RI
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
-CFG = dict(bn=1, imH=24, imW=32, R=12, C=16, K=24, eh=16, ew=32, fov=57.0, F0=0.05, seed=20208, flavour="stress")
+CFG = dict(bn=1, imH=24, imW=32, R=12, C=16, K=24, eh=16, ew=32, fov=57.0, F0=0.05, seed=20208, flavour="stress", rng="numpy")
 
 
 def main():
@@ -40,8 +40,8 @@ def main():
                 v = v[:, :, ::2, ::2]
             v = v.numpy()
             blob[f"{tag}_{k}"] = v if (tag == "ref64" and v.size < 50000) else v.astype(np.float32)
-    blob["cfg_keys"] = np.array(sorted(k for k in CFG if k != "flavour"))
-    blob["cfg_vals"] = np.array([float(CFG[k]) for k in sorted(k for k in CFG if k != "flavour")])
+    blob["cfg_keys"] = np.array(sorted(k for k in CFG if k not in ("flavour", "rng")))
+    blob["cfg_vals"] = np.array([float(CFG[k]) for k in sorted(k for k in CFG if k not in ("flavour", "rng"))])
     path = os.path.join(OUT, "g8_cfg5_small.npz")
     np.savez_compressed(path, **blob)
     print("wrote", path, f"{os.path.getsize(path) / 1e6:.2f} MB")

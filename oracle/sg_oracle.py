@@ -421,3 +421,39 @@ def synthetic_inputs(bn: int, imH: int, imW: int, R: int, C: int, K: int = 12,
     out = dict(albedo=albedo, normal=normal, rough=rough, axis=axis, lamb=lamb, weight=weight,
                im=im, seg=seg, env_gt=env_gt)
     return {k: v.to(dtype).contiguous() for k, v in out.items()}
+
+
+def synthetic_inputs_np(bn: int, imH: int, imW: int, R: int, C: int, K: int = 12, eh: int = 8, ew: int = 16, seed: int = 20202,
+                        benign: bool = False, unit_normals_only: bool = False):
+    """:func:`synthetic_inputs` with the same distributions drawn from ``numpy.random.RandomState(seed)`` -- the legacy MT19937 stream,
+    frozen by NumPy's compatibility policy (NEP 19) -- instead of torch's CPU generator, whose stream is an implementation detail of the
+    installed torch.  The reference-made full-size fixtures (tests/golden/g7, g8, g9) store only results and regenerate their inputs from
+    the seed, so those inputs must not depend on the torch version: rounds 3-4 skipped the comparison when the checksums differed."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    hi = 0.9 if benign else 1.0
+    albedo = f32(rs.random_sample((bn, 3, imH, imW)))
+    n = rs.standard_normal((bn, 3, imH, imW))
+    n[:, 2] = np.abs(n[:, 2]) + 0.5
+    normal = f32(n)
+    normal = normal / normal.norm(dim=1, keepdim=True)          # fp32 normalisation, like synthetic_inputs (unit to one rounding)
+    rough = f32(rs.random_sample((bn, 1, imH, imW)) * 2.0 - 1.0)
+    a = f32(rs.standard_normal((bn, K, 3, R, C)))
+    axis = a / a.norm(dim=2, keepdim=True)
+    lamb = f32(rs.random_sample((bn, K, R, C)) * hi)
+    weight = f32(rs.random_sample((bn, 3 * K, R, C)) * hi)
+    im = f32(rs.random_sample((bn, 3, imH, imW)))
+    seg = f32((rs.random_sample((bn, 1, imH, imW)) < 0.9).astype(np.float32))
+    env_gt = f32(rs.random_sample((bn, 3, R, C, eh, ew)) * 2.0)
+    out = dict(albedo=albedo, normal=normal, rough=rough, axis=axis, lamb=lamb, weight=weight, im=im, seg=seg, env_gt=env_gt)
+    return {k: v.contiguous() for k, v in out.items()}
+
+
+def synthetic_cotangents_np(bn: int, R: int, C: int, eh: int, ew: int, seed: int):
+    """Standard-normal cotangents ``(ct_env [bn,3,R,C,eh,ew], ct_d, ct_s [bn,3,R,C])`` from ``numpy.random.RandomState(seed)``."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    return [f32(rs.standard_normal((bn, 3, R, C, eh, ew))), f32(rs.standard_normal((bn, 3, R, C))), f32(rs.standard_normal((bn, 3, R, C)))]
+

@@ -24,7 +24,7 @@ def _build_if_missing():
     (``__graft_entry__.build()``: hipcc cross-compiles gfx950 without a GPU, about a minute).  Test infrastructure only -- the package
     itself never builds anything and raises ``SgrenderUnavailable`` when a library is missing (tests/test_abi.py)."""
     pkg = os.path.join(ROOT, "inverserenderingofindoorscene_amd")
-    if all(os.path.isfile(os.path.join(pkg, f)) for f in ("libsgrender.so", "libsgrender_torch.so")):
+    if all(os.path.isfile(os.path.join(pkg, f)) for f in ("libsgrender.so", "libsgrender_torch.so", "libsgrender_h5.so")):
         return
     import __graft_entry__
     __graft_entry__.build()

@@ -1,7 +1,7 @@
 """GPU: parity AT SIZE, whole images.  BASELINE config 2 (batch 16, 240x320 -> 120x160, SGNum 12, 8x16): ALL sixteen images,
 every env cell, forward and backward w.r.t. the SG parameters AND the BRDF maps, against the fp64 oracle; one image against the
 reference-made fixture g7_cfg2_one_image.npz (oracle/make_golden_fullsize.py: the unmodified reference in fp32 and fp64), which
-supplies the reference's own fp32 error e_ref as the yardstick; one full image of config 5 (480x640 -> 240x320, SGNum 24,
+supplies the reference's own fp32 error e_ref as the yardstick; the clamp kink at size against reference fp32 (g9_ratio1_unit_normals.npz); one full image of config 5 (480x640 -> 240x320, SGNum 24,
 16x32) with e_ref from the reference-made fixture g8_cfg5_small.npz (oracle/make_golden_cfg5.py), which is also compared
 against directly; and a fixed-seed randomised shape sweep.  Every tolerance is ``max(2 e_ref, 1e-4)`` (BASELINE.md section 3 /
 north_star), capped at 2e-4 for the normal / roughness gradients, whose reference fp32 evaluation is itself only good to 1e-3
@@ -51,6 +51,18 @@ def g8():
     return _fixture_with_eref("g8_cfg5_small.npz")
 
 
+def _regenerated_inputs(O, z, cfg):
+    """The inputs and cotangents of a results-only fixture (g7, g8, g9), regenerated from the seed out of NumPy's frozen legacy stream
+    (oracle.synthetic_inputs_np) -- and the stored checksums HOLD: rounds 3-4 drew them from torch's CPU generator and skipped the
+    comparison when a machine's stream differed, which would have switched the strongest tests off silently after a torch update."""
+    inp = O.synthetic_inputs_np(cfg["bn"], cfg["imH"], cfg["imW"], cfg["R"], cfg["C"], cfg["K"], cfg["eh"], cfg["ew"], seed=cfg["seed"])
+    chk = np.array([inp[k].double().sum().item() for k in NAMES])
+    assert np.allclose(chk, z["in_checksums"], rtol=1e-12), ("regenerated inputs differ from the ones the fixture was made with", chk, z["in_checksums"])
+    cts = O.synthetic_cotangents_np(cfg["bn"], cfg["R"], cfg["C"], cfg["eh"], cfg["ew"], cfg["seed"] + 7)
+    assert np.allclose([c.double().sum().item() for c in cts], z["ct_checksums"], rtol=1e-12)
+    return inp, cts
+
+
 def _fwd_bwd(sgr, inp, cts, R, C, eh=8, ew=16, wrt=SG):
     x = {k: inp[k].cuda() for k in NAMES}
     for k in wrt:
@@ -77,14 +89,8 @@ def test_one_image_vs_reference_fixture(sgr, g7):
     """The reference itself at full size: fp32 values, and fp64 values as the arbiter; SG and BRDF-map gradients."""
     from oracle import sg_oracle as O
     z, cfg, e_ref = g7
-    inp = O.synthetic_inputs(cfg["bn"], cfg["imH"], cfg["imW"], cfg["R"], cfg["C"], cfg["K"], cfg["eh"], cfg["ew"], seed=cfg["seed"])
-    chk = np.array([inp[k].double().sum().item() for k in NAMES])
-    if not np.allclose(chk, z["in_checksums"], rtol=1e-12):
-        pytest.skip("torch's CPU generator produced different synthetic inputs on this machine")
-    g = torch.Generator().manual_seed(cfg["seed"] + 7)
+    inp, cts = _regenerated_inputs(O, z, cfg)
     R, C, eh, ew = cfg["R"], cfg["C"], cfg["eh"], cfg["ew"]
-    cts = [torch.randn((1, 3, R, C, eh, ew), generator=g), torch.randn((1, 3, R, C), generator=g), torch.randn((1, 3, R, C), generator=g)]
-    assert np.allclose([c.double().sum().item() for c in cts], z["ct_checksums"], rtol=1e-12)
     env, d, s, grads = _fwd_bwd(sgr, inp, cts, R, C, eh, ew, wrt=SG + BRDF)
     se, ss = [int(v) for v in z["strides"]]
     got = dict(env=env[:, :, ::se, ::se], diffuse=d, spec=s, **{f"glin_{k}": gk[..., ::ss, ::ss] for k, gk in grads.items()})
@@ -97,11 +103,61 @@ def test_one_image_vs_reference_fixture(sgr, g7):
         assert e64 <= (2.0 * e_ref[k] if loose else tol2(e_ref[k], 1e-5)), (k, "vs reference fp64", e64, e_ref[k])
         assert e32 <= (3.0 * e_ref[k] if loose else 1e-4), (k, "vs reference fp32", e32, e_ref[k])
     print("config 2, one image vs the reference-made fixture: (vs ref32, vs ref64, e_ref)", {k: tuple(f"{x:.2e}" for x in v) for k, v in report.items()})
-    assert rel_max(d.cpu(), z["ref32_diffuse"]) < 2e-4 and rel_max(s.cpu(), z["ref32_spec"]) < 2e-4
+    # max-abs / max|ref| against reference fp32 (<= 2e-4) -- or twice the reference's OWN max-norm error against its fp64 run where
+    # that is larger: on this image the reference's fp32 specular term is 2.7e-4 off its fp64 one in the max norm, the kernel 6e-5
+    for k, v in (("diffuse", d), ("spec", s)):
+        own = rel_max(z["ref32_" + k], z["ref64_" + k])
+        assert rel_max(v.cpu(), z["ref32_" + k]) <= max(2e-4, 2.0 * own), (k, rel_max(v.cpu(), z["ref32_" + k]), own)
+        assert rel_max(v.cpu(), z["ref64_" + k]) <= max(2e-4, 2.0 * own), (k, rel_max(v.cpu(), z["ref64_" + k]), own)
     assert abs(env.double().norm().item() - float(z["ref32_env_norm"][0])) < 1e-5 * float(z["ref32_env_norm"][0])
     for k in SG:
         n = float(z[f"ref32_glin_{k}_norm"][0])
         assert abs(grads[k].double().norm().item() - n) < 1e-4 * n, k
+
+
+def test_clamp_kink_at_size_vs_reference_fp32(sgr):
+    """Fixture g9 (round 5; oracle/make_golden_fullsize.py): BRDF maps AT the env-grid resolution (120x160, no pooling) with unit input
+    normals -- every pixel sits on the |N|^2 == 1 kink of the two-sided clamp (models.py:467-468), where the reference's fp32 and fp64
+    normal gradients differ by O(1) (0.99 rel-L2 over this image) and fp64 is no arbiter.  The reference's fp32 VALUES are the semantics:
+    normal / roughness gradients against reference fp32 over ALL pixels within max(3 e_ref, 1e-4), e_ref = the reference's own fp32-vs-fp64
+    error on the pixels where its two runs take the same clamp branch (`agree`, 66 % of the image: 4.6e-4 / 2.8e-4) -- and against reference
+    fp64 on those pixels within 2 e_ref.  (Rounds 3-4 held this case to a bare 2e-3 against the fp32 ORACLE on small random shapes.)"""
+    from oracle import sg_oracle as O
+    z = np.load(os.path.join(GOLDEN_DIR, "g9_ratio1_unit_normals.npz"))
+    cfg = {k: v for k, v in zip(z["cfg_keys"].tolist(), z["cfg_vals"].tolist())}
+    for k in ("bn", "imH", "imW", "R", "C", "K", "eh", "ew", "seed"):
+        cfg[k] = int(cfg[k])
+    inp, cts = _regenerated_inputs(O, z, cfg)
+    R, C, eh, ew = cfg["R"], cfg["C"], cfg["eh"], cfg["ew"]
+    assert (cfg["imH"], cfg["imW"]) == (R, C)
+    env, d, s, grads = _fwd_bwd(sgr, inp, cts, R, C, eh, ew, wrt=SG + BRDF)
+    se, ss = [int(v) for v in z["strides"]]
+    agree = torch.from_numpy(z["agree"])
+    regular = _regular_normals(inp, 0, R, C)                       # N parallel to up: the reference's gradient is O(1e20) garbage there
+    report = {}
+    # values and the gradients the kink does not touch: the usual bounds
+    got = dict(env=env[:, :, ::se, ::se], diffuse=d, spec=s, glin_albedo=grads["albedo"], **{f"glin_{k}": grads[k][..., ::ss, ::ss] for k in SG})
+    for k, v in got.items():
+        r32, r64 = torch.from_numpy(z["ref32_" + k]), torch.from_numpy(z["ref64_" + k])
+        e_ref = rel_l2(r32, r64)
+        e32, e64 = rel_l2(v.cpu(), r32), rel_l2(v.cpu(), r64)
+        report[k] = (e32, e64, e_ref)
+        # vs reference fp64 within twice the reference's own fp32 error; vs reference fp32 within 1e-4 -- or that same 2 e_ref where the
+        # reference's fp32 run is itself farther than 5e-5 from its fp64 one (the specular term of this image: 1.8e-4)
+        assert e64 <= tol2(e_ref, 1e-5) and e32 <= tol2(e_ref), (k, e32, e64, e_ref)
+    for k in ("normal", "rough"):
+        a = grads[k].cpu()
+        r32, r64 = torch.from_numpy(z[f"ref32_glin_{k}"]), torch.from_numpy(z[f"ref64_glin_{k}"])
+        m_all = regular.expand_as(a)
+        m_agree = (regular & agree).expand_as(a)
+        e_ref = rel_l2(r32[m_agree], r64[m_agree])                  # the reference's own fp32 error where fp64 is an arbiter
+        e32_all = rel_l2(a[m_all], r32[m_all])
+        e64_agree = rel_l2(a[m_agree], r64[m_agree])
+        report["glin_" + k] = (e32_all, e64_agree, e_ref, rel_l2(r32[m_all], r64[m_all]))
+        assert e32_all <= max(3.0 * e_ref, 1e-4), (k, "vs reference fp32, all pixels", e32_all, e_ref)
+        assert e64_agree <= max(2.0 * e_ref, 2e-4), (k, "vs reference fp64 where the clamp branches agree", e64_agree, e_ref)
+    print("clamp kink at size (g9): (vs ref32, vs ref64 [agreeing pixels for normal / rough], e_ref[, ref32 vs ref64 over all pixels])",
+          {k: tuple(f"{x:.2e}" for x in v) for k, v in report.items()})
 
 
 def test_config2_all_sixteen_images_forward_backward(sgr, g7):
@@ -137,13 +193,7 @@ def test_config5_small_vs_reference_fixture(sgr, g8):
     from oracle import sg_oracle as O
     z, cfg, e_ref = g8
     R, C, K, eh, ew = cfg["R"], cfg["C"], cfg["K"], cfg["eh"], cfg["ew"]
-    inp = O.synthetic_inputs(cfg["bn"], cfg["imH"], cfg["imW"], R, C, K, eh, ew, seed=cfg["seed"])
-    chk = np.array([inp[k].double().sum().item() for k in NAMES])
-    if not np.allclose(chk, z["in_checksums"], rtol=1e-12):
-        pytest.skip("torch's CPU generator produced different synthetic inputs on this machine")
-    g = torch.Generator().manual_seed(cfg["seed"] + 7)
-    cts = [torch.randn((1, 3, R, C, eh, ew), generator=g), torch.randn((1, 3, R, C), generator=g), torch.randn((1, 3, R, C), generator=g)]
-    assert np.allclose([c.double().sum().item() for c in cts], z["ct_checksums"], rtol=1e-12)
+    inp, cts = _regenerated_inputs(O, z, cfg)
     env, d, s, grads = _fwd_bwd(sgr, inp, cts, R, C, eh, ew, wrt=SG + BRDF)
     st = int(z["env_stride"][0])
     got = dict(env=env[:, :, ::st, ::st], diffuse=d, spec=s, **{f"glin_{k}": gk for k, gk in grads.items()})

@@ -220,12 +220,28 @@ def test_shapes_vs_oracle(sgr, shape):
     # pooling, fp32 and fp64 evaluations of |N|^2 land on different sides of the kink pixel by pixel (e32 of that gradient is
     # then O(1)).  The reference semantics are the fp32 ones, which the kernels follow (|N|^2 with torch's own rounding), so
     # there the gradient is compared with the oracle evaluated in fp32; likewise roughness, which sees the same pixels.
+    # Round 5: no bare constant any more (rounds 3-4: 2e-3 against the fp32 oracle).  `agree` = the pixels where the fp32 and the fp64
+    # evaluation of the clamp take the same branch: there fp64 IS an arbiter and e_kink = the fp32 oracle's own error on those pixels is
+    # the yardstick -- the gradient must be within 2 e_kink of fp64 there, and within max(3 e_kink, 1e-4) of the fp32 evaluation over ALL
+    # pixels (a kernel that took the other branch on a single pixel would be O(1) off on it).  The same comparison against the REFERENCE's
+    # own fp32 and fp64 values, at size, is tests/test_gpu_fullsize.py::test_clamp_kink_at_size_vs_reference_fp32 (fixture g9).
+    n_in = inp["normal"]
+    pooled = n_in if (shape["imH"], shape["imW"]) == (shape["R"], shape["C"]) else None
     for k, a in zip(NAMES, grads):
         assert torch.isfinite(a).all(), k
         e, noise = rel_l2(a, r64["g_" + k]), e32["g_" + k]
         if k in ("normal", "rough") and noise > 1e-3:
+            assert pooled is not None, (shape, k, noise)      # only unpooled unit normals sit on the kink
+            nn32 = torch.sum(pooled.float() * pooled.float(), dim=1, keepdim=True)
+            nn64 = torch.sum(pooled.double() * pooled.double(), dim=1, keepdim=True)
+            agree = ((nn32 <= 1.0) == (nn64 <= 1.0)).cuda().expand_as(a)
+            e_kink = rel_l2(r32["g_" + k][agree], r64["g_" + k][agree])
             e_f32 = rel_l2(a, r32["g_" + k])
-            assert e_f32 <= 2e-3, (shape, k, "vs the fp32 oracle (clamp kink: fp64 is no arbiter)", e_f32, noise)
+            # floor 2e-4: the cap the full-size tests hold these two gradients to (tests/test_gpu_fullsize.py), not 1e-4 -- a handful of
+            # near-singular pixels carry the norm of the normal gradient on a 9 x 13 grid
+            assert e_f32 <= max(3.0 * e_kink, 2e-4), (shape, k, "vs the fp32 evaluation, all pixels (clamp kink: fp64 is no arbiter)", e_f32, e_kink)
+            e_agree = rel_l2(a[agree], r64["g_" + k][agree])
+            assert e_agree <= max(2.0 * e_kink, 2e-4), (shape, k, "vs fp64 where the clamp branches agree", e_agree, e_kink)
         else:
             assert e <= (2.0 * noise if k in ("normal", "rough") and noise > 5e-5 else tol2(noise)), (shape, k, e, noise)
 

@@ -4,10 +4,11 @@
 (= RCCL on ROCm) drives everything the 8-GPU run does except the wire: ``init_process_group("nccl")``, the all-reduce of the
 device-resident ``[num, den]`` pair between the render loss's passes and its finalize operator (wrapperBRDFLight.py:192,205-207:
 the normaliser is batch-global), the two all-reduces between the light objective's three stage operators (with and without the decoder
-heads as the kernels' prologue), on the stream the kernels run on.  A sum over one rank is the identity, so every loss and every
-gradient must be BIT-identical to the unsharded call's -- except the objective's reconstruction term, which the one-rank operator folds
-together with the scalar tail in one kernel and the staged route folds in two (same partials, same order, one rounding apart at most:
-held to 2e-7 relative).  Runs in a subprocess: a process group must not outlive the test in the pytest process.
+heads as the kernels' prologue), on the stream the kernels run on.  A sum over one rank is the identity, so the render loss, every image
+output and EVERY GRADIENT must be BIT-identical to the unsharded call's -- and are.  The objective's two reported scalars (the reconstruction
+term and the weighted sum) may differ by one rounding: the one-rank operator folds the batch totals and the scalar tail in one kernel, the
+staged route in a stage operator's fold plus the finalize operator (1.1e-7 relative on two images of config 2, 0 on the small cases): held to
+2e-7.  Runs in a subprocess: a process group must not outlive the test in the pytest process.
 tests/test_gpu_sharded.py covers world size 2 (gloo, host copies); N > 1 over RCCL has never been run -- it is the driver's."""
 import json
 import os
@@ -103,11 +104,10 @@ def test_render_loss_and_light_objective_through_rccl_world_of_one():
     print(json.dumps(out))
     for case, rec in out.items():
         assert rec["obj_grads_finite_nonzero"] is True, (case, rec)
-        # what the two routes share kernel for kernel is bit-identical (a sum over one rank is the identity)
-        for k in ("rendered_equal", "obj_rendered_equal"):
+        for k in ("render_err_equal", "rendered_equal", "render_grads_equal", "obj_render_err_equal", "obj_rendered_equal", "obj_grads_equal"):
             assert rec[k] is True, (case, k, rec)
-        # the rest differs by where the batch totals are folded (one kernel on one rank, a stage operator's fold + the finalize operator
-        # when sharded): the same partials in the same order, a rounding apart at most
-        for k in ("render_err_rel", "render_grads_rel", "obj_grads_rel", "obj_rel", "recon_rel", "obj_ng_rel", "rendered_rel"):
-            assert rec[k] <= 5e-7, (case, k, rec)
+        for k in ("render_err_rel", "render_grads_rel", "obj_grads_rel", "rendered_rel"):
+            assert rec[k] == 0.0, (case, k, rec)
+        for k in ("obj_rel", "recon_rel", "obj_ng_rel"):
+            assert rec[k] <= 2e-7, (case, k, rec)
         assert rec["obj_ng_vs_grad_rel"] <= 2e-6, (case, rec)

@@ -1,0 +1,187 @@
+"""CPU: the cascade hand-off container (include/sgrender_h5.h, inverserenderingofindoorscene_amd/handoff.py).
+
+The reference writes its cascade-0 predictions with ``utils.writeH5ToFile`` (utils.py:92-99: one float32 dataset ``data`` per file, h5py
+``compression='lzf'``; outputBRDFLight.py:246-301) and reads them back with ``dataLoader.loadH5`` (dataLoader.py:277-283).  Pinned here:
+
+* **h5py -> product**: fixtures written by the real h5py 3.3.0 exactly as the reference writes them (oracle/make_golden_h5.py, run under the
+  image's Anaconda interpreter; tests/golden/h5/) decode bit for bit -- compressible, incompressible (stored raw by the optional filter),
+  multi-chunk, a single value, and an uncompressed dataset;
+* **product -> h5py**: files written by the product open in that h5py (a subprocess of /opt/conda/bin/python3.9; skipped where it does not
+  exist) with ``compression == 'lzf'``, the chunk shape h5py itself would have guessed, and identical values;
+* the LZF coder (this package's own; the liblzf stream format) round-trips structured and random buffers and declines incompressible input;
+* the drop-in functions keep the reference's behaviour (per-image files, truncation, ``None`` on unreadable files, the export's file names,
+  existing files left alone, env written only where ``envmapsInd == 1``);
+* the C ABI library exports every symbol its header declares."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR, ROOT
+
+from inverserenderingofindoorscene_amd import handoff as H
+
+H5DIR = os.path.join(GOLDEN_DIR, "h5")
+CONDA_PY = "/opt/conda/bin/python3.9"
+CASES = sorted(f[:-3] for f in os.listdir(H5DIR) if f.endswith(".h5"))
+
+
+def test_library_loads_and_exports_its_header():
+    assert H.h5_available(), "libsgrender_h5.so must find a libhdf5 >= 1.10 in this image (/opt/conda/lib/libhdf5.so.103)"
+    lib = ctypes.CDLL(os.path.join(ROOT, "inverserenderingofindoorscene_amd", "libsgrender_h5.so"))
+    header = open(os.path.join(ROOT, "include", "sgrender_h5.h")).read()
+    names = set(re.findall(r"\b(sgr_[a-z0-9_]+)\s*\(", header))
+    assert {"sgr_h5_write_f32", "sgr_h5_read_f32", "sgr_h5_shape", "sgr_h5_dataset_info", "sgr_h5_available", "sgr_lzf_compress", "sgr_lzf_decompress"} <= names
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.sgr_h5_abi_version() == 1
+    ver = (ctypes.c_uint * 3)()
+    assert lib.sgr_h5_available(ver) == 1 and ver[0] == 1 and ver[1] >= 10
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_files_written_by_h5py_read_bit_for_bit(case):
+    want = np.load(os.path.join(H5DIR, case + ".npy"))
+    got = H.loadH5(os.path.join(H5DIR, case + ".h5"))
+    assert got is not None and got.dtype == np.float32 and got.shape == want.shape
+    assert np.array_equal(got, want)
+    info = H.h5_dataset_info(os.path.join(H5DIR, case + ".h5"))
+    assert info["compression"] == (None if case == "uncompressed" else "lzf")
+
+
+def _arrays():
+    rs = np.random.RandomState(5)
+    return {
+        "imenv": np.tanh(rs.standard_normal((84, 12, 16))).astype(np.float32),
+        "smooth": np.linspace(0, 1, 3 * 120 * 160, dtype=np.float32).reshape(3, 120, 160),
+        "zeros": np.zeros((3, 24, 32), dtype=np.float32),
+        "quantised": (rs.randint(0, 4, size=(84, 30, 40)) * 0.25).astype(np.float32),
+        "noise": rs.standard_normal((3, 40, 50)).astype(np.float32),
+        "one": np.array([[[-7.5]]], dtype=np.float32),
+        "special": np.array([[[0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, 3.4e38, -1.0]]], dtype=np.float32),
+        "rank1": np.arange(1000, dtype=np.float32),
+        "rank5": rs.random_sample((3, 4, 5, 8, 16)).astype(np.float32),      # an env image in miniature
+    }
+
+
+def test_round_trip_through_the_product(tmp_path):
+    for name, arr in _arrays().items():
+        p = str(tmp_path / (name + ".h5"))
+        H._write(p, arr)
+        back = H.loadH5(p)
+        assert back is not None and back.shape == arr.shape and back.tobytes() == arr.tobytes(), name      # bytes: NaN and -0.0 included
+        info = H.h5_dataset_info(p)
+        assert info["compression"] == "lzf" and len(info["chunks"]) == arr.ndim, (name, info)
+    sizes = {n: os.path.getsize(str(tmp_path / (n + ".h5"))) for n in ("zeros", "quantised", "noise", "smooth")}
+    assert sizes["zeros"] < 3 * 24 * 32 * 4 and sizes["quantised"] < 0.5 * 84 * 30 * 40 * 4      # the filter does compress (h5py with liblzf: 162 983 B for this array, here 163 077)
+    assert sizes["noise"] >= 3 * 40 * 50 * 4                                                       # ... and stores noise raw
+    H._write(str(tmp_path / "raw.h5"), _arrays()["quantised"], compression=False)
+    assert H.h5_dataset_info(str(tmp_path / "raw.h5"))["compression"] is None
+    assert np.array_equal(H.loadH5(str(tmp_path / "raw.h5")), _arrays()["quantised"])
+
+
+@pytest.mark.skipif(not os.path.isfile(CONDA_PY), reason="the image's Anaconda interpreter (h5py 3.3.0) is not present")
+def test_files_written_by_the_product_open_in_h5py(tmp_path):
+    arrs = _arrays()
+    for name, arr in arrs.items():
+        H._write(str(tmp_path / (name + ".h5")), arr)
+        np.save(str(tmp_path / (name + ".npy")), arr)
+    script = r'''
+import json, os, sys
+import h5py, numpy as np
+d = sys.argv[1]
+out = {}
+for f in sorted(os.listdir(d)):
+    if not f.endswith(".h5"):
+        continue
+    want = np.load(os.path.join(d, f[:-3] + ".npy"))
+    with h5py.File(os.path.join(d, f), "r") as hf:
+        ds = hf["data"]
+        got = np.array(hf.get("data"))                      # dataLoader.py:280
+        tmp = os.path.join(d, "_ref.h5")
+        with h5py.File(tmp, "w") as hr:                     # what h5py itself would have chosen for this array
+            ref_chunks = hr.create_dataset("data", data=want, compression="lzf").chunks
+        out[f[:-3]] = dict(equal=bool(got.tobytes() == want.tobytes()), dtype=str(ds.dtype), compression=ds.compression, chunks=list(ds.chunks),
+                           ref_chunks=list(ref_chunks), shape=list(ds.shape))
+print("RESULT " + json.dumps(out))
+'''
+    p = subprocess.run([CONDA_PY, "-c", script, str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    assert set(out) == set(arrs)
+    for name, r in out.items():
+        assert r["equal"] and r["dtype"] == "float32" and r["compression"] == "lzf", (name, r)
+        assert r["shape"] == list(arrs[name].shape) and r["chunks"] == r["ref_chunks"], (name, r)
+
+
+def test_lzf_coder_round_trips_and_declines_incompressible_input():
+    lib = H._load()
+    rs = np.random.RandomState(11)
+    bufs = [b"a", b"ab", b"abc", b"aaaa", b"abcabcabcabcabcabc" * 50, bytes(5000), bytes(range(256)) * 40, rs.bytes(1), rs.bytes(4097),
+            np.repeat(rs.randint(0, 256, 300).astype(np.uint8), rs.randint(1, 40, 300)).tobytes(),       # runs of every length
+            (np.arange(20000) % 251).astype(np.uint8).tobytes(),                                        # period just under the literal limit
+            np.tile(rs.bytes(9000), 3),                                                                 # matches farther back than the 8 KiB window
+            np.tile(np.frombuffer(rs.bytes(300), dtype=np.uint8), 40).tobytes()]                         # long matches (> 264 bytes: split)
+    for b in bufs:
+        b = bytes(b)
+        cap = len(b) + len(b) // 16 + 64
+        comp = ctypes.create_string_buffer(cap)
+        n = lib.sgr_lzf_compress(b, len(b), comp, cap)
+        assert 0 < n <= cap, len(b)
+        out = ctypes.create_string_buffer(len(b))
+        m = lib.sgr_lzf_decompress(comp.raw[:n], n, out, len(b))
+        assert m == len(b) and out.raw[:m] == b
+        assert lib.sgr_lzf_decompress(comp.raw[:n], n, out, len(b) - 1) == 0 if len(b) > 1 else True      # output too small: refused
+    noise = rs.bytes(4096)
+    comp = ctypes.create_string_buffer(4096)
+    assert lib.sgr_lzf_compress(noise, 4096, comp, 4096) == 0            # no gain into a buffer of the input's size: "store raw"
+    zeros = bytes(4096)
+    assert 0 < lib.sgr_lzf_compress(zeros, 4096, comp, 4096) < 64
+    assert lib.sgr_lzf_decompress(b"\xff\xff", 2, comp, 4096) == 0       # a back reference before the start of the output
+
+
+def test_drop_in_functions_keep_the_reference_behaviour(tmp_path):
+    g = torch.Generator().manual_seed(3)
+    bn, K, R, C = 3, 12, 6, 8
+    env = torch.randn(bn, 7 * K, R, C, generator=g)
+    diffuse, spec = torch.rand(bn, 3, R, C, generator=g), torch.rand(bn, 3, R, C, generator=g)
+    ims = [str(tmp_path / f"main_xml/scene{n:04d}/im_{n + 1}.hdr") for n in range(bn)]
+    for p in ims:
+        os.makedirs(os.path.dirname(p), exist_ok=True)
+    # utils.writeH5ToFile: image n -> nameBatch[n], [ch, H, W]
+    names = [str(tmp_path / f"x{n}.h5") for n in range(bn)]
+    H.writeH5ToFile(env, names)
+    for n in range(bn):
+        back = H.loadH5(names[n])
+        assert back.shape == (7 * K, R, C) and np.array_equal(back, env[n].numpy())
+    H.writeH5ToFile(diffuse[0:1], names[0:1])                            # mode 'w': truncated and replaced
+    assert H.loadH5(names[0]).shape == (3, R, C)
+    with pytest.raises(AssertionError):
+        H.writeH5ToFile(env, names[:2])                                  # utils.py:94
+    # dataLoader.loadH5: None for anything unreadable
+    assert H.loadH5(str(tmp_path / "missing.h5")) is None
+    junk = tmp_path / "junk.h5"
+    junk.write_bytes(b"not an hdf5 file at all")
+    assert H.loadH5(str(junk)) is None
+    # outputBRDFLight.py:246-301
+    assert H.handoff_names("/d/main_xml/scene0001/im_3.hdr", 0) == {"env": "/d/main_xml/scene0001/imenv_3_0.h5", "diffuse": "/d/main_xml/scene0001/imdiffuse_3_0.h5",
+                                                                   "specular": "/d/main_xml/scene0001/imspecular_3_0.h5"}
+    ind = torch.tensor([1.0, 0.0, 1.0]).reshape(bn, 1, 1, 1)
+    written = H.write_cascade_handoff(env, diffuse, spec, ims, envmapsInd=ind)
+    assert len(written) == 3 * bn - 1 and not os.path.isfile(H.handoff_names(ims[1])["env"])
+    got = H.read_cascade_handoff(ims[0])
+    assert np.array_equal(got["env"], env[0].numpy()) and np.array_equal(got["diffuse"], diffuse[0].numpy()) and np.array_equal(got["specular"], spec[0].numpy())
+    assert H.read_cascade_handoff(ims[1])["env"] is None
+    assert H.write_cascade_handoff(env * 2, diffuse, spec, ims, envmapsInd=ind) == []          # existing files are left alone
+    assert np.array_equal(H.read_cascade_handoff(ims[2])["env"], env[2].numpy())
+    assert len(H.write_cascade_handoff(env * 2, diffuse, spec, ims, envmapsInd=ind, overwrite=True)) == 3 * bn - 1
+    assert np.array_equal(H.read_cascade_handoff(ims[2])["env"], (env[2] * 2).numpy())
+    # the packed layout splits back into what output2env takes (layers.unpack_envmaps; models.py:229 feeds it to cascade 1)
+    from inverserenderingofindoorscene_amd import unpack_envmaps
+    a, l, w = unpack_envmaps(torch.from_numpy(got["env"]).unsqueeze(0), K)
+    assert tuple(a.shape) == (1, K, 3, R, C) and tuple(l.shape) == (1, K, R, C) and tuple(w.shape) == (1, 3 * K, R, C)
