@@ -14,5 +14,7 @@ for d in $G/pmc_*; do
   w=${d#$G/pmc_}; [ -f $d/summary.txt ] || continue
   case $w in sq_*) cp $d/summary.txt $P/${T}_sq_${w#sq_}.txt;; *) cp $d/summary.txt $P/${T}_pmc_traffic_$w.txt;; esac
 done
+for f in bench_fresh_records; do [ -f $G/$f.txt ] && last $G/$f.txt $P/${T}_$f.json; done
+[ -f $G/wavetrace_report.txt ] && cp $G/wavetrace_report.txt $P/${T}_wavetrace_report.txt
 cp $G/traffic.json $G/sq.json $P/
 ls $P | grep "^${T}_" | wc -l

@@ -9,11 +9,12 @@ LIB=inverserenderingofindoorscene_amd/libsgrender.so
 echo "== pytest gpu"; t0=$SECONDS; timeout 1500 python -m pytest tests -q -m gpu --durations=6 -s > gpurun_out/pytest_gpu.txt 2>&1; echo "pytest wall $((SECONDS-t0)) s"; tail -10 gpurun_out/pytest_gpu.txt | cut -c1-200
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee gpurun_out/smoke.txt | cut -c1-600
 echo "== kbench"; timeout 300 ./tools/kbench $LIB 16 20 > gpurun_out/kbench.txt 2>&1; cat gpurun_out/kbench.txt
-echo "== bench"; t0=$SECONDS; timeout 900 python bench.py > gpurun_out/bench.txt 2>&1; echo "bench wall $((SECONDS-t0)) s" | tee gpurun_out/bench_time.txt; tail -1 gpurun_out/bench.txt | cut -c1-2600
-echo "== bench, driver-style short warm-up"; timeout 600 python bench.py --warmup 5 --steps 20 --no-cpu-baseline --layer-only > gpurun_out/bench_warmup5.txt 2>&1; tail -1 gpurun_out/bench_warmup5.txt | cut -c1-900
-echo "== bench torchrun world=1 (RCCL init / barrier / all-reduce path)"; timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 1 --no-cpu-baseline --layer-only > gpurun_out/bench_torchrun1.txt 2>&1; tail -1 gpurun_out/bench_torchrun1.txt | cut -c1-500
+# bench.py writes the ONE JSON line to stdout and everything else (RCCL's banner included) to stderr: keep the two apart
+echo "== bench"; t0=$SECONDS; timeout 900 python bench.py > gpurun_out/bench.txt 2> gpurun_out/bench.err; echo "bench wall $((SECONDS-t0)) s, stdout lines: $(wc -l < gpurun_out/bench.txt)" | tee gpurun_out/bench_time.txt; tail -1 gpurun_out/bench.txt | cut -c1-2600
+echo "== bench, exactly as the driver runs it"; t0=$SECONDS; timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_warmup5.txt 2> gpurun_out/bench_warmup5.err; echo "wall $((SECONDS-t0)) s"; tail -1 gpurun_out/bench_warmup5.txt | cut -c1-900
+echo "== bench torchrun world=1 (RCCL init / barrier / all-reduce path)"; timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 1 --no-cpu-baseline --layer-only > gpurun_out/bench_torchrun1.txt 2> gpurun_out/bench_torchrun1.err; tail -1 gpurun_out/bench_torchrun1.txt | cut -c1-500
 echo "== host overhead"; timeout 300 python tools/host_overhead.py 2>&1 | tail -10 | tee gpurun_out/host_overhead.txt
-echo "== rocprof bench loop"; cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 20 --reps 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/rocprof.txt 2>&1; cd $GRAFT_REPO_ROOT
+echo "== rocprof bench loop"; cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 20 --reps 2 --no-cpu-baseline --no-config5 > $GRAFT_REPO_ROOT/gpurun_out/rocprof.txt 2>&1; cd $GRAFT_REPO_ROOT
 for f in $(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); do cp $f gpurun_out/kernel_stats.csv; head -12 $f | cut -c1-200; done
 find gpurun_out/prof -name "*kernel_trace.csv" -size +1M -delete
 echo "== rocprof config-3 step (examples/train_light_synthetic.py)"; cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof3 -- python $GRAFT_REPO_ROOT/examples/train_light_synthetic.py --batch 16 --steps 43 > $GRAFT_REPO_ROOT/gpurun_out/rocprof3.txt 2>&1; cd $GRAFT_REPO_ROOT
@@ -31,10 +32,13 @@ echo "== pmc traffic config 5"; bash tools/pmc_traffic.sh config5_batch4_env --c
 echo "== pmc sq config 5"; bash tools/pmc_sq.sh config5_batch4_env --config 5 | grep -E "fwd_pk|sg_bwd_pk"
 echo "== pmc traffic config 5, objective"; bash tools/pmc_traffic.sh config5_batch4_objective --config 5 --pmc-workload objective | grep -E "fwd_pk|sg_bwd_recon"
 echo "== pmc sq config 5, objective"; bash tools/pmc_sq.sh config5_batch4_objective --config 5 --pmc-workload objective | grep -E "fwd_pk|sg_bwd_recon"
-echo "== config 5"; timeout 900 python bench.py --config 5 --no-cpu-baseline > gpurun_out/bench_config5.txt 2>&1; tail -1 gpurun_out/bench_config5.txt | cut -c1-1800
-echo "== batch sweep"; for b in 5 8 16 32 64; do st=100; wu=300; if [ $b -ge 32 ]; then st=40; wu=80; fi; timeout 300 python bench.py --batch $b --steps $st --warmup $wu --no-cpu-baseline --layer-only 2>&1 | tail -1 | python -c "
+echo "== config 5"; timeout 900 python bench.py --config 5 --no-cpu-baseline > gpurun_out/bench_config5.txt 2> gpurun_out/bench_config5.err; tail -1 gpurun_out/bench_config5.txt | cut -c1-1800
+# the counter records are fresh now: the line of record carries them un-stale (config 5's leg included)
+echo "== bench with the fresh counter records"; cp gpurun_out/traffic.json profiles/traffic.json; cp gpurun_out/sq.json profiles/sq.json; timeout 900 python bench.py > gpurun_out/bench_fresh_records.txt 2> gpurun_out/bench_fresh_records.err; tail -1 gpurun_out/bench_fresh_records.txt | cut -c1-1200
+echo "== wavetrace (schedule + shader clock under load)"; if [ -f inverserenderingofindoorscene_amd/variants/libsgrender_trace.so ]; then timeout 300 ./tools/wavetrace inverserenderingofindoorscene_amd/variants/libsgrender_trace.so 16 > /tmp/trace.txt 2>/dev/null; python tools/wavetrace_report.py /tmp/trace.txt > gpurun_out/wavetrace_report.txt 2>&1; grep -E "^[a-z_0-9]+:|shader clock" gpurun_out/wavetrace_report.txt | cut -c1-200; fi
+echo "== batch sweep"; for b in 5 8 16 32 64; do st=100; wu=300; if [ $b -ge 32 ]; then st=40; wu=80; fi; timeout 300 python bench.py --batch $b --steps $st --warmup $wu --no-cpu-baseline --layer-only --graph-leg 2>/dev/null | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); k=d['kernels']; print('batch $b', d['value'], 'Mpix/s', d['ms_per_step'], 'ms/step  fwd', k['forward (sgr_fused_fwd)']['ms'], 'bwd', k['backward (sgr_fused_bwd_sg)']['ms'], 'with loss', d['config']['Mpix_per_s_with_render_loss'])"; done | tee gpurun_out/bench_batch_sweep.txt
+d=json.loads(sys.stdin.read()); k=d['kernels']; print('batch $b', d['value'], 'Mpix/s', d['ms_per_step'], 'ms/step  fwd', k['forward (sgr_fused_fwd)']['ms'], 'bwd', k['backward (sgr_fused_bwd_sg)']['ms'], 'with loss', d['config']['Mpix_per_s_with_render_loss'], 'with loss, replayed from a HIP graph', d['config']['Mpix_per_s_with_render_loss_graph_replay'])"; done | tee gpurun_out/bench_batch_sweep.txt
 echo "== trainlight example (fused objective + HIP heads | unfused + torch heads)"
 timeout 300 python examples/train_light_synthetic.py --batch 16 --steps 23 2>&1 | tail -1 | tee gpurun_out/trainlight_fused.txt
 timeout 300 python examples/train_light_synthetic.py --batch 16 --steps 23 --unfused --torch-heads 2>&1 | tail -1 | tee gpurun_out/trainlight_unfused.txt
