@@ -240,8 +240,10 @@ def test_shapes_vs_oracle(sgr, shape):
             # floor 2e-4: the cap the full-size tests hold these two gradients to (tests/test_gpu_fullsize.py), not 1e-4 -- a handful of
             # near-singular pixels carry the norm of the normal gradient on a 9 x 13 grid
             assert e_f32 <= max(3.0 * e_kink, 2e-4), (shape, k, "vs the fp32 evaluation, all pixels (clamp kink: fp64 is no arbiter)", e_f32, e_kink)
+            # 3 e_kink, not 2: e_kink is the fp32 ORACLE's error on a couple of hundred pixels -- a proxy for the reference's own, good to a
+            # factor ~1.5 (conftest.oracle_with_noise); with the reference's own e_ref at size the bound is 2 e_ref (fixture g9)
             e_agree = rel_l2(a[agree], r64["g_" + k][agree])
-            assert e_agree <= max(2.0 * e_kink, 2e-4), (shape, k, "vs fp64 where the clamp branches agree", e_agree, e_kink)
+            assert e_agree <= max(3.0 * e_kink, 2e-4), (shape, k, "vs fp64 where the clamp branches agree", e_agree, e_kink)
         else:
             assert e <= (2.0 * noise if k in ("normal", "rough") and noise > 5e-5 else tol2(noise)), (shape, k, e, noise)
 
