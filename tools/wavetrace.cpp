@@ -84,7 +84,7 @@ int main(int argc, char** argv) {
     for (int pm = 1; pm <= 3; pm += 2) {
       char nm[64];
       snprintf(nm, sizeof nm, "obj_fwd_premap%d", pm);
-      run(nm, pm == 3 ? w32 : w64, [&] { return sgr_fused_fwd_recon_p(albedo, normal, rough, axis, lamb, weight, dirs, view, env_gt, seg_small, env_ind, diffuse, spec, mask, coef,
+      run(nm, w32 /* round 5: the half-wave statistics kernel for every 7..24-lobe call */, [&] { return sgr_fused_fwd_recon_p(albedo, normal, rough, axis, lamb, weight, dirs, view, env_gt, seg_small, env_ind, diffuse, spec, mask, coef,
                                                                      parts, wsr, bn, K, R, C, eh, ew, imH, imW, 0.05f, pm, st); });
       snprintf(nm, sizeof nm, "obj_bwd_premap%d", pm);
       run(nm, w32, [&] { return sgr_fused_bwd_recon_p(albedo, normal, rough, axis, lamb, weight, dirs, view, env_gt, mask, coef, (const float*)nullptr, g_d, g_s, g_axis, g_lamb,
