@@ -68,3 +68,40 @@ def test_light_encoder_input_vs_wrapper_fixture(sgr, name):
     out2, _, _ = sgr.light_encoder_input(t["im"], t["albedo_raw"], t["normalPred"], t["roughPred"], t["depth_raw"], size=(100, 150))
     want = torch.nn.functional.interpolate(t["im"], [100, 150], mode="bilinear")
     assert rel_l2(out2[:, :3].cpu(), want.cpu()) < 1e-6
+
+
+def test_cascade_handoff_files_round_trip_through_the_path(sgr, tmp_path):
+    """SURVEY.md 8f rank 4 end to end on the GPU: cascade 0's export (outputBRDFLight.py:246-301) -- the packed raw SG parameters out of
+    `light_heads(need_packed=True)` and the rendered diffuse / specular images -- written as the reference's lzf-HDF5 files
+    (`sgr.write_cascade_handoff`), read back the way cascade 1's loader does (`sgr.read_cascade_handoff`, dataLoader.py:97-105,277-283), split
+    with `unpack_envmaps` and rendered again: the files are lossless, so every tensor and the second render are BIT-identical."""
+    import os
+    bn, K, R, C = 3, 12, 12, 16
+    g = torch.Generator().manual_seed(41)
+    xa, xl, xw = [torch.randn(s, generator=g).cuda() for s in ((bn, 3 * K, R, C), (bn, K, R, C), (bn, 3 * K, R, C))]
+    axis, lamb, weight, packed = sgr.light_heads(xa, xl, xw, need_packed=True)
+    assert tuple(packed.shape) == (bn, 7 * K, R, C)
+    albedo, rough = torch.rand(bn, 3, 2 * R, 2 * C, generator=g).cuda(), (torch.rand(bn, 1, 2 * R, 2 * C, generator=g) * 2 - 1).cuda()
+    n = torch.randn(bn, 3, 2 * R, 2 * C, generator=g)
+    n[:, 2] = n[:, 2].abs() + 0.5
+    normal = (n / n.norm(dim=1, keepdim=True)).cuda()
+    layer = sgr.renderingLayer(imWidth=C, imHeight=R)
+    _, d0, s0 = layer.forwardSG(albedo, normal, rough, axis, lamb, weight, need_env=False)
+    ims = [str(tmp_path / f"scene{i:04d}" / f"im_{i + 1}.hdr") for i in range(bn)]
+    for p in ims:
+        os.makedirs(os.path.dirname(p), exist_ok=True)
+    ind = torch.tensor([1.0, 1.0, 0.0]).reshape(bn, 1, 1, 1).cuda()
+    written = sgr.write_cascade_handoff(packed, d0, s0, ims, envmapsInd=ind)
+    assert len(written) == 3 * bn - 1
+    for i in range(bn):
+        got = sgr.read_cascade_handoff(ims[i])
+        assert torch.equal(torch.from_numpy(got["diffuse"]).cuda(), d0[i]) and torch.equal(torch.from_numpy(got["specular"]).cuda(), s0[i])
+        if i == 2:
+            assert got["env"] is None                      # envmapsInd == 0: no env file (outputBRDFLight.py:292-301)
+            continue
+        env = torch.from_numpy(got["env"]).cuda().unsqueeze(0)
+        assert torch.equal(env[0], packed[i])
+        a1, l1, w1 = sgr.unpack_envmaps(env, K)
+        assert torch.equal(a1[0], axis[i]) and torch.equal(l1[0], lamb[i]) and torch.equal(w1[0], weight[i])
+        _, d1, s1 = layer.forwardSG(albedo[i:i + 1], normal[i:i + 1], rough[i:i + 1], a1.contiguous(), l1.contiguous(), w1.contiguous(), need_env=False)
+        assert torch.equal(d1[0], d0[i]) and torch.equal(s1[0], s0[i])
