@@ -74,3 +74,24 @@ def test_sq_records_imply_physical_clocks():
                 assert r["frac_at_max_clock"] <= r["frac"] + 1e-3, (tag, k)
             n += 1
     assert n >= 10
+
+
+def test_bench_stdout_is_the_json_line_alone():
+    """The contract: rank 0 prints ONE JSON line.  Native libraries write to file descriptor 1 behind Python's back -- RCCL prints a five-line
+    banner when its first communicator is created, buffered, so it lands AFTER the line at exit (seen in the first round-5 run of the
+    RCCL world-of-one leg) -- so bench.py moves descriptor 1 to stderr at start and writes its line to the saved descriptor."""
+    import subprocess
+    import sys
+    code = ("import ctypes, importlib.util, os, sys\n"
+            f"spec = importlib.util.spec_from_file_location('b', os.path.join({ROOT!r}, 'bench.py')); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+            "emit = b._claim_stdout()\n"
+            "libc = ctypes.CDLL(None)\n"
+            "libc.printf(b'native banner, buffered until exit\\n')\n"      # what RCCL does
+            "print('python print after the claim')\n"
+            "os.write(1, b'raw write to fd 1\\n')\n"
+            "emit('{\"metric\": 1}')\n")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-1000:]
+    assert p.stdout == '{"metric": 1}\n', repr(p.stdout)
+    for needle in ("native banner", "python print after the claim", "raw write to fd 1"):
+        assert needle in p.stderr, (needle, p.stderr[-500:])
