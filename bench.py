@@ -103,13 +103,24 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} needs a torchrun launch with WORLD_SIZE={args.gpus} (got {world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render layer has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # SGR_BENCH_BACKEND=gloo (rehearsal only): the N > 1 flow -- barriers, the sharded render loss in the timed step, max over ranks, rank 0's
+    # line -- on a box with fewer GPUs than ranks: ranks share devices and the collectives go through the host.  Such a line says so
+    # (`config.rehearsal`) and is no measurement; the driver's runs use the default, nccl (= RCCL), one GPU per rank.
+    backend = os.environ.get("SGR_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and local_rank >= ndev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible (RCCL needs one GPU per rank)")
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:       # input generation is CPU work: do not oversubscribe the host with world x all-core thread pools
         torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import inverserenderingofindoorscene_amd as pkg
     from inverserenderingofindoorscene_amd import _lib
@@ -376,7 +387,8 @@ def main() -> None:
                        "ms_per_step_light_objective_unfused": None if obj_unfused_ms is None else round(obj_unfused_ms, 4),
                        "ms_per_step_light_objective_forward_only": None if obj_fwd_only_ms is None else round(obj_fwd_only_ms, 4),
                        "config3": cfg3,
-                       "parallelism": f"batch-sharded x{world}"},
+                       "parallelism": f"batch-sharded x{world}",
+                       "rehearsal": None if backend == "nccl" else f"backend {backend}, {ndev} GPU(s) for {world} ranks: the N > 1 flow only, not a measurement"},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(dom[3], 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(dom[3] / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_record_stale": traffic_stale,
                          "algorithmic_bytes_per_launch": dom[2], "avg_launch_ms": round(dom[1], 4),
