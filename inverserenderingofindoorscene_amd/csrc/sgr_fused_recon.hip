@@ -343,7 +343,7 @@ __global__ __launch_bounds__(kWave, OCC) void sg_bwd_recon_pk_kernel(const Args 
       }
     }
   };
-  if (ortho) row_loop(std::true_type{}); else row_loop(std::false_type{});
+  if ((SGR_ABLATE & 64) || ortho) row_loop(std::true_type{}); else row_loop(std::false_type{});      // ablation 64: the degenerate-frame loop compiled out
 
   // loss partial of the tile: sum_p m_p sum_{c,j} (ln x - ln(gt+off))^2   (each group holds its directions' share)
   {

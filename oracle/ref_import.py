@@ -50,7 +50,7 @@ def _to_dtype(obj, dtype):
 
 
 def make_layers(K: int, R: int, C: int, eh: int = 8, ew: int = 16, fov: float = 57, F0: float = 0.05,
-                dtype=torch.float32):
+                dtype=torch.float32, cameraPos=(0, 0, 0)):
     """Reference ``(output2env, renderingLayer)`` on CPU, tables cast to ``dtype``.
 
     With ``dtype=torch.float64`` this is "the reference code run in fp64" that
@@ -58,5 +58,5 @@ def make_layers(K: int, R: int, C: int, eh: int = 8, ew: int = 16, fov: float = 
     """
     m = models()
     o2e = m.output2env(SGNum=K, envWidth=ew, envHeight=eh, isCuda=False)
-    rl = m.renderingLayer(imWidth=C, imHeight=R, fov=fov, F0=F0, envWidth=ew, envHeight=eh, isCuda=False)
+    rl = m.renderingLayer(imWidth=C, imHeight=R, fov=fov, F0=F0, cameraPos=list(cameraPos), envWidth=ew, envHeight=eh, isCuda=False)
     return _to_dtype(o2e, dtype), _to_dtype(rl, dtype)

@@ -11,7 +11,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
-GOLDEN_CASES = ["g1_q4_k12", "g2_q1_k5", "g3_edges"]
+GOLDEN_CASES = ["g1_q4_k12", "g2_q1_k5", "g3_edges", "g10_cam_f0_q4", "g10_cam_f0_q1"]
 
 
 def pytest_configure(config):
@@ -35,7 +35,15 @@ def load_golden(name):
     cfg = {k: v for k, v in zip(z["cfg_keys"].tolist(), z["cfg_vals"].tolist())}
     for k in ("bn", "imH", "imW", "R", "C", "K", "eh", "ew", "seed"):
         cfg[k] = int(cfg[k])
+    # constructor kwarg cameraPos (models.py:408,428-430): g10 moves it off the origin, every other fixture has the default
+    cfg["cam"] = [float(cfg.pop("cam_x", 0.0)), float(cfg.pop("cam_y", 0.0)), float(cfg.pop("cam_z", 0.0))]
     return z, cfg
+
+
+def layer_kwargs(cfg):
+    """Constructor kwargs of renderingLayer for a fixture's configuration -- ALL of the contract's (models.py:408)."""
+    return dict(imWidth=cfg["C"], imHeight=cfg["R"], fov=cfg["fov"], F0=cfg["F0"], cameraPos=cfg.get("cam", [0.0, 0.0, 0.0]),
+                envWidth=cfg["ew"], envHeight=cfg["eh"])
 
 
 def rel_l2(a, b):
@@ -61,14 +69,14 @@ def golden(request):
 NAMES6 = ("albedo", "normal", "rough", "axis", "lamb", "weight")
 
 
-def oracle_fwd_bwd(O, inp, cts, eh, ew, wrt, dtype, device, b=None, fov=57.0, F0=0.05):
+def oracle_fwd_bwd(O, inp, cts, eh, ew, wrt, dtype, device, b=None, fov=57.0, F0=0.05, cam=(0.0, 0.0, 0.0)):
     """``oracle.render_from_sg`` forward + gradients of ``<env,ct_env> + <diffuse,ct_d> + <spec,ct_s>`` w.r.t. ``wrt``,
     evaluated in ``dtype`` on ``device`` -- fp64 ON THE GPU for whole images at BASELINE sizes (the restatement is
     device-generic torch; an image of config 2 takes about a second there instead of twenty on the host).  ``b``: one image of
     the batch.  Returns ``dict(env, diffuse, spec, g_<name>...)`` of detached tensors on ``device``."""
     sl = (lambda t: t) if b is None else (lambda t: t[b:b + 1])
     x = {k: sl(inp[k]).to(device=device, dtype=dtype).clone().requires_grad_(k in wrt) for k in NAMES6}
-    env, d, s = O.render_from_sg(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], eh, ew, fov, F0)
+    env, d, s = O.render_from_sg(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], eh, ew, fov, F0, cam)
     ct = [sl(c).to(device=device, dtype=dtype) for c in cts]
     grads = torch.autograd.grad([env, d, s], [x[k] for k in wrt], grad_outputs=ct)
     out = dict(env=env.detach(), diffuse=d.detach(), spec=s.detach())
@@ -76,13 +84,13 @@ def oracle_fwd_bwd(O, inp, cts, eh, ew, wrt, dtype, device, b=None, fov=57.0, F0
     return out
 
 
-def oracle_with_noise(O, inp, cts, eh, ew, wrt, device, b=None, fov=57.0, F0=0.05):
+def oracle_with_noise(O, inp, cts, eh, ew, wrt, device, b=None, fov=57.0, F0=0.05, cam=(0.0, 0.0, 0.0)):
     """``(ref64, ref32, e32)``: the oracle in fp64 (the arbiter), in fp32, and the rel-L2 distance between the two per output --
     the fp32 rounding noise of the reference's ALGORITHM on these inputs.  Where no reference-made fixture supplies the
     reference's own fp32-vs-fp64 error (g1..g3, g7, g8 do), this is the ``e_ref`` of BASELINE.md section 3's tolerance
     ``max(2 e_ref, 1e-4)``: a restatement's noise, i.e. a proxy -- the two agree to within a factor ~1.5 where both exist."""
-    r64 = oracle_fwd_bwd(O, inp, cts, eh, ew, wrt, torch.float64, device, b, fov, F0)
-    r32 = oracle_fwd_bwd(O, inp, cts, eh, ew, wrt, torch.float32, device, b, fov, F0)
+    r64 = oracle_fwd_bwd(O, inp, cts, eh, ew, wrt, torch.float64, device, b, fov, F0, cam)
+    r32 = oracle_fwd_bwd(O, inp, cts, eh, ew, wrt, torch.float32, device, b, fov, F0, cam)
     e32 = {k: rel_l2(r32[k], r64[k]) for k in r64}
     return r64, r32, e32
 

@@ -27,6 +27,15 @@ def _cases():
         K, eh = ri(1, 24 if ri(0, 2) == 0 else 12), ri(1, 9 if ew == 16 else 16)
         ind = [float(ri(0, 4) > 0) for _ in range(bn)]
         out.append(dict(case=case, bn=bn, R=R, C=C, q=q, K=K, eh=eh, ew=ew, benign=bool(ri(0, 1)), ind=ind))
+    # round 6: the constructor kwargs fov / F0 / cameraPos (models.py:408) vary too; drawn from a SECOND stream so that the thirty
+    # shapes above stay the ones rounds 4-5 ran.  Every third case keeps the reference's defaults.
+    g2 = torch.Generator().manual_seed(20260)
+    ru = lambda lo, hi: round(float(lo + (hi - lo) * torch.rand(1, generator=g2).item()), 4)
+    for c in out:
+        if c["case"] % 3 == 0:
+            c.update(fov=57.0, F0=0.05, cam=[0.0, 0.0, 0.0])
+        else:
+            c.update(fov=ru(35.0, 75.0), F0=ru(0.02, 0.12), cam=[ru(-0.3, 0.3), ru(-0.3, 0.3), ru(-0.3, 0.4)])
     return out
 
 
@@ -41,11 +50,11 @@ def sgr():
     return pkg
 
 
-def _objective_oracle(O, inp, ind, R, C, eh, ew, dtype):
+def _objective_oracle(O, inp, ind, R, C, eh, ew, dtype, fov=57.0, F0=0.05, cam=(0.0, 0.0, 0.0)):
     x = {k: v.to("cuda", dtype) for k, v in inp.items()}
     for k in SG:
         x[k] = x[k].clone().requires_grad_(True)
-    env, d, s = O.render_from_sg(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], eh, ew)
+    env, d, s = O.render_from_sg(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], eh, ew, fov, F0, cam)
     r, _, _, _ = O.render_loss(d, s, x["im"], x["seg"], R, C)
     c, _, _, _ = O.recon_loss(env, x["env_gt"], x["seg"], ind.to("cuda", dtype), R, C)
     g = torch.autograd.grad(r + 10.0 * c, [x[k] for k in SG])
@@ -62,13 +71,14 @@ def test_random_case_vs_oracle(sgr, c):
     x = {k: v.cuda() for k, v in inp.items()}
     for k in SG:
         x[k].requires_grad_(True)
-    layer = sgr.renderingLayer(imWidth=C, imHeight=R, envWidth=ew, envHeight=eh)
+    fov, F0, cam = c["fov"], c["F0"], c["cam"]
+    layer = sgr.renderingLayer(imWidth=C, imHeight=R, fov=fov, F0=F0, cameraPos=cam, envWidth=ew, envHeight=eh)
     # ---- the fused layer: values and SG gradients --------------------------------------------------------------------------------
     env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=True)
     g = torch.Generator().manual_seed(99 + c["case"])
     cts = [torch.randn(env.shape, generator=g), torch.randn(d.shape, generator=g), torch.randn(s.shape, generator=g)]
     grads = torch.autograd.grad([env, d, s], [x[k] for k in SG], grad_outputs=[t.cuda() for t in cts])
-    r64, _, e32 = oracle_with_noise(O, inp, cts, eh, ew, SG, "cuda")
+    r64, _, e32 = oracle_with_noise(O, inp, cts, eh, ew, SG, "cuda", None, fov, F0, cam)
     for k, v in (("env", env), ("diffuse", d), ("spec", s)):
         assert rel_l2(v.detach(), r64[k]) <= tol2(e32[k]), (c, k, rel_l2(v.detach(), r64[k]), e32[k])
     for k, a in zip(SG, grads):
@@ -77,8 +87,8 @@ def test_random_case_vs_oracle(sgr, c):
     # ---- the fused light objective ------------------------------------------------------------------------------------------------
     obj = sgr.light_objective(layer, x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], x["im"], x["seg"], x["env_gt"], ind.cuda(), 1.0, 10.0)
     g_obj = torch.autograd.grad(obj[0], [x[k] for k in SG])
-    ro, co, go = _objective_oracle(O, inp, ind, R, C, eh, ew, torch.float64)
-    r3, c3, g3 = _objective_oracle(O, inp, ind, R, C, eh, ew, torch.float32)
+    ro, co, go = _objective_oracle(O, inp, ind, R, C, eh, ew, torch.float64, fov, F0, cam)
+    r3, c3, g3 = _objective_oracle(O, inp, ind, R, C, eh, ew, torch.float32, fov, F0, cam)
     assert scalar_close(obj[1].item(), ro.item(), r3.item() - ro.item()), (c, "renderErr", obj[1].item(), ro.item(), r3.item())
     assert scalar_close(obj[2].item(), co.item(), c3.item() - co.item()), (c, "reconstErr", obj[2].item(), co.item(), c3.item())
     for k, a, b, b32 in zip(SG, g_obj, go, g3):

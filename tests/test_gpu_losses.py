@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_l2, rel_max, scalar_close
+from conftest import layer_kwargs, rel_l2, rel_max, scalar_close
 
 pytestmark = pytest.mark.gpu
 
@@ -93,7 +93,7 @@ def test_trainlight_objective_grads_vs_golden(sgr, golden):
     x = {k: _t(z, "in_" + k) for k in NAMES}
     for k in ("axis", "lamb", "weight"):
         x[k].requires_grad_(True)
-    layer = sgr.renderingLayer(imWidth=C, imHeight=R, fov=cfg["fov"], F0=cfg["F0"], envWidth=cfg["ew"], envHeight=cfg["eh"])
+    layer = sgr.renderingLayer(**layer_kwargs(cfg))
     env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=True)
     rerr, ren = sgr.render_loss(d, s, _t(z, "in_im"), _t(z, "in_seg"), R, C)
     ind = torch.ones(cfg["bn"], 1, 1, 1, device="cuda")

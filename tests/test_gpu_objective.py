@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_l2, scalar_close
+from conftest import layer_kwargs, rel_l2, scalar_close
 
 pytestmark = pytest.mark.gpu
 
@@ -44,7 +44,7 @@ def test_light_objective_vs_golden(sgr, golden):
     x = {k: _t(z, "in_" + k) for k in NAMES}
     for k in ("axis", "lamb", "weight"):
         x[k].requires_grad_(True)
-    layer = sgr.renderingLayer(imWidth=C, imHeight=R, fov=cfg["fov"], F0=cfg["F0"], envWidth=cfg["ew"], envHeight=cfg["eh"])
+    layer = sgr.renderingLayer(**layer_kwargs(cfg))
     ind = torch.ones(cfg["bn"], 1, 1, 1, device="cuda")
     args = (layer, x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], _t(z, "in_im"), _t(z, "in_seg"),
             _t(z, "in_env_gt"), ind)

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import NAMES6, oracle_fwd_bwd, oracle_with_noise, rel_l2, rel_max, tol2
+from conftest import NAMES6, layer_kwargs, oracle_fwd_bwd, oracle_with_noise, rel_l2, rel_max, tol2
 
 pytestmark = pytest.mark.gpu
 
@@ -80,8 +80,7 @@ def _check_grads(name, z, cfg, grads, which="glin"):
 def test_fused_forward_vs_golden(sgr, golden):
     name, z, cfg = golden
     x = _dev_inputs(z)
-    layer = sgr.renderingLayer(imWidth=cfg["C"], imHeight=cfg["R"], fov=cfg["fov"], F0=cfg["F0"],
-                               envWidth=cfg["ew"], envHeight=cfg["eh"])
+    layer = sgr.renderingLayer(**layer_kwargs(cfg))
     env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=True)
     _check_fwd(name, z, dict(env=env, diffuse=d, spec=s))
     none, d2, s2 = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=False)
@@ -94,8 +93,7 @@ def test_dropin_two_call_forward_vs_golden(sgr, golden):
     name, z, cfg = golden
     x = _dev_inputs(z)
     o2e = sgr.output2env(SGNum=cfg["K"], envWidth=cfg["ew"], envHeight=cfg["eh"])
-    rl = sgr.renderingLayer(imWidth=cfg["C"], imHeight=cfg["R"], fov=cfg["fov"], F0=cfg["F0"],
-                            envWidth=cfg["ew"], envHeight=cfg["eh"])
+    rl = sgr.renderingLayer(**layer_kwargs(cfg))
     env, axis, lam_t, w_t = o2e.output2env(x["axis"], x["lamb"], x["weight"])
     assert axis is x["axis"]
     d, s = rl.forwardEnv(x["albedo"], x["normal"], x["rough"], env)
@@ -106,7 +104,7 @@ def test_dropin_two_call_forward_vs_golden(sgr, golden):
     # the nn.Module aliases route to the same kernels
     env3, _, _, _ = sgr.output_radiance(cfg["K"], cfg["ew"], cfg["eh"])(x["axis"], x["lamb"], x["weight"])
     assert torch.equal(env3, env)
-    d3, s3 = sgr.renderLayer(cfg["C"], cfg["R"], cfg["fov"], cfg["F0"], [0, 0, 0], cfg["ew"], cfg["eh"])(
+    d3, s3 = sgr.renderLayer(cfg["C"], cfg["R"], cfg["fov"], cfg["F0"], cfg["cam"], cfg["ew"], cfg["eh"])(
         x["albedo"], x["normal"], x["rough"], env)
     assert torch.equal(d3, d) and torch.equal(s3, s)
 
@@ -118,8 +116,7 @@ def _cotangents(z):
 def test_fused_backward_vs_golden(sgr, golden):
     name, z, cfg = golden
     x = _dev_inputs(z, grad=NAMES)
-    layer = sgr.renderingLayer(imWidth=cfg["C"], imHeight=cfg["R"], fov=cfg["fov"], F0=cfg["F0"],
-                               envWidth=cfg["ew"], envHeight=cfg["eh"])
+    layer = sgr.renderingLayer(**layer_kwargs(cfg))
     env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=True)
     ce, cd, cs = _cotangents(z)
     lin = (env * ce).sum() + (d * cd).sum() + (s * cs).sum()
@@ -131,8 +128,7 @@ def test_dropin_two_call_backward_vs_golden(sgr, golden):
     name, z, cfg = golden
     x = _dev_inputs(z, grad=NAMES)
     o2e = sgr.output2env(SGNum=cfg["K"], envWidth=cfg["ew"], envHeight=cfg["eh"])
-    rl = sgr.renderingLayer(imWidth=cfg["C"], imHeight=cfg["R"], fov=cfg["fov"], F0=cfg["F0"],
-                            envWidth=cfg["ew"], envHeight=cfg["eh"])
+    rl = sgr.renderingLayer(**layer_kwargs(cfg))
     env, _, _, _ = o2e.output2env(x["axis"], x["lamb"], x["weight"])
     d, s = rl.forwardEnv(x["albedo"], x["normal"], x["rough"], env)
     ce, cd, cs = _cotangents(z)
@@ -145,8 +141,7 @@ def test_brdf_grads_without_env_image(sgr, golden):
     """need_env=False: the BRDF-map adjoint re-evaluates the radiance from the SG lobes (brdf_bwd_pk_sg_kernel on the 8x16 grid)
     instead of reading the env image -- same gradients as the env-given kernel, and against the fixture like it."""
     name, z, cfg = golden
-    layer = sgr.renderingLayer(imWidth=cfg["C"], imHeight=cfg["R"], fov=cfg["fov"], F0=cfg["F0"],
-                               envWidth=cfg["ew"], envHeight=cfg["eh"])
+    layer = sgr.renderingLayer(**layer_kwargs(cfg))
     _, cd, cs = _cotangents(z)
     out = []
     for need_env in (False, True):
@@ -163,8 +158,7 @@ def test_sg_only_grads_like_trainlight(sgr, golden):
     """trainLight mode: only the SG parameters need gradients, no env cotangent."""
     name, z, cfg = golden
     x = _dev_inputs(z, grad=("axis", "lamb", "weight"))
-    layer = sgr.renderingLayer(imWidth=cfg["C"], imHeight=cfg["R"], fov=cfg["fov"], F0=cfg["F0"],
-                               envWidth=cfg["ew"], envHeight=cfg["eh"])
+    layer = sgr.renderingLayer(**layer_kwargs(cfg))
     _, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=False)
     _, cd, cs = _cotangents(z)
     g = torch.autograd.grad((d * cd).sum() + (s * cs).sum(), [x["axis"], x["lamb"], x["weight"]])
@@ -176,7 +170,7 @@ def test_sg_only_grads_like_trainlight(sgr, golden):
         for k in ("axis", "lamb", "weight"):
             xo[k].requires_grad_(True)
         _, do, so = O.render_from_sg(xo["albedo"], xo["normal"], xo["rough"], xo["axis"], xo["lamb"], xo["weight"],
-                                     cfg["eh"], cfg["ew"], cfg["fov"], cfg["F0"])
+                                     cfg["eh"], cfg["ew"], cfg["fov"], cfg["F0"], cfg["cam"])
         return torch.autograd.grad((do * cd.to(dtype)).sum() + (so * cs.to(dtype)).sum(), [xo["axis"], xo["lamb"], xo["weight"]])
 
     go, go32 = oracle(torch.float64), oracle(torch.float32)

@@ -42,7 +42,7 @@ def _forward(emul, z, cfg):
     bn, K, R, C, eh, ew = cfg["bn"], cfg["K"], cfg["R"], cfg["C"], cfg["eh"], cfg["ew"]
     J = eh * ew
     dirs = tables.packed_direction_table(eh, ew)
-    view = tables.view_vectors(C, R, cfg["fov"])
+    view = tables.view_vectors(C, R, cfg["fov"], cfg["cam"])
     env = np.empty((bn, 3, R, C, eh, ew), np.float32)
     d = np.empty((bn, 3, R, C), np.float32)
     s = np.empty((bn, 3, R, C), np.float32)
@@ -65,7 +65,7 @@ def _sep_tables(eh, ew):
     return rows, np.ascontiguousarray(cols.reshape(-1))
 
 
-FAST_CASES = ["g1_q4_k12", "g3_edges"]          # envWidth 16: the separable fast path applies
+FAST_CASES = ["g1_q4_k12", "g3_edges", "g10_cam_f0_q4", "g10_cam_f0_q1"]          # envWidth 16: the separable fast path applies
 
 
 @pytest.mark.parametrize("name", FAST_CASES)
@@ -77,7 +77,7 @@ def test_fast_path_math_vs_golden(emul, name):
     x = _inputs(z)
     bn, K, R, C, eh, ew = cfg["bn"], cfg["K"], cfg["R"], cfg["C"], cfg["eh"], cfg["ew"]
     rows, cols = _sep_tables(eh, ew)
-    view = tables.view_vectors(C, R, cfg["fov"])
+    view = tables.view_vectors(C, R, cfg["fov"], cfg["cam"])
     env = np.empty((bn, 3, R, C, eh, ew), np.float32)
     d = np.empty((bn, 3, R, C), np.float32)
     s = np.empty((bn, 3, R, C), np.float32)
@@ -190,6 +190,28 @@ def test_c_tables_match_numpy():
         got = np.empty_like(want)
         assert lib.sgr_fill_view_vectors(got.ctypes.data, R, C, ctypes.c_float(fov), None) == 0
         assert np.abs(got - want).max() <= 1.2e-7
+    # a camera off the origin (constructor kwarg cameraPos, models.py:408,428-430): the C-side table's camera branch
+    for R, C, fov, cam in [(120, 160, 57.0, (0.1, -0.05, 0.2)), (8, 12, 42.75, (0.1, -0.05, 0.2)), (6, 8, 57.0, (-0.3, 0.25, -0.5))]:
+        want = tables.view_vectors(C, R, fov, cam)
+        assert np.abs(want - tables.view_vectors(C, R, fov)).max() > 1e-2      # the camera does move the table
+        got = np.empty_like(want)
+        cam32 = np.asarray(cam, np.float32)
+        assert lib.sgr_fill_view_vectors(got.ctypes.data, R, C, ctypes.c_float(fov), cam32.ctypes.data) == 0
+        assert np.abs(got - want).max() <= 1.2e-7
+
+
+@pytest.mark.parametrize("name", ["g10_cam_f0_q4", "g10_cam_f0_q1"])
+def test_view_table_with_camera_equals_the_reference_bits(name):
+    """Fixture g10 carries the reference's own `renderingLayer(cameraPos=[0.1,-0.05,0.2], fov=42.75).v` (oracle/make_golden.py: rl_view):
+    the product's host table and the oracle's are the same bits."""
+    from conftest import load_golden
+    from oracle import sg_oracle as O
+    z, cfg = load_golden(name)
+    assert cfg["cam"] == [0.1, -0.05, 0.2] and cfg["F0"] == 0.04
+    ref = z["ref_view"]
+    assert np.array_equal(tables.view_vectors(cfg["C"], cfg["R"], cfg["fov"], cfg["cam"]), ref)
+    assert np.array_equal(O.view_vectors(cfg["C"], cfg["R"], cfg["fov"], cfg["cam"]), ref)
+    assert not np.array_equal(tables.view_vectors(cfg["C"], cfg["R"], cfg["fov"]), ref)
 
 
 # --------------------------------------------------------------------------- #

@@ -14,7 +14,7 @@ NAMES = ("albedo", "normal", "rough", "axis", "lamb", "weight")
 def _run(z, cfg, dtype):
     x = {k: torch.from_numpy(z["in_" + k]).to(dtype).requires_grad_(True) for k in NAMES}
     env, d, s = O.render_from_sg(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"],
-                                 cfg["eh"], cfg["ew"], cfg["fov"], cfg["F0"])
+                                 cfg["eh"], cfg["ew"], cfg["fov"], cfg["F0"], cfg["cam"])
     ct = {k: torch.from_numpy(z[k]).to(dtype) for k in ("ct_env", "ct_d", "ct_s")}
     lin = (env * ct["ct_env"]).sum() + (d * ct["ct_d"]).sum() + (s * ct["ct_s"]).sum()
     g_lin = torch.autograd.grad(lin, [x[k] for k in NAMES], retain_graph=True)

@@ -35,6 +35,9 @@ def test_view_vectors_and_tables_bit_equal():
         _, rl = RI.make_layers(12, R, C, fov=fov)
         v = O.view_vectors(C, R, fov)
         assert np.array_equal(v, rl.v[0].numpy())
+        cam = [0.1, -0.05, 0.2]
+        _, rl = RI.make_layers(12, R, C, fov=fov, cameraPos=cam)
+        assert np.array_equal(O.view_vectors(C, R, fov, cam), rl.v[0].numpy())
     for eh, ew in [(8, 16), (16, 32), (4, 8)]:
         o2e, rl = RI.make_layers(12, 6, 8, eh, ew)
         ls, om = O.direction_table(eh, ew)
