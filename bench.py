@@ -11,34 +11,42 @@ One "step" = one pass of the hot path over one batch of synthetic inputs already
 
 through the package's autograd functions (i.e. through the drop-in boundary, not around it).
 Workload = BASELINE.json configs[1] per GPU: batch 16, 240x320 BRDF maps, 120x160 env grid,
-12 SG lobes, 8x16 directions.  For N > 1 the driver launches one rank per GPU with torchrun;
-images shard across ranks (weak scaling: 16 images per GPU) and the timed step additionally runs the
-render loss (LSregressDiffSpec + masked L2, wrapperBRDFLight.py:170-207) with its only collective --
-the all-reduce of the loss numerator/denominator pair over RCCL -- between
-forward and backward, so the N-GPU number contains the exchange north_star names.  The N = 1 line
-carries the same with-loss step as `config.Mpix_per_s_with_render_loss` for a like-for-like ratio.
+12 SG lobes, 8x16 directions.
+
+N > 1 (round 6: launch-proof).  `python bench.py --gpus N` WITHOUT torchrun re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (one rank per GPU, RCCL); under
+torchrun (the driver's form) it uses the RANK / LOCAL_RANK / WORLD_SIZE it finds.  Images shard across ranks (weak scaling:
+--batch images per GPU, default 16) and the timed step additionally runs the render loss (LSregressDiffSpec + masked L2,
+wrapperBRDFLight.py:170-207) with its only collective -- the all-reduce of the loss numerator / denominator pair over RCCL
+ -- between forward and backward, so the N-GPU number contains the exchange north_star names.
+Like-for-like anchors, flat in `config` at EVERY N: `Mpix_layer_only` (the N = 1 headline's step, no collective) and
+`Mpix_with_loss` (the N > 1 headline's step); the N = 1 line also carries `scaling_anchor_Mpix_per_s` (= its with-loss figure,
+what an N-GPU `value` divides by) and leaves it in `.bench_anchor.json` for the N > 1 runs that follow on the same box.
+N > 1 legs (all ranks): `cfg4_*` = BASELINE configs[3] (8 images per GPU, batch 64 at N = 8), `strong16_*` = 16 images split
+N ways (SURVEY 8d strong scaling), `obj_ms` = the sharded light objective, `n_ranks_seen` = an RCCL all-reduce of ones.
 
 Timing: `--reps` (default 15) repetitions of the K-step loop, each bracketed by barrier + device
-synchronise on both sides and maximised over ranks; the line reports the MEDIAN repetition
-(`ms_per_step`) and lists all of them (`config.ms_per_step_repetitions`).
+synchronise on both sides and maximised over ranks; the line reports the MEDIAN repetition (`ms_per_step`).
 
-Informational legs (single process only; they can never fail the contract line): the cascade-0 light objective fused / unfused
-(`ms_per_step_light_objective_*`), and BASELINE config 3 -- the synthetic trainLight step: decoder-head activations ->
-light objective -> backward -> Adam over the 103 MB of decoder outputs (`config3`: eager, and the whole step replayed from a HIP
-graph with the fused capturable Adam).  Round 2's HIP-graph replay legs of the two- and few-kernel steps are gone: with nothing but
-long kernels in the step there is no launch gap to remove, and a replay pays ~10-40 us of graph-launch latency per step that
-eager launches hide behind the running kernel (driver, round 2: 0.469 vs 0.422 ms).
+THE LINE (round 6): <= 6 KB, `config` holds flat scalars with keys <= 40 characters and strings <= 120 (what the driver's
+record keeps); every nested object of rounds 1-5 (per-kernel rooflines, VALU records, per-mode baselines, repetitions) goes to
+`bench_detail.json` beside this file (`config.detail_file`).  tests/test_bench_contract.py asserts the limits.
+
+Informational legs (single process only; they can never fail the contract line): the cascade-0 light objective fused / unfused /
+forward-only, BASELINE config 3 (the synthetic trainLight step incl. Adam; eager and HIP-graph replay), config 5, RCCL with a
+world of one (c10d route and the extension's in-stream ncclAllReduce), and the COLD column: the layer step and the objective step
+rotating through four input sets (2.4 GB, ten times the 256 MB Infinity Cache) -- what a loader handing over fresh batches sees.
 
 `roofline` is the HBM roofline north_star names (algorithmic bytes / live kernel time); `roofline_valu` is the resource that
 actually binds the fused kernels -- VALU issue -- from the SQ counters of the same workload (profiles/sq.json, tools/pmc_sq.sh).
-
-Rank 0 prints ONE JSON line; see README/DESIGN.md for the field definitions.
 """
 from __future__ import annotations
 
 import argparse
+import datetime
 import json
 import os
+import socket
 import sys
 import time
 
@@ -50,6 +58,10 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+LINE_LIMIT = 6000        # bytes of the contract line (the driver's record keeps an 8.7 KB tail)
+KEY_LIMIT, STR_LIMIT = 40, 120
+DETAIL_FILE = os.environ.get("SGR_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json"))
+ANCHOR_FILE = os.path.join(ROOT, ".bench_anchor.json")
 
 
 def algorithmic_bytes_per_shaded_px(K: int, J: int, q: int) -> dict:
@@ -75,16 +87,16 @@ def _claim_stdout():
     return emit
 
 
-def main() -> None:
-    emit = _claim_stdout()
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=300, help="untimed steps first (0.15 s at config 2: the GPU's clocks ramp up over the first ~100 ms of load)")
-    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
+    ap.add_argument("--batch", "--per-gpu-batch", dest="batch", type=int, default=16, help="images per GPU (weak scaling; BASELINE configs[3] = 8)")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: --batch is the TOTAL, split evenly over the ranks (SURVEY.md 8d config 4: 16 images 2/4/8 ways)")
     ap.add_argument("--reps", type=int, default=15, help="repetitions of the K-step timed loop; the median is reported (fifteen: with a short --warmup the first three repetitions still run on ramping clocks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--layer-only", action="store_true", help="skip the informational legs (two streams, HIP graph, light objective, baselines): profiling runs")
+    ap.add_argument("--layer-only", action="store_true", help="skip the informational legs (light objective, config 3 / 4 / 5, cold column, HIP graph, baselines): profiling and rehearsal runs")
     ap.add_argument("--no-env", action="store_true", help="render-only variant (env image never materialised)")
     ap.add_argument("--graph-leg", action="store_true", help="with --layer-only: still time the with-render-loss step replayed from a HIP graph (sgr.capture_step) -- the batch sweep's launch-bound sizes")
     ap.add_argument("--no-config5", action="store_true", help="skip the compact BASELINE configs[4] leg of the default run")
@@ -94,13 +106,116 @@ def main() -> None:
                          "for --warmup + --steps iterations and print a short record instead of the contract line")
     ap.add_argument("--config", type=int, default=2, choices=(2, 5),
                     help="BASELINE.json configs index: 2 = headline (default); 5 = 480x640, SGNum 24, 16x32 stress (batch 4)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def _free_port() -> int:
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch_command(gpus: int, argv) -> list:
+    """`python bench.py --gpus N ...` outside torchrun -> the driver's own launch form for N > 1 (one rank per GPU, rendezvous on 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args) -> None:
+    """Round 5 raised SystemExit here ("needs a torchrun launch"): the same command the driver uses at N = 1, with --gpus 8, died before
+    touching a GPU.  Now the process BECOMES the torchrun launcher (exec: same stdout, same exit code), after checking that the box has the
+    GPUs -- RCCL needs one per rank; SGR_BENCH_BACKEND=gloo is the flagged rehearsal on fewer."""
+    backend = os.environ.get("SGR_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev == 0:
+        raise SystemExit("bench.py needs a GPU: the render layer has no CPU path")
+    if backend == "nccl" and ndev < args.gpus:
+        raise SystemExit(f"--gpus {args.gpus}: only {ndev} GPU(s) visible and RCCL needs one per rank "
+                         "(SGR_BENCH_BACKEND=gloo rehearses the N > 1 flow on fewer GPUs; such a line is flagged config.rehearsal)")
+    cmd = self_launch_command(args.gpus, sys.argv[1:])
+    print("# bench.py: --gpus %d outside torchrun -> %s" % (args.gpus, " ".join(cmd[1:8])), file=sys.stderr)
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
+def median(v):
+    v = sorted(v)
+    return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+
+
+class Workload:
+    """One rank's batch of synthetic inputs (generated on the CPU, seed offset per rank) and the steps timed on it."""
+
+    def __init__(self, pkg, O, dev, bn, dims, seed, need_env=True, group=None):
+        imH, imW, R, C, K, eh, ew = dims
+        self.pkg, self.dev, self.bn, self.R, self.C, self.need_env, self.group = pkg, dev, bn, R, C, need_env, group
+        inp = O.synthetic_inputs(bn, imH, imW, R, C, K, eh, ew, seed=seed)
+        self.x = {k: v.to(dev) for k, v in inp.items()}
+        for k in ("axis", "lamb", "weight"):
+            self.x[k].requires_grad_(True)
+        g = torch.Generator().manual_seed(99 + seed % 1000)
+        self.ct_env = (torch.randn((bn, 3, R, C, eh, ew), generator=g) * 1e-3).to(dev) if need_env else None
+        self.ct_d = torch.randn((bn, 3, R, C), generator=g).to(dev)
+        self.ct_s = torch.randn((bn, 3, R, C), generator=g).to(dev)
+        self.layer = pkg.renderingLayer(imWidth=C, imHeight=R, envWidth=ew, envHeight=eh)
+        self.ind = torch.ones(bn, 1, 1, 1, device=dev)
+
+    def sg(self, x=None):
+        x = x or self.x
+        return [x["axis"], x["lamb"], x["weight"]]
+
+    def step(self, ev=None, x=None, ct_env=None):
+        """the N = 1 headline: fused forward + fused backward of the layer"""
+        x = x or self.x
+        ct_env = self.ct_env if ct_env is None else ct_env
+        if ev is not None:
+            ev[0].record()
+        env, d, s = self.layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=self.need_env)
+        if ev is not None:
+            ev[1].record()
+        outs, cts = ([env, d, s], [ct_env, self.ct_d, self.ct_s]) if self.need_env else ([d, s], [self.ct_d, self.ct_s])
+        grads = torch.autograd.grad(outs, self.sg(x), grad_outputs=cts)
+        if ev is not None:
+            ev[2].record()
+        return grads
+
+    def step_with_loss(self, group="default"):
+        """the same step with the render loss in the loop (LSregressDiffSpec + masked L2 kernels, wrapperBRDFLight.py:170-207 around the
+        layer); sharded: the all-reduce of [num, den] sits between forward and backward -- the N > 1 headline"""
+        x, group = self.x, (self.group if group == "default" else group)
+        env, d, s = self.layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=self.need_env)
+        err, _ = self.pkg.render_loss(d, s, x["im"], x["seg"], self.R, self.C, group=group)
+        if self.need_env:
+            return torch.autograd.grad([err, env], self.sg(), grad_outputs=[None, self.ct_env])
+        return torch.autograd.grad([err], self.sg())
+
+    def step_objective(self, group="default", x=None):
+        """the cascade-0 light objective (render loss + 10 x env reconstruction loss, wrapperBRDFLight.py:167-207), fused, fwd + bwd"""
+        x, group = x or self.x, (self.group if group == "default" else group)
+        obj = self.pkg.light_objective(self.layer, x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"],
+                                       x["im"], x["seg"], x["env_gt"], self.ind, 1.0, 10.0, group=group)[0]
+        return torch.autograd.grad(obj, self.sg(x))
+
+    def release(self):
+        self.x = self.ct_env = self.ct_d = self.ct_s = None
+
+
+def clip(v, n=STR_LIMIT):
+    return v if not isinstance(v, str) or len(v) <= n else v[:n - 1] + "~"
+
+
+def main() -> None:
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                      # does not return
+    emit = _claim_stdout()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs a torchrun launch with WORLD_SIZE={args.gpus} (got {world})")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or without torchrun: bench.py launches itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render layer has no CPU path")
     # SGR_BENCH_BACKEND=gloo (rehearsal only): the N > 1 flow -- barriers, the sharded render loss in the timed step, max over ranks, rank 0's
@@ -113,14 +228,19 @@ def main() -> None:
     dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    n_ranks_seen = 1
     if world > 1:       # input generation is CPU work: do not oversubscribe the host with world x all-core thread pools
         torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
-    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # a rank that dies leaves the others in a collective: ten minutes, then they fail too instead of holding the box
+        kw = dict(timeout=datetime.timedelta(minutes=10))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, **kw)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, **kw)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                  # the first collective: every rank is there, over the backend the line names
+        n_ranks_seen = int(ones.item())
 
     import inverserenderingofindoorscene_amd as pkg
     from inverserenderingofindoorscene_amd import _lib
@@ -130,73 +250,46 @@ def main() -> None:
     bn, imH, imW, R, C, K, eh, ew = args.batch, 240, 320, 120, 160, 12, 8, 16
     if args.config == 5:      # BASELINE configs[4]: env grid 240x320 assumed
         bn, imH, imW, R, C, K, eh, ew = (4 if args.batch == 16 else args.batch), 480, 640, 240, 320, 24, 16, 32
+    if args.strong:
+        if bn % world:
+            raise SystemExit(f"--strong: {bn} images do not split evenly over {world} ranks")
+        bn //= world
+    dims = (imH, imW, R, C, K, eh, ew)
     J, q = eh * ew, (imH // R) * (imW // C)
     need_env = not args.no_env
+    group = dist.group.WORLD if world > 1 else None
 
     # different images on every rank (seed offset), generated on the CPU like SURVEY 8d prescribes
-    inp = O.synthetic_inputs(bn, imH, imW, R, C, K, eh, ew, seed=20202 + 1000 * rank)
-    x = {k: v.to(dev) for k, v in inp.items()}
-    for k in ("axis", "lamb", "weight"):
-        x[k].requires_grad_(True)
-    g = torch.Generator().manual_seed(99 + rank)
-    ct_env = (torch.randn((bn, 3, R, C, eh, ew), generator=g) * 1e-3).to(dev) if need_env else None
-    ct_d = torch.randn((bn, 3, R, C), generator=g).to(dev)
-    ct_s = torch.randn((bn, 3, R, C), generator=g).to(dev)
-    layer = pkg.renderingLayer(imWidth=C, imHeight=R, envWidth=ew, envHeight=eh)
-
+    wl = Workload(pkg, O, dev, bn, dims, 20202 + 1000 * rank, need_env, group)
+    x, layer = wl.x, wl.layer
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-    group = dist.group.WORLD if world > 1 else None
 
     if args.pmc_workload != "layer":      # counter-collection workload: the objective's kernels alone
         heads = args.pmc_workload == "objective_heads"
-        ind1 = torch.ones(bn, 1, 1, 1, device=dev)
         if heads:
             gh = torch.Generator().manual_seed(7)
             sg = [(torch.randn(s, generator=gh) * 0.5).to(dev).requires_grad_(True) for s in ((bn, 3 * K, R, C), (bn, K, R, C), (bn, 3 * K, R, C))]
         else:
-            sg = [x["axis"], x["lamb"], x["weight"]]
+            sg = wl.sg()
         for _ in range(args.warmup + args.steps):
-            obj = pkg.light_objective(layer, x["albedo"], x["normal"], x["rough"], sg[0], sg[1], sg[2], x["im"], x["seg"], x["env_gt"], ind1, 1.0, 10.0,
+            obj = pkg.light_objective(layer, x["albedo"], x["normal"], x["rough"], sg[0], sg[1], sg[2], x["im"], x["seg"], x["env_gt"], wl.ind, 1.0, 10.0,
                                       decoder_outputs=heads)[0]
             torch.autograd.grad(obj, sg)
         torch.cuda.synchronize()
         emit(json.dumps({"pmc_workload": args.pmc_workload, "config": args.config, "batch": bn, "iterations": args.warmup + args.steps}))
         return
 
-    def step(i=None):
-        if i is not None:
-            ev[i][0].record()
-        env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=need_env)
-        if i is not None:
-            ev[i][1].record()
-        outs, cts = ([env, d, s], [ct_env, ct_d, ct_s]) if need_env else ([d, s], [ct_d, ct_s])
-        grads = torch.autograd.grad(outs, [x["axis"], x["lamb"], x["weight"]], grad_outputs=cts)
-        if i is not None:
-            ev[i][2].record()
-        return grads
-
-    # the same step with the render loss in the loop (LSregressDiffSpec + masked L2 kernels, wrapperBRDFLight.py:170-207
-    # around the layer); sharded: the all-reduce of [num, den] sits between forward and backward
-    def step_with_loss(i=None):
-        env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=need_env)
-        err, _ = pkg.render_loss(d, s, x["im"], x["seg"], R, C, group=group)
-        if need_env:
-            grads = torch.autograd.grad([err, env], [x["axis"], x["lamb"], x["weight"]], grad_outputs=[None, ct_env])
-        else:
-            grads = torch.autograd.grad([err], [x["axis"], x["lamb"], x["weight"]])
-        return grads
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(fn, with_events=False):
-        """EXACTLY args.steps steps between two barrier + synchronise brackets; seconds, max over ranks."""
+    def timed(fn, steps, events=None):
+        """EXACTLY `steps` steps between two barrier + synchronise brackets; seconds, max over ranks."""
         barrier()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            fn(i if with_events else None)
+        for i in range(steps):
+            fn(events[i]) if events is not None else fn()
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -205,125 +298,158 @@ def main() -> None:
             dt = t.item()
         return dt
 
-    def median(v):
-        v = sorted(v)
-        return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
-
     for _ in range(args.warmup):
-        step()
-        step_with_loss()
+        wl.step()
+        wl.step_with_loss()
 
     reps = max(1, args.reps)
     fwd_acc = bwd_acc = 0.0
     plain_dts, loss_dts = [], []
     for _ in range(reps):
-        plain_dts.append(timed(step, with_events=True))
+        plain_dts.append(timed(wl.step, args.steps, ev))
         fwd_acc += sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
         bwd_acc += sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
     for _ in range(reps):
-        loss_dts.append(timed(step_with_loss))
+        loss_dts.append(timed(wl.step_with_loss, args.steps))
     fwd_ms, bwd_ms = fwd_acc / reps, bwd_acc / reps
     plain_ms, loss_step_ms = median(plain_dts) / args.steps * 1e3, median(loss_dts) / args.steps * 1e3
     # the contract line: single GPU = the layer's forward + backward; sharded = the same plus the loss and its all-reduce
     headline_dts = plain_dts if world == 1 else loss_dts
     dt = median(headline_dts)
 
-    # informational: the whole cascade-0 light objective (render loss + 10 x env reconstruction loss,
-    # wrapperBRDFLight.py:167-207) -- fused (env image never written, sgr.light_objective) and unfused.  Single process only:
-    # a leg that failed on one rank would leave the others in its barrier
-    obj_ms = obj_unfused_ms = obj_fwd_only_ms = None
-    cfg3 = None
     # The informational legs keep their own loop lengths: at least 60 timed iterations after 10 untimed ones, whatever --steps / --warmup say.
     # With the driver's `--steps 20 --warmup 5` a 20-iteration loop of a 0.5 ms step is 10 ms -- shorter than the ~100 ms the clocks take
     # to settle after the previous leg -- and read 3-8 % high (config 3: 0.78 vs 0.71 ms on one box).  The headline honours the flags exactly.
     leg_steps, leg_warmup = max(args.steps, 60), 10
-    if world == 1 and need_env and not args.layer_only:
-        ind = torch.ones(bn, 1, 1, 1, device=dev)
 
+    def loop_ms(fn, n=leg_steps, warm=leg_warmup):
+        for _ in range(warm):
+            fn()
+        return timed(fn, n) / n * 1e3
+
+    flat, detail = {}, {}      # flat: scalars for `config` (keys <= 40 chars); detail: everything nested -> bench_detail.json
+    legs = need_env and not args.layer_only and args.config == 2
+
+    # ---- N > 1 legs: every rank takes part, in the same order (a leg that one rank skipped would leave the others in its barrier) ----------
+    if world > 1 and legs:
+        flat["obj_ms"] = round(loop_ms(wl.step_objective), 4)                   # the sharded light objective: 2 all-reduces per step
+        if not args.strong:
+            if bn != 8:      # BASELINE configs[3]: 8 images per GPU (batch 64 at N = 8), render loss + all-reduce in the step
+                w4 = Workload(pkg, O, dev, 8, dims, 24202 + 1000 * rank, True, group)
+                ms = loop_ms(w4.step_with_loss)
+                flat["cfg4_ms"], flat["cfg4_Mpix_per_s"], flat["cfg4_global_batch"] = round(ms, 4), round(world * 8 * imH * imW / (ms * 1e-3) / 1e6, 1), 8 * world
+                w4.release()
+            if 16 % world == 0:      # SURVEY 8d strong scaling: the N = 1 batch of 16 split N ways
+                ws = Workload(pkg, O, dev, 16 // world, dims, 25202 + 1000 * rank, True, group)
+                ms = loop_ms(ws.step_with_loss)
+                flat["strong16_ms"], flat["strong16_Mpix_per_s"] = round(ms, 4), round(16 * imH * imW / (ms * 1e-3) / 1e6, 1)
+                ws.release()
+
+    # ---- single-process informational legs -------------------------------------------------------------------------------------------------
+    cfg3 = cfg5 = rccl1 = None
+    if world == 1 and legs:
         def clear():
             for k in ("axis", "lamb", "weight"):
                 x[k].grad = None
 
-        def step_obj_fused():
-            obj = pkg.light_objective(layer, x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"],
-                                      x["im"], x["seg"], x["env_gt"], ind, 1.0, 10.0)[0]
-            obj.backward()
-            clear()
-
         def step_obj_forward_only():      # evaluation loops (testLight.py drives the same wrapper without a backward): no gradient kernel is launched
             with torch.no_grad():
-                pkg.light_objective(layer, x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], x["im"], x["seg"], x["env_gt"], ind, 1.0, 10.0)
+                pkg.light_objective(layer, x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], x["im"], x["seg"], x["env_gt"], wl.ind, 1.0, 10.0)
 
         def step_obj_unfused():
             env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=True)
             err, _ = pkg.render_loss(d, s, x["im"], x["seg"], R, C)
-            rec = pkg.recon_loss(env, x["env_gt"], x["seg"], ind, R, C)
+            rec = pkg.recon_loss(env, x["env_gt"], x["seg"], wl.ind, R, C)
             (err + 10.0 * rec).backward()
             clear()
 
-        def loop_ms(fn, n):
-            for _ in range(leg_warmup):
-                fn()
-            barrier()
-            t2 = time.perf_counter()
-            for _ in range(n):
-                fn()
-            barrier()
-            return (time.perf_counter() - t2) / n * 1e3
-
         try:
-            obj_ms = loop_ms(step_obj_fused, leg_steps)
-            obj_unfused_ms = loop_ms(step_obj_unfused, leg_steps)
-            obj_fwd_only_ms = loop_ms(step_obj_forward_only, leg_steps)
+            flat["obj_ms"] = round(loop_ms(wl.step_objective), 4)
+            flat["obj_unfused_ms"] = round(loop_ms(step_obj_unfused), 4)
+            flat["obj_fwd_only_ms"] = round(loop_ms(step_obj_forward_only), 4)
         except Exception as exc:       # informational legs: never fail the bench over them
-            obj_ms = obj_unfused_ms = obj_fwd_only_ms = None
             print(f"# light-objective legs skipped: {str(exc)[:160]}", file=sys.stderr)
 
         # BASELINE config 3: the synthetic trainLight cascade-0 step (trainLight.py:203-244 around wrapperBRDFLight.py:158-207):
         # learnable decoder outputs -> output activations (sgr.light_heads) -> light objective -> backward -> Adam
         try:
-            cfg3 = config3_legs(pkg, layer, x, ind, bn, R, C, K, leg_steps, barrier, leg_warmup)
+            cfg3 = config3_legs(pkg, layer, x, wl.ind, bn, R, C, K, leg_steps, barrier, leg_warmup)
         except Exception as exc:
             cfg3 = {"error": str(exc)[:200]}
+        detail["config3"] = cfg3
+        flat["cfg3_ms"] = cfg3.get("ms_per_step_config3")
+        flat["cfg3_ms_graph"] = cfg3.get("ms_per_step_config3_hipgraph")
+        flat["cfg3_ms_standalone_heads"] = cfg3.get("ms_per_step_config3_standalone_heads")
+        for tag, kk in (("obj", "kernels_config3_standalone_heads"), ("cfg3", "kernels_config3")):      # obj_*: the plain objective's kernels; cfg3_*: heads as prologue
+            ks = cfg3.get(kk) or {}
+            for side, name in (("fwd", "objective_forward"), ("bwd", "objective_backward")):
+                r = (ks.get(name) or {}).get("roofline")
+                if r:
+                    flat[f"{tag}_{side}_frac"], flat[f"{tag}_{side}_us"] = r["frac"], round(r["avg_launch_ms"] * 1e3, 1)
+                    if r.get("traffic"):
+                        flat[f"{tag}_{side}_traffic_ratio"] = round(r["traffic"] / r["algorithmic_bytes_per_launch"], 3)
+
+        # BASELINE configs[3] at one rank: 8 images, render loss in the step -- the per-GPU work of the 8-GPU batch of 64
+        try:
+            if bn != 8:
+                w4 = Workload(pkg, O, dev, 8, dims, 24202, True, None)
+                ms = loop_ms(w4.step_with_loss)
+                flat["cfg4_ms"], flat["cfg4_Mpix_per_s"], flat["cfg4_global_batch"] = round(ms, 4), round(8 * imH * imW / (ms * 1e-3) / 1e6, 1), 8
+                w4.release()
+                del w4
+        except Exception as exc:
+            print(f"# config-4 leg skipped: {str(exc)[:160]}", file=sys.stderr)
+
+        # the COLD column: the same two steps rotating through four input sets (4 x 0.6 GB of inputs against 256 MB of Infinity Cache), so that
+        # no step finds its inputs in a cache -- what a data loader handing over a fresh batch every step sees (profiles/r05l_*: forwardEnv
+        # alone loses 45 % cold, the objective's forward 11 %)
+        try:
+            flat.update(cold_legs(wl, leg_steps, loop_ms))
+        except Exception as exc:
+            print(f"# cold legs skipped: {str(exc)[:160]}", file=sys.stderr)
+            torch.cuda.empty_cache()
 
     # informational: the with-render-loss step replayed from a HIP graph (sgr.capture_step): what a launch-bound caller -- the reference's
     # default batch of 5, trainLight.py:28 -- gets by capturing its step
-    graph_loss_ms = None
-    if world == 1 and (args.graph_leg or not args.layer_only):
+    if world == 1 and (args.graph_leg or legs):
         try:
-            captured = pkg.capture_step(step_with_loss)
+            captured = pkg.capture_step(wl.step_with_loss)
             captured.replay()
-            barrier()
-            t2 = time.perf_counter()
-            for _ in range(max(args.steps, 60)):
-                captured.replay()
-            barrier()
-            graph_loss_ms = (time.perf_counter() - t2) / max(args.steps, 60) * 1e3
+            flat["ms_with_loss_graph"] = round(timed(captured.replay, leg_steps) / leg_steps * 1e3, 4)
             del captured
         except Exception as exc:
             print(f"# graph-replay leg skipped: {str(exc)[:160]}", file=sys.stderr)
 
-    # informational, LAST (it creates and destroys a process group): the same with-loss step and the fused objective through RCCL with a
-    # world of one rank -- init_process_group("nccl"), the all-reduces of the device-resident [num, den] vectors between the loss passes
-    # (wrapperBRDFLight.py:192,205-207 under batch sharding) -- so the collectives' latency on the step is a measured number.
-    # N > 1 is the driver's to run.
-    rccl1 = None
-    if world == 1 and need_env and not args.layer_only and args.config == 2:
+    # informational, LAST of the config-2 legs (it creates and destroys a process group): the with-loss step and the fused objective through
+    # RCCL with a world of one rank -- the c10d route (dist.all_reduce between the stage operators) and the extension's in-stream route
+    # (ncclAllReduce enqueued on the current HIP stream by sgrender::allreduce_sum_, no c10d call in the step) -- so the collectives' cost
+    # on the step is a measured number.  N > 1 is the driver's to run.
+    if world == 1 and legs:
         try:
-            rccl1 = rccl_world1_legs(pkg, layer, x, ct_env, R, C, leg_steps, dev)
+            rccl1 = rccl_world1_legs(pkg, wl, leg_steps, dev)
         except Exception as exc:
             rccl1 = {"error": str(exc)[:200]}
+        detail["rccl_world1"] = rccl1
+        for k_out, k_in in (("rccl1_loss_base_ms", "ms_per_step_with_render_loss"), ("rccl1_loss_ms", "ms_per_step_with_render_loss_sharded_world1"),
+                            ("rccl1_loss_native_ms", "ms_per_step_with_render_loss_native_world1"),
+                            ("rccl1_obj_base_ms", "ms_per_step_light_objective"), ("rccl1_obj_ms", "ms_per_step_light_objective_sharded_world1"),
+                            ("rccl1_obj_native_ms", "ms_per_step_light_objective_native_world1")):
+            flat[k_out] = rccl1.get(k_in)
 
-    cfg5 = None
-    if world == 1 and need_env and not args.layer_only and args.config == 2 and not args.no_config5:
+    if world == 1 and legs and not args.no_config5:
         try:
-            for k in list(x):
-                x[k] = None      # config 2's inputs are done with: 1.2 GB back to the allocator before config 5's 6 GB
-            ct_env = None
+            wl.release()      # config 2's inputs are done with: 1.2 GB back to the allocator before config 5's 6 GB
+            x = None
             torch.cuda.empty_cache()
             cfg5 = config5_leg(pkg, dev)
         except Exception as exc:
             cfg5 = {"error": str(exc)[:200]}
+        detail["config5"] = cfg5
+        flat["cfg5_Mpix_per_s"], flat["cfg5_ms"] = cfg5.get("value"), cfg5.get("ms_per_step")
+        for side, name in (("fwd", "forward (sgr_fused_fwd)"), ("bwd", "backward (sgr_fused_bwd_sg)")):
+            r = ((cfg5.get("kernels") or {}).get(name) or {}).get("roofline")
+            if r:
+                flat[f"cfg5_{side}_frac"] = r["frac"]
 
     if rank == 0:
         P = bn * R * C                      # shaded (env-grid) pixels per GPU per step
@@ -346,14 +472,44 @@ def main() -> None:
             dom_name = ("sg_bwd" if dom[0] == "bwd" else "fwd") + " kernel (no PMC record for this workload)"
         # the resource that actually binds the fused kernels: VALU issue.  SQ counters of the same workload (tools/pmc_sq.sh ->
         # profiles/sq.json): SQ_ACTIVE_INST_VALU counts, per SIMD quad, the cycles a VALU instruction is in flight; x 4 / SIMDs
-        # against the kernel's duration in shader-clock cycles is the fraction of issue cycles used.  Round 5: the duration is the
-        # per-shader-engine SQ_BUSY_CYCLES (capped at kernel_ms x 2.4 GHz), not GRBM_GUI_ACTIVE / XCDs, which under the counter mode
-        # also counts the launch's pre- and post-amble and implied clocks above the part's maximum (tools/parse_sq.py).
-        # Both records are OFFLINE (counter passes cannot run inside the timed loop) and stamped with the hash of the kernel sources
-        # they were measured on: a record from other sources is reported as stale and does not decide `limited_by`
+        # against the kernel's duration in shader-clock cycles (per-shader-engine SQ_BUSY_CYCLES, tools/parse_sq.py) is the fraction of
+        # issue cycles used.  Both records are OFFLINE (counter passes cannot run inside the timed loop) and stamped with the hash of
+        # the kernel sources they were measured on: a record from other sources is reported as stale and does not decide `limited_by`
         valu = valu_roofline(tkey, want, dom[1])
         limited_by = limited(valu, dom[3] / HBM_PEAK_GBPS)
         mpix = lambda ms: round(world * img_px / (ms * 1e-3) / 1e6, 1)
+        cfg_idx = 1 if args.config == 2 else 4
+        config = {
+            "workload": clip(f"BASELINE configs[{cfg_idx}]/GPU: {bn}x{imH}x{imW} maps -> {R}x{C} env grid, K={K}, {eh}x{ew} dirs; fused fwd "
+                             f"({'env written' if need_env else 'render only'}) + bwd (SG grads)"),
+            "timed_step": "layer fwd + bwd" if world == 1 else "fwd + render loss (all-reduce [num,den] over RCCL) + bwd",
+            "parallelism": f"batch-sharded x{world}", "n_ranks_seen": n_ranks_seen, "backend": backend if world > 1 else None,
+            "batch_per_gpu": bn, "global_batch": bn * world, "strong": bool(args.strong),
+            "shaded_px_per_step_per_gpu": P, "image_px_per_step_per_gpu": img_px, "q": q,
+            "Mshade_per_s": round(world * P / (dt / args.steps) / 1e6, 1),
+            "repetitions": reps, "statistic": "median repetition of the K-step loop, max over ranks",
+            "ms_layer_only": round(plain_ms, 4), "Mpix_layer_only": mpix(plain_ms),
+            "ms_with_loss": round(loss_step_ms, 4), "Mpix_with_loss": mpix(loss_step_ms),
+            "fwd_us": round(fwd_ms * 1e3, 1), "bwd_us": round(bwd_ms * 1e3, 1),
+            "fwd_frac": round(fwd_gbps / HBM_PEAK_GBPS, 4), "bwd_frac": round(bwd_gbps / HBM_PEAK_GBPS, 4),
+            "legs_timed_iterations": leg_steps, "legs_untimed_iterations": leg_warmup,
+        }
+        # the like-for-like anchor of an N-GPU `value` (whose step carries the render loss): the N = 1 with-loss figure
+        anchor_key = f"cfg{args.config}_b{bn}_{'env' if need_env else 'noenv'}"
+        if world == 1:
+            config["scaling_anchor_Mpix_per_s"] = mpix(loss_step_ms)
+            if not args.strong:
+                _write_anchor(anchor_key, dict(Mpix_with_loss=mpix(loss_step_ms), Mpix_layer_only=mpix(plain_ms), cfg4_Mpix_per_s=flat.get("cfg4_Mpix_per_s"),
+                                               obj_ms=flat.get("obj_ms")))
+        else:
+            a = _read_anchor(f"cfg{args.config}_b{16 if args.strong else bn}_{'env' if need_env else 'noenv'}")
+            config["scaling_anchor_Mpix_per_s"] = a.get("Mpix_with_loss")
+            config["anchor_Mpix_layer_only"] = a.get("Mpix_layer_only")
+            config["anchor_cfg4_Mpix_per_s"] = a.get("cfg4_Mpix_per_s")
+            config["anchor_source"] = a.get("source")
+        config.update({k: v for k, v in flat.items()})
+        config["rehearsal"] = None if backend == "nccl" else clip(f"backend {backend}, {ndev} GPU(s) for {world} ranks: the N > 1 flow only, not a measurement")
+        config["detail_file"] = os.path.basename(DETAIL_FILE)
         out = {
             "metric": "Mpix/s shaded (fwd+bwd), 240x320x12-SG render layer" if args.config == 2 else "Mpix/s shaded (fwd+bwd), 480x640x24-SG 16x32 render layer (stress config)",
             "value": round(value, 1),
@@ -363,87 +519,150 @@ def main() -> None:
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{1 if args.config == 2 else 4}] per GPU: batch {bn} x {imH}x{imW} BRDF maps -> "
-                                   f"{R}x{C} env grid, SGNum={K}, {eh}x{ew} directions; fused fwd "
-                                   f"({'env image written' if need_env else 'render only'}) + fused bwd (SG grads), trainLight mode",
-                       "shaded_px_per_step_per_gpu": P, "image_px_per_step_per_gpu": img_px, "q": q,
-                       "Mshade_per_s": round(world * P / (dt / args.steps) / 1e6, 1),
-                       "timed_step": "fwd + bwd of the layer" if world == 1 else "fwd + render loss (all-reduce of [num, den] over RCCL) + bwd",
-                       "repetitions": reps, "statistic": "median repetition of the K-step loop, max over ranks",
-                       "ms_per_step_repetitions": [round(t / args.steps * 1e3, 4) for t in headline_dts],
-                       "ms_per_step_layer_only": round(plain_ms, 4), "Mpix_per_s_layer_only": mpix(plain_ms),
-                       "ms_per_step_with_render_loss": round(loss_step_ms, 4), "Mpix_per_s_with_render_loss": mpix(loss_step_ms),
-                       "ms_per_step_with_render_loss_graph_replay": None if graph_loss_ms is None else round(graph_loss_ms, 4),
-                       "Mpix_per_s_with_render_loss_graph_replay": None if graph_loss_ms is None else mpix(graph_loss_ms),
-                       "informational_legs": {"timed_iterations": max(args.steps, 60), "untimed_iterations": 10,
-                                              "note": "objective / config-3 / RCCL / graph legs: their own loop lengths, independent of --steps / --warmup (the headline honours the flags exactly)"},
-                       "rccl_world1": rccl1,
-                       "config5": cfg5,
-                       "ms_per_step_light_objective_fused": None if obj_ms is None else round(obj_ms, 4),
-                       "ms_per_step_light_objective_unfused": None if obj_unfused_ms is None else round(obj_unfused_ms, 4),
-                       "ms_per_step_light_objective_forward_only": None if obj_fwd_only_ms is None else round(obj_fwd_only_ms, 4),
-                       "config3": cfg3,
-                       "parallelism": f"batch-sharded x{world}",
-                       "rehearsal": None if backend == "nccl" else f"backend {backend}, {ndev} GPU(s) for {world} ranks: the N > 1 flow only, not a measurement"},
-            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(dom[3], 1), "peak": HBM_PEAK_GBPS,
+            "config": config,
+            "roofline": {"bound": "hbm", "kernel": clip(dom_name, 80), "achieved": round(dom[3], 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(dom[3] / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_record_stale": traffic_stale,
                          "algorithmic_bytes_per_launch": dom[2], "avg_launch_ms": round(dom[1], 4),
                          "limited_by": limited_by},
-            "roofline_valu": valu,
-            "kernels": {"forward (sgr_fused_fwd)": {"ms": round(fwd_ms, 4), "GBps": round(fwd_gbps, 1), "frac": round(fwd_gbps / HBM_PEAK_GBPS, 4),
-                                                       "bytes": fwd_bytes},
-                        "backward (sgr_fused_bwd_sg)": {"ms": round(bwd_ms, 4), "GBps": round(bwd_gbps, 1), "frac": round(bwd_gbps / HBM_PEAK_GBPS, 4),
-                                                           "bytes": bwd_bytes}},
         }
+        if valu is not None:      # compact; the full record (per-wave cycle shares, instruction counts, the source note) -> bench_detail.json
+            out["roofline_valu"] = {k: valu.get(k) for k in ("bound", "kernel", "frac", "frac_at_max_clock", "effective_clock_GHz", "pmc_kernel_ms",
+                                                             "live_kernel_ms", "record", "record_stale")}
+            out["roofline_valu"]["kernel"] = clip(out["roofline_valu"]["kernel"], 80)
+        detail["roofline_valu"] = valu
+        detail["ms_per_step_repetitions"] = [round(t / args.steps * 1e3, 4) for t in headline_dts]
+        detail["ms_layer_only_repetitions"] = [round(t / args.steps * 1e3, 4) for t in plain_dts]
+        detail["ms_with_loss_repetitions"] = [round(t / args.steps * 1e3, 4) for t in loss_dts]
+        detail["kernels"] = {"forward (sgr_fused_fwd)": {"ms": round(fwd_ms, 4), "GBps": round(fwd_gbps, 1), "frac": round(fwd_gbps / HBM_PEAK_GBPS, 4), "bytes": fwd_bytes},
+                             "backward (sgr_fused_bwd_sg)": {"ms": round(bwd_ms, 4), "GBps": round(bwd_gbps, 1), "frac": round(bwd_gbps / HBM_PEAK_GBPS, 4), "bytes": bwd_bytes}}
         if world == 1 and not args.no_cpu_baseline and not args.layer_only and args.config == 2:
-            out["cpu_baseline"] = cpu_baseline(O, 240, 320, 120, 160, 12, 8, 16)
+            cb = cpu_baseline(O, 240, 320, 120, 160, 12, 8, 16)
             # port vs the UNMODIFIED reference on the same cores, measured where the reference exists (the authoring
             # container; oracle/calibrate_port_vs_reference.py -> profiles/cpu_calibration.json)
             try:
-                out["cpu_baseline"]["calibration"] = json.load(open(os.path.join(ROOT, "profiles", "cpu_calibration.json")))
+                cal = json.load(open(os.path.join(ROOT, "profiles", "cpu_calibration.json")))
             except Exception:
-                out["cpu_baseline"]["calibration"] = None
+                cal = None
+            detail["cpu_baseline"] = dict(cb, calibration=cal)
+            ratio = ((cal or {}).get("modes", {}).get("fwd_bwd_sg", {}) or {}).get("broadcast_port_over_reference_speed")
+            out["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                   "sample": clip(cb["sample_short"]), "cpu": clip(cb["cpu"], 60),
+                                   "fwd_only_Mpix_per_s": cb["modes"]["forward_only"]["Mpix_per_s"],
+                                   "all_grads_Mpix_per_s": cb["modes"]["fwd_bwd_all_grads"]["Mpix_per_s"]}
+            if cb["kind"] == "port" and ratio:      # an ESTIMATE: the ratio was measured on the authoring container's CPU, not this one
+                out["cpu_baseline"]["port_over_reference_speed"] = ratio
+                out["cpu_baseline"]["reference_estimate_Mpix_per_s"] = round(cb["value"] / ratio, 4)
             try:
-                out["eager_gpu_baseline"] = eager_gpu_baseline(O, dev, 240, 320, 120, 160, 12, 8, 16)
+                eg = eager_gpu_baseline(O, dev, 240, 320, 120, 160, 12, 8, 16)
+                detail["eager_gpu_baseline"] = eg
+                out["eager_gpu_baseline"] = {"value": eg["value"], "unit": eg["unit"], "kind": eg["kind"]}
             except Exception as exc:       # informational leg: never fail the bench over it
-                out["eager_gpu_baseline"] = {"error": str(exc)[:200]}
-        emit(json.dumps(out))
+                out["eager_gpu_baseline"] = {"error": str(exc)[:120]}
+        detail["line"] = out
+        try:
+            with open(DETAIL_FILE, "w") as fh:
+                json.dump(detail, fh, indent=1)
+        except OSError as exc:
+            print(f"# bench_detail.json not written: {exc}", file=sys.stderr)
+        emit(fit_line(out))
 
     if world > 1:
         dist.destroy_process_group()
 
 
-def rccl_world1_legs(pkg, layer, x, ct_env, R, C, steps, dev) -> dict:
+def fit_line(out: dict) -> str:
+    """The contract line within LINE_LIMIT bytes: None-valued optional `config` keys go first, then the optional top-level objects."""
+    line = json.dumps(out)
+    if len(line) <= LINE_LIMIT:
+        return line
+    cfg = out["config"]
+    for k in [k for k, v in cfg.items() if v is None]:
+        del cfg[k]
+    for k in ("eager_gpu_baseline", "roofline_valu"):
+        if len(json.dumps(out)) <= LINE_LIMIT:
+            break
+        out.pop(k, None)
+    return json.dumps(out)
+
+
+def _write_anchor(key, rec):
+    try:
+        try:
+            allrec = json.load(open(ANCHOR_FILE))
+        except Exception:
+            allrec = {}
+        allrec[key] = dict(rec, host=socket.gethostname(), time=time.time())
+        with open(ANCHOR_FILE, "w") as fh:
+            json.dump(allrec, fh)
+    except OSError:
+        pass
+
+
+def _read_anchor(key) -> dict:
+    """The N = 1 figures an N > 1 line is read against: left by an N = 1 run of this bench on the same host within the last two hours (the
+    driver runs N = 1, 2, 4, 8 back to back); otherwise nothing -- never a figure from another box."""
+    try:
+        rec = json.load(open(ANCHOR_FILE)).get(key)
+        if rec and rec.get("host") == socket.gethostname() and time.time() - rec.get("time", 0) < 7200:
+            return dict(rec, source="N=1 run of this bench on this host, %d s earlier" % int(time.time() - rec["time"]))
+    except Exception:
+        pass
+    return {}
+
+
+def cold_legs(wl, steps, loop_ms, nsets=4) -> dict:
+    """`ms_per_step_cold` / `obj_ms_cold`: the layer step and the fused-objective step with the inputs rotating through `nsets` copies at different
+    addresses (0.6 GB per set for the layer step incl. the env cotangent, 0.6 GB for the objective incl. the ground-truth env), against the warm
+    figure taken back to back with the same loop length."""
+    names = ("albedo", "normal", "rough", "axis", "lamb", "weight", "im", "seg", "env_gt")
+    sets = []
+    for _ in range(nsets):
+        xs = {k: wl.x[k].detach().clone() for k in names}
+        for k in ("axis", "lamb", "weight"):
+            xs[k].requires_grad_(True)
+        sets.append((xs, wl.ct_env.clone()))
+    state = {"i": 0}
+
+    def nxt():
+        state["i"] = (state["i"] + 1) % nsets
+        return sets[state["i"]]
+
+    def layer_cold():
+        xs, ct = nxt()
+        wl.step(None, xs, ct)
+
+    def obj_cold():
+        xs, _ = nxt()
+        wl.step_objective(None, xs)
+
+    out = {}
+    warm = loop_ms(wl.step, steps)
+    out["ms_per_step_cold"], out["ms_per_step_warm_same_loop"] = round(loop_ms(layer_cold, steps), 4), round(warm, 4)
+    warm_o = loop_ms(lambda: wl.step_objective(None), steps)
+    out["obj_ms_cold"], out["obj_ms_warm_same_loop"] = round(loop_ms(obj_cold, steps), 4), round(warm_o, 4)
+    out["cold_input_sets"] = nsets
+    del sets
+    torch.cuda.empty_cache()
+    return out
+
+
+def rccl_world1_legs(pkg, wl, steps, dev) -> dict:
     """The sharded code path over RCCL with ONE rank (single-process bench only): `render_loss(group=WORLD)` between the layer's forward and
-    backward, and `light_objective(group=WORLD)` (three stage operators, two all-reduces) -- against the same steps without a group, timed
-    back to back.  What it measures is the collectives' enqueue + latency on the critical path; the wire (xGMI) is not involved."""
-    import socket
+    backward, and `light_objective(group=WORLD)` (three stage operators, two all-reduces) -- through c10d (`dist.all_reduce`) and through the
+    extension's own communicator (`sgr.enable_native_allreduce`: ncclAllReduce enqueued on the current HIP stream by
+    `torch.ops.sgrender.allreduce_sum_`) -- against the same steps without a group, timed back to back.  What it measures is the collectives'
+    enqueue + latency on the critical path; the wire (xGMI) is not involved."""
     created = False
     if not dist.is_initialized():
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ["MASTER_PORT"] = str(port)
+        os.environ["MASTER_PORT"] = str(_free_port())
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         created = True
     try:
-        sg = [x["axis"], x["lamb"], x["weight"]]
-        ind = torch.ones(x["albedo"].shape[0], 1, 1, 1, device=dev)
-
-        def with_loss(group):
-            env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], sg[0], sg[1], sg[2], need_env=True)
-            err, _ = pkg.render_loss(d, s, x["im"], x["seg"], R, C, group=group)
-            torch.autograd.grad([err, env], sg, grad_outputs=[None, ct_env])
-
-        def objective(group):
-            obj = pkg.light_objective(layer, x["albedo"], x["normal"], x["rough"], sg[0], sg[1], sg[2], x["im"], x["seg"], x["env_gt"], ind, 1.0, 10.0, group=group)[0]
-            torch.autograd.grad(obj, sg)
-
         def loop_ms(fn, group):
             for _ in range(5):
                 fn(group)
@@ -456,15 +675,26 @@ def rccl_world1_legs(pkg, layer, x, ct_env, R, C, steps, dev) -> dict:
 
         W = dist.group.WORLD
         out = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
-        # alternate the two routes so that both see the same clocks
-        a = [loop_ms(with_loss, None), loop_ms(with_loss, W), loop_ms(with_loss, None), loop_ms(with_loss, W)]
-        b = [loop_ms(objective, None), loop_ms(objective, W), loop_ms(objective, None), loop_ms(objective, W)]
+        # alternate the routes so that all see the same clocks
+        a = [loop_ms(wl.step_with_loss, None), loop_ms(wl.step_with_loss, W), loop_ms(wl.step_with_loss, None), loop_ms(wl.step_with_loss, W)]
+        b = [loop_ms(wl.step_objective, None), loop_ms(wl.step_objective, W), loop_ms(wl.step_objective, None), loop_ms(wl.step_objective, W)]
         out["ms_per_step_with_render_loss"] = round(min(a[0], a[2]), 4)
         out["ms_per_step_with_render_loss_sharded_world1"] = round(min(a[1], a[3]), 4)
         out["ms_per_step_light_objective"] = round(min(b[0], b[2]), 4)
         out["ms_per_step_light_objective_sharded_world1"] = round(min(b[1], b[3]), 4)
+        try:      # the in-stream route: same group, the collectives now enqueued by the extension itself
+            pkg.enable_native_allreduce(W)
+            c = [loop_ms(wl.step_with_loss, W), loop_ms(wl.step_with_loss, None), loop_ms(wl.step_with_loss, W)]
+            d = [loop_ms(wl.step_objective, W), loop_ms(wl.step_objective, None), loop_ms(wl.step_objective, W)]
+            out["ms_per_step_with_render_loss_native_world1"] = round(min(c[0], c[2]), 4)
+            out["ms_per_step_light_objective_native_world1"] = round(min(d[0], d[2]), 4)
+            out["ms_per_step_with_render_loss_2"], out["ms_per_step_light_objective_2"] = round(c[1], 4), round(d[1], 4)
+        except Exception as exc:
+            out["native_error"] = str(exc)[:200]
+        finally:
+            pkg.disable_native_allreduce(W)
         out["note"] = ("one rank over the nccl (= RCCL) backend: one all-reduce of [num, den] per render loss, two per light objective, on device tensors; "
-                       "N > 1 has never been timed by the builder (one GPU per box) -- the scaling curve is the driver's")
+                       "'sharded' = through c10d, 'native' = ncclAllReduce on the current stream from the extension")
         return out
     finally:
         if created:
@@ -839,6 +1069,7 @@ def cpu_baseline(O, imH, imW, R, C, K, eh, ew) -> dict:
         pass
     mp = lambda t: round(imH * imW / t / 1e6, 4)
     return {"value": mp(best), "unit": "Mpix/s", "cores": torch.get_num_threads(), "kind": kind,
+            "sample_short": f"1 image (1/16 step) of the workload, fp32, fwd+bwd(SG grads), best of {runs}: {best:.3f} s; kind={kind} (see detail file)",
             "modes": {m: {"Mpix_per_s": mp(res[m][0]), "seconds_per_image": round(res[m][0], 3), "runs": res[m][1]} for m in MODES},
             "sample": f"1 image (1/16 of a step) of the same workload, {what}, best of <= 4 per mode; value = fwd+bwd (SG grads), best of {runs}; {best:.3f} s per image",
             "cpu": model}

@@ -23,7 +23,6 @@
 //   each half evaluates loss, reconstruction and render cotangent for the half row it now holds (6 values)
 //   swap(D = g, S = g):  D = cotangent of half row 1 in all lanes, S = cotangent of half row 0 in all lanes
 // 12 VALU swaps + 6 adds per chunk; no LDS traffic, no barrier, no duplicated transcendental.
-#include <stdlib.h>
 #include <string.h>
 #include "sgr_forward.inl"
 #include "sgr_recon_fold.h"
@@ -78,11 +77,12 @@ template <> __device__ __forceinline__ void wait_vmcnt<3>() { asm volatile("s_wa
 // GRADS = false (round 4): the same pass without its gradient half -- the reconstruction-loss VALUE alone, for forward-only callers
 // of the objective (torch.no_grad(): testLight.py-style evaluation): lobes -> exponentials -> radiance of the azimuth pair -> the
 // log-L2 term.  No shading frame, no cotangents, no accumulators, no all-gather; the first 6 (+3) swaps stay.
-// KPW lobes per lane group (round 5: NG = 4 x KPW = 3 carries the reference's 12 lobes at a quarter of the accumulators per lane -- the
-// review's candidate for more resident waves; see SGR_RECON_K12_NG4 at the launch), OCC = resident waves per SIMD asked of the compiler
-template <int POOL, int EW = 16, int NG = 2, bool HEADS = false, bool GRADS = true, int KPW = 6, int OCC = 2>
-__global__ __launch_bounds__(kWave, OCC) void sg_bwd_recon_pk_kernel(const Args a) {
-  constexpr int HALF = 8, NP = 4, KH = (KPW + 1) / 2, Q = EW / 16, PXW = kWave / NG;       // PXW pixels per wave
+// Six lobes per lane group, two resident waves per SIMD.  (Round 5 carried the lobes per group and the occupancy as template parameters for
+// the NG = 4 x 3-lobe experiment -- measured slower, see fused_bwd_recon_impl -- and left them and an odd-lobe-count path without an
+// instantiation; ADVICE round 5: removed, the record of the experiment is profiles/r05a_* and DESIGN_HISTORY.md.)
+template <int POOL, int EW = 16, int NG = 2, bool HEADS = false, bool GRADS = true>
+__global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a) {
+  constexpr int KPW = 6, HALF = 8, NP = 4, KH = KPW / 2, Q = EW / 16, PXW = kWave / NG;       // PXW pixels per wave
   constexpr int kTile = 3 * PXW * 16;                                           // floats per ground-truth virtual-row tile
   // ground-truth rows: double-buffered one-row tiles, row vr+1 requested while row vr is consumed.  PMC (round 4, profiles/r04b_pmc_traffic_
   // config2_batch16_objective.txt): 826 MB fetched where ~610 MB are read -- a row is one 64-byte half of each 128-byte line, and the other
@@ -598,8 +598,8 @@ static int fused_bwd_recon_impl(const float* albedo, const float* normal, const 
   a.F0 = F0; a.premap = premap;
   const int tiles32 = recon_tiles32(R * C);
   // Round 5, measured and NOT adopted (profiles/r05a_objective_bwd_lane_groups_kbench.txt, r05a_sq_config2_batch16_objective_k12ng4.txt; one box,
-  // three alternations): 7..12 lobes on the 8x16 grid as FOUR lane groups of THREE lobes (sg_bwd_recon_pk_kernel<POOL, 16, 4, HEADS, GRADS, 3, OCC>:
-  // a quarter of the accumulators per lane).  Asked for three waves per SIMD: 168 VGPRs, 56 B of scratch outside the hot loop, 2.78 resident
+  // three alternations): 7..12 lobes on the 8x16 grid as FOUR lane groups of THREE lobes (a quarter of the accumulators per lane; the
+  // template parameters it needed are gone again).  Asked for three waves per SIMD: 168 VGPRs, 56 B of scratch outside the hot loop, 2.78 resident
   // waves per SIMD, VALU-busy 0.92 at 2.05 GHz (1888 busy cycles per SIMD and microsecond against 1544) -- and 356-364 us against 324-328, because
   // the wave now covers 16 pixels: per azimuth pair 213 VALU instructions per 16 pixels against 311 per 32 (+37 %: the microfacet terms and the
   // loss / cotangent of a direction are scalar, one direction per lane group, and the exchange is 18 swaps per 16 pixels instead of 12 per 32).

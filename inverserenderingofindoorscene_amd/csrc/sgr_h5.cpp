@@ -89,16 +89,18 @@ extern "C" size_t sgr_lzf_compress(const void* in_, size_t in_len, void* out_, s
   return op <= out_len ? op : 0;
 }
 
-extern "C" size_t sgr_lzf_decompress(const void* in_, size_t in_len, void* out_, size_t out_len) {
-  const uint8_t* in = static_cast<const uint8_t*>(in_);
-  uint8_t* out = static_cast<uint8_t*>(out_);
+// `*full` (nullable): the OUTPUT buffer was too small -- the one failure a caller may answer by growing it; every other return of 0 is a
+// malformed stream (truncated literal run / back reference, a reference before the start of the output)
+static size_t lzf_decode(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_len, bool* full) {
+  if (full) *full = false;
   if (!in || !out) return 0;
   size_t ip = 0, op = 0;
   while (ip < in_len) {
     const unsigned ctrl = in[ip++];
     if (ctrl < 32) {
       const size_t n = ctrl + 1;
-      if (ip + n > in_len || op + n > out_len) return 0;
+      if (ip + n > in_len) return 0;
+      if (op + n > out_len) { if (full) *full = true; return 0; }
       memcpy(out + op, in + ip, n);
       ip += n;
       op += n;
@@ -111,13 +113,17 @@ extern "C" size_t sgr_lzf_decompress(const void* in_, size_t in_len, void* out_,
       }
       const size_t off = ((size_t)(ctrl & 0x1f) << 8) + in[ip++] + 1;
       len += 2;
-      if (off > op || op + len > out_len) return 0;
+      if (off > op) return 0;
+      if (op + len > out_len) { if (full) *full = true; return 0; }
       const uint8_t* src = out + op - off;
       for (size_t i = 0; i < len; ++i) out[op + i] = src[i];              // byte by byte: the ranges may overlap
       op += len;
     }
   }
   return op;
+}
+extern "C" size_t sgr_lzf_decompress(const void* in_, size_t in_len, void* out_, size_t out_len) {
+  return lzf_decode(static_cast<const uint8_t*>(in_), in_len, static_cast<uint8_t*>(out_), out_len, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
@@ -210,11 +216,16 @@ size_t lzf_filter(unsigned flags, size_t cd_nelmts, const unsigned cd_values[], 
     *buf_size = nbytes;
     return n;
   }
-  size_t out_size = (cd_nelmts >= 3 && cd_values[2] != 0) ? cd_values[2] : *buf_size;
-  for (int attempt = 0; attempt < 32; ++attempt) {
+  // The chunk size travels in cd_values[2] (h5py sets it at creation): ONE attempt into exactly that.  Only a file without it is decoded by
+  // growing the buffer, and only while the decoder says "output full" -- a malformed stream fails at once instead of walking through 32
+  // doublings of malloc (h5py grows on E2BIG alone), and the growth stops at 64x the compressed size's first guess.
+  const bool known = cd_nelmts >= 3 && cd_values[2] != 0;
+  size_t out_size = known ? cd_values[2] : *buf_size;
+  for (int attempt = 0; attempt < (known ? 1 : 7); ++attempt) {
     void* out = malloc(out_size ? out_size : 1);
     if (!out) return 0;
-    const size_t n = sgr_lzf_decompress(*buf, nbytes, out, out_size);
+    bool full = false;
+    const size_t n = lzf_decode(static_cast<const uint8_t*>(*buf), nbytes, static_cast<uint8_t*>(out), out_size, &full);
     if (n) {
       free(*buf);
       *buf = out;
@@ -222,11 +233,14 @@ size_t lzf_filter(unsigned flags, size_t cd_nelmts, const unsigned cd_values[], 
       return n;
     }
     free(out);
-    out_size *= 2;      // a file whose cd_values do not carry the chunk size: grow and retry (h5py does the same on E2BIG)
+    if (!full) return 0;
+    out_size = out_size ? out_size * 2 : 64;
   }
   return 0;
 }
 const H5Z_class2_t kLzfClass = {1, kLzfFilter, 1, 1, "lzf", nullptr, nullptr, lzf_filter};
+
+bool validate(std::string& why);
 
 void load_once() {
   std::vector<std::string> paths;
@@ -234,17 +248,29 @@ void load_once() {
   for (const char* p : {"libhdf5.so", "libhdf5.so.103", "libhdf5.so.200", "libhdf5.so.310", "libhdf5_serial.so", "libhdf5_serial.so.103",
                         "/opt/conda/lib/libhdf5.so.103", "/opt/conda/lib/libhdf5.so", "/usr/lib/x86_64-linux-gnu/hdf5/serial/libhdf5.so"})
     paths.push_back(p);
+  // every candidate is opened AND validated (symbols, version >= 1.10, the *_g globals, the filter): one that fails is closed and the next
+  // is tried -- an old unversioned libhdf5.so of a dev package in front of a good /opt/conda/lib/libhdf5.so.103 no longer ends the search
+  // (ADVICE round 5).  The reason per path goes into `tried`.
   for (const auto& p : paths) {
-    g.lib = dlopen(p.c_str(), RTLD_NOW | RTLD_LOCAL);
     g.tried += (g.tried.empty() ? "" : ", ") + p;
-    if (g.lib) break;
+    void* lib = dlopen(p.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!lib) { g.tried += " (not found)"; continue; }
+    g.lib = lib;
+    std::string why;
+    if (validate(why)) return;
+    g.tried += " (" + why + ")";
+    dlclose(lib);
+    g.lib = nullptr;
   }
-  if (!g.lib) return;
+}
+
+// resolves the API in g.lib and registers the filter; false + reason when this library cannot serve
+bool validate(std::string& why) {
   bool all = true;
 #define SGR_SYM(name)                                                    \
   do {                                                                   \
     g.name = reinterpret_cast<decltype(g.name)>(dlsym(g.lib, #name));    \
-    if (!g.name) { all = false; g.tried += std::string("; missing ") + #name; } \
+    if (!g.name) { all = false; why += std::string(why.empty() ? "" : "; ") + "missing " #name; } \
   } while (0)
   SGR_SYM(H5open); SGR_SYM(H5get_libversion); SGR_SYM(H5Eset_auto2); SGR_SYM(H5Fcreate); SGR_SYM(H5Fopen); SGR_SYM(H5Fclose);
   SGR_SYM(H5Screate_simple); SGR_SYM(H5Sclose); SGR_SYM(H5Sget_simple_extent_ndims); SGR_SYM(H5Sget_simple_extent_dims);
@@ -253,11 +279,12 @@ void load_once() {
   SGR_SYM(H5Dget_space); SGR_SYM(H5Dget_type); SGR_SYM(H5Dget_create_plist); SGR_SYM(H5Tget_class); SGR_SYM(H5Tget_size); SGR_SYM(H5Tclose);
   SGR_SYM(H5Zregister); SGR_SYM(H5Zfilter_avail);
 #undef SGR_SYM
-  if (!all || g.H5open() < 0) return;
+  if (!all) return false;
+  if (g.H5open() < 0) { why = "H5open failed"; return false; }
   g.H5get_libversion(&g.ver[0], &g.ver[1], &g.ver[2]);
   if (g.ver[0] != 1 || g.ver[1] < 10) {      // 64-bit hid_t since 1.10
-    g.tried += "; found HDF5 " + std::to_string(g.ver[0]) + "." + std::to_string(g.ver[1]) + ", need >= 1.10";
-    return;
+    why = "HDF5 " + std::to_string(g.ver[0]) + "." + std::to_string(g.ver[1]) + ", need >= 1.10";
+    return false;
   }
   auto global = [&](const char* name) -> hid_t {
     const hid_t* p = reinterpret_cast<const hid_t*>(dlsym(g.lib, name));
@@ -267,15 +294,16 @@ void load_once() {
   g.ieee_f32le = global("H5T_IEEE_F32LE_g");
   g.dataset_create = global("H5P_CLS_DATASET_CREATE_ID_g");
   if (g.native_float < 0 || g.ieee_f32le < 0 || g.dataset_create < 0) {
-    g.tried += "; HDF5 globals not found";
-    return;
+    why = "HDF5 globals not found";
+    return false;
   }
   g.H5Eset_auto2(0, nullptr, nullptr);      // no error stacks on stderr: failures are reported through return codes
   if (g.H5Zfilter_avail(kLzfFilter) <= 0 && g.H5Zregister(&kLzfClass) < 0) {
-    g.tried += "; H5Zregister(lzf) failed";
-    return;
+    why = "H5Zregister(lzf) failed";
+    return false;
   }
   g_ok = true;
+  return true;
 }
 
 bool ready() {

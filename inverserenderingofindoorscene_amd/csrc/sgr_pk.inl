@@ -115,7 +115,7 @@ __device__ __forceinline__ Pix locate_unit(const Args& a, int u) {
 // what the decoders' clamp produces -- is replaced by the floor: exp2(2^-40 t) is exactly 1, like exp2(0 t).
 template <int KP>
 struct LobesPk {
-  static constexpr int KH = (KP + 1) / 2;      // lobe pairs; an odd KP (round 5: three lobes per lane group) leaves the last pair's second half unused
+  static constexpr int KH = KP / 2;      // lobe pairs (KP is even: load_lobes_pk asserts it)
   f32x2 axy[KP];        // (ax, ay)
   f32x2 w01[KP];        // (w0, w1)
   f32x2 w2p[KH];        // (w2 of lobe 2m, w2 of lobe 2m+1)
@@ -238,7 +238,8 @@ constexpr float kLpFloor = 9.094947017729282e-13f;
 // to 5 % (objective backward) through register allocation alone (measured, round 3).
 template <int KP, bool FOLD, bool HEADS = false>
 __device__ __forceinline__ void load_lobes_pk(const Args& a, int b, unsigned up, bool active, int kg, LobesPk<KP>& P, bool write_tan) {
-  constexpr int KH = (KP + 1) / 2, KE = 2 * KH;      // KE: KP rounded up to whole pairs (the pad slot mirrors lobe KP - 1, never stored)
+  static_assert(KP % 2 == 0, "lobes come in packed pairs: every instantiation carries 6 or 12 per lane group (round 5's odd-count pad slot had none and is gone)");
+  constexpr int KH = KP / 2, KE = KP;
   const int RC = a.R * a.C, K = a.K;
   const float* axis_b = a.axis + (size_t)b * K * 3 * RC;
   const float* lamb_b = a.lamb + (size_t)b * K * RC;
@@ -272,7 +273,6 @@ __device__ __forceinline__ void load_lobes_pk(const Args& a, int b, unsigned up,
     w2[k] = *reinterpret_cast<const float*>(pw + (size_t)RC * 8 + v3);
 #endif
   }
-  if (KE != KP) { ax[KP] = ax[KP - 1]; ay[KP] = ay[KP - 1]; az[KP] = az[KP - 1]; lp[KP] = lp[KP - 1]; w0[KP] = w0[KP - 1]; w1[KP] = w1[KP - 1]; w2[KP] = w2[KP - 1]; }
   if (HEADS) {
 #pragma unroll
     for (int m = 0; m < KH; ++m) {
@@ -325,7 +325,6 @@ __device__ __forceinline__ void load_lobes_pk(const Args& a, int b, unsigned up,
     P.axy[k] = f32x2{ax[k], ay[k]};
     P.w01[k] = f32x2{w0[k], w1[k]};
   }
-  if (KE != KP) { w2[KP] = 0.0f; az[KP] = az[KP - 1]; lp[KP] = lp[KP - 1]; }
 #pragma unroll
   for (int m = 0; m < KH; ++m) {
     P.w2p[m] = f32x2{w2[2 * m], w2[2 * m + 1]};
@@ -338,7 +337,7 @@ __device__ __forceinline__ void fence_lobes(LobesPk<KP>& P) {
 #pragma unroll
   for (int k = 0; k < KP; ++k) { SGR_FENCE2(P.axy[k]); SGR_FENCE2(P.w01[k]); }
 #pragma unroll
-  for (int m = 0; m < (KP + 1) / 2; ++m) SGR_FENCE2(P.w2p[m]);
+  for (int m = 0; m < KP / 2; ++m) SGR_FENCE2(P.w2p[m]);
 }
 
 // Per-pixel and per-(pixel, table row) constants of the orthonormal microfacet path, in pairs (see brdf_ortho_dir)

@@ -28,8 +28,10 @@
 //   lsregress_*_coef   LSregress / LSregressDiffSpec coefficients    models.py:7-21, 23-84
 //   sg_shading, light_albedo_scale, light_encoder_input             utils.py:156-195, testReal.py:421-432, wrapperBRDFLight.py:138-156
 #include <dlfcn.h>
+#include <link.h>
 
 #include <cstdlib>
+#include <cstring>
 #include <deque>
 #include <map>
 #include <mutex>
@@ -43,6 +45,8 @@
 #include <c10/hip/HIPStream.h>
 #include <torch/csrc/autograd/custom_function.h>
 #include <torch/library.h>
+
+#include <rccl/rccl.h>      // declarations only: the functions are resolved from the RCCL PyTorch itself has loaded (rccl() below)
 
 #include "../../include/sgrender.h"
 
@@ -198,18 +202,30 @@ Tensor table(const TableKey& key, const c10::Device& dev, int64_t n, Fill fill) 
   std::lock_guard<std::mutex> lock(g_tables_mutex);
   auto it = g_tables.find(key);
   if (it != g_tables.end()) return it->second;
-  if (key.kind == 1) {
-    if (g_view_order.size() >= kMaxViewTables) {
-      g_tables.erase(g_view_order.front());
-      g_view_order.pop_front();
-    }
-    g_view_order.push_back(key);
-  }
+  // build and upload FIRST: if either throws (out of memory; a first use inside a HIP-graph capture, which fails loudly by design) the
+  // bookkeeping below has not run -- round 5 pushed the key into g_view_order before the upload, so a failed upload left a key without a
+  // table, a retry pushed a duplicate, and the live count drifted below the bound
   Tensor host = at::empty({n}, at::TensorOptions().dtype(at::kFloat));
   fill(host.data_ptr<float>());
   Tensor t = host.to(dev);
+  if (key.kind == 1) {
+    if (g_view_order.size() >= kMaxViewTables) {
+      g_tables.erase(g_view_order.front());      // drops the CACHE's reference only: a captured HIP graph keeps its tables alive through
+      g_view_order.pop_front();                  // cached_tables() (graphs.py: CapturedStep holds what the capture may have read)
+    }
+    g_view_order.push_back(key);
+  }
   g_tables.emplace(key, t);
   return t;
+}
+// every table currently cached (graphs.py): a CapturedStep keeps these references for as long as its graph lives, so that the eviction
+// of a view table from the bounded cache can never free memory a captured launch still reads
+std::vector<Tensor> cached_tables() {
+  std::lock_guard<std::mutex> lock(g_tables_mutex);
+  std::vector<Tensor> out;
+  out.reserve(g_tables.size());
+  for (const auto& kv : g_tables) out.push_back(kv.second);
+  return out;
 }
 // test hook (tests/test_gpu_ops.py): number of cached tables of a kind (0 direction tables, 1 view-vector tables)
 int64_t table_cache_count(int64_t kind) {
@@ -1220,6 +1236,114 @@ void no_cpu_path(const c10::OperatorHandle&, torch::jit::Stack*) { TORCH_CHECK(f
 
 }  // namespace
 
+// ==================================================================================================================
+// in-stream collectives ("optional native variant: ncclAllReduce on the same HIP stream from the extension")
+// ==================================================================================================================
+// The batch-sharded losses couple the ranks through one all-reduce of a handful of floats between two kernels of the step
+// (wrapperBRDFLight.py:192,205-207 under sharding).  Through c10d that is a Python call, ProcessGroupNCCL's bookkeeping and -- at
+// world 1, measured in round 5 -- 9 us per all-reduce on the step.  Here the extension owns an RCCL communicator per process group
+// (bootstrapped once by the host layer: ncclGetUniqueId on rank 0, the 128 bytes broadcast through the existing c10d group) and
+// `allreduce_sum_` enqueues ncclAllReduce on the CURRENT HIP stream: no side stream, no event pair, capturable in a HIP graph.
+// The RCCL used is the one already in the process (PyTorch-ROCm links it): found among the loaded objects, never a second copy.
+struct Rccl {
+  decltype(&::ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&::ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&::ncclAllReduce) AllReduce = nullptr;
+  decltype(&::ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&::ncclGetErrorString) GetErrorString = nullptr;
+  std::string path;
+};
+int find_rccl(struct dl_phdr_info* info, size_t, void* out) {
+  if (info->dlpi_name && std::strstr(info->dlpi_name, "librccl")) {
+    *static_cast<std::string*>(out) = info->dlpi_name;
+    return 1;
+  }
+  return 0;
+}
+const Rccl& rccl() {
+  static const Rccl r = [] {
+    Rccl x;
+    dl_iterate_phdr(&find_rccl, &x.path);
+    TORCH_CHECK(!x.path.empty(), "sgrender: no librccl in this process (PyTorch-ROCm loads it with its distributed backend); the in-stream all-reduce needs it");
+    void* h = dlopen(x.path.c_str(), RTLD_NOW | RTLD_NOLOAD);
+    TORCH_CHECK(h, "sgrender: cannot re-open ", x.path, ": ", dlerror());
+#define SGR_RCCL(name)                                                                \
+  x.name = reinterpret_cast<decltype(x.name)>(dlsym(h, "nccl" #name));                \
+  TORCH_CHECK(x.name, "sgrender: ", x.path, " does not export nccl" #name);
+    SGR_RCCL(GetUniqueId) SGR_RCCL(CommInitRank) SGR_RCCL(AllReduce) SGR_RCCL(CommDestroy) SGR_RCCL(GetErrorString)
+#undef SGR_RCCL
+    return x;
+  }();
+  return r;
+}
+void rccl_ok(ncclResult_t rc, const char* what) { TORCH_CHECK(rc == ncclSuccess, "sgrender: ", what, " failed: ", rccl().GetErrorString(rc)); }
+
+struct CommEntry { ncclComm_t comm; int device, rank, world; };
+std::mutex g_comm_mutex;
+std::map<int64_t, CommEntry> g_comms;
+int64_t g_next_comm = 1;
+
+Tensor comm_unique_id() {
+  static_assert(sizeof(ncclUniqueId) == NCCL_UNIQUE_ID_BYTES, "ncclUniqueId is an opaque byte array");
+  ncclUniqueId id;
+  rccl_ok(rccl().GetUniqueId(&id), "ncclGetUniqueId");
+  Tensor t = at::empty({(int64_t)sizeof(id)}, at::TensorOptions().dtype(at::kByte));
+  std::memcpy(t.data_ptr<uint8_t>(), &id, sizeof(id));
+  return t;
+}
+// collective over the ranks of the communicator being made (ncclCommInitRank synchronises with them); device = this rank's GPU
+int64_t comm_init(const Tensor& uid, int64_t rank, int64_t world, int64_t device) {
+  TORCH_CHECK(uid.device().is_cpu() && uid.scalar_type() == at::kByte && uid.is_contiguous() && uid.numel() == (int64_t)sizeof(ncclUniqueId),
+              "sgrender: comm_init needs the ", sizeof(ncclUniqueId), " bytes of comm_unique_id() as a CPU uint8 tensor");
+  TORCH_CHECK(world >= 1 && rank >= 0 && rank < world, "sgrender: comm_init: rank ", rank, " of ", world);
+  ncclUniqueId id;
+  std::memcpy(&id, uid.const_data_ptr<uint8_t>(), sizeof(id));
+  const c10::DeviceGuard guard(c10::Device(c10::kCUDA, (c10::DeviceIndex)device));
+  ncclComm_t comm = nullptr;
+  rccl_ok(rccl().CommInitRank(&comm, (int)world, id, (int)rank), "ncclCommInitRank");
+  std::lock_guard<std::mutex> lock(g_comm_mutex);
+  const int64_t h = g_next_comm++;
+  g_comms[h] = CommEntry{comm, (int)device, (int)rank, (int)world};
+  return h;
+}
+void comm_destroy(int64_t handle) {
+  CommEntry e{};
+  {
+    std::lock_guard<std::mutex> lock(g_comm_mutex);
+    auto it = g_comms.find(handle);
+    if (it == g_comms.end()) return;
+    e = it->second;
+    g_comms.erase(it);
+  }
+  const c10::DeviceGuard guard(c10::Device(c10::kCUDA, (c10::DeviceIndex)e.device));
+  rccl_ok(rccl().CommDestroy(e.comm), "ncclCommDestroy");
+}
+int64_t comm_world_size(int64_t handle) {
+  std::lock_guard<std::mutex> lock(g_comm_mutex);
+  auto it = g_comms.find(handle);
+  TORCH_CHECK(it != g_comms.end(), "sgrender: unknown communicator handle ", handle);
+  return it->second.world;
+}
+// t <- sum over the ranks of t, enqueued on the current stream of t's device (fp32 / fp64, contiguous)
+void allreduce_sum_cuda(Tensor& t, int64_t handle) {
+  TORCH_CHECK(t.is_cuda() && t.is_contiguous(), "sgrender: allreduce_sum_ needs a contiguous device tensor");
+  TORCH_CHECK(t.scalar_type() == at::kFloat || t.scalar_type() == at::kDouble, "sgrender: allreduce_sum_ needs fp32 or fp64, got ", t.scalar_type());
+  CommEntry e{};
+  {
+    std::lock_guard<std::mutex> lock(g_comm_mutex);
+    auto it = g_comms.find(handle);
+    TORCH_CHECK(it != g_comms.end(), "sgrender: unknown communicator handle ", handle);
+    e = it->second;
+  }
+  TORCH_CHECK(t.device().index() == e.device, "sgrender: allreduce_sum_: the tensor lives on device ", (int)t.device().index(), ", the communicator on ", e.device);
+  if (t.numel() == 0) return;
+  const c10::DeviceGuard guard(t.device());
+  rccl_ok(rccl().AllReduce(t.data_ptr(), t.data_ptr(), (size_t)t.numel(), t.scalar_type() == at::kFloat ? ncclFloat32 : ncclFloat64, ncclSum, e.comm,
+                           (hipStream_t)stream_of(t.device())),
+          "ncclAllReduce");
+}
+void allreduce_sum_meta(Tensor&, int64_t) {}
+
 TORCH_LIBRARY(sgrender, m) {
   m.def("sg_to_env(Tensor axis, Tensor lamb, Tensor weight, int eh, int ew, bool premap, bool want_tan=False) -> (Tensor, Tensor, Tensor)");
   m.def("sg_to_env_bwd(Tensor g_env, Tensor axis, Tensor lamb, Tensor weight, int eh, int ew, int premap) -> (Tensor, Tensor, Tensor)");
@@ -1259,7 +1383,14 @@ TORCH_LIBRARY(sgrender, m) {
   m.def("light_objective_stage3(Tensor render_err, Tensor num_e, Tensor sums, float ren_w, float rec_w, int eh, int ew) -> (Tensor, Tensor)");
   // host-side queries (no tensors, no dispatch key): cached constant tables of a kind (test hook), the objective's workspace size
   m.def("table_cache_count(int kind) -> int", &table_cache_count);
+  m.def("cached_tables() -> Tensor[]", &cached_tables);
   m.def("recon_workspace_floats(int bn, int R, int C) -> int", &recon_workspace_floats);
+  // in-stream collectives: communicator management is host-side (no dispatch key); the all-reduce itself is a device operator
+  m.def("comm_unique_id() -> Tensor", &comm_unique_id);
+  m.def("comm_init(Tensor uid, int rank, int world, int device) -> int", &comm_init);
+  m.def("comm_destroy(int comm) -> ()", &comm_destroy);
+  m.def("comm_world_size(int comm) -> int", &comm_world_size);
+  m.def("allreduce_sum_(Tensor(a!) t, int comm) -> ()");
 }
 
 TORCH_LIBRARY_IMPL(sgrender, CUDA, m) {
@@ -1289,6 +1420,7 @@ TORCH_LIBRARY_IMPL(sgrender, CUDA, m) {
   m.impl("light_objective_stage1", &light_objective_stage1_cuda);
   m.impl("light_objective_stage2", &light_objective_stage2_cuda);
   m.impl("light_objective_stage3", &light_objective_stage3_cuda);
+  m.impl("allreduce_sum_", &allreduce_sum_cuda);
 }
 
 TORCH_LIBRARY_IMPL(sgrender, Meta, m) {
@@ -1318,6 +1450,7 @@ TORCH_LIBRARY_IMPL(sgrender, Meta, m) {
   m.impl("light_objective_stage1", &light_objective_stage1_meta);
   m.impl("light_objective_stage2", &light_objective_stage2_meta);
   m.impl("light_objective_stage3", &light_objective_stage3_meta);
+  m.impl("allreduce_sum_", &allreduce_sum_meta);
 }
 
 TORCH_LIBRARY_IMPL(sgrender, Autograd, m) {
@@ -1337,6 +1470,6 @@ TORCH_LIBRARY_IMPL(sgrender, CPU, m) {
   for (const char* name : {"sg_to_env", "sg_to_env_bwd", "render_env", "render_env_bwd_env", "render_bwd_brdf", "fused_render", "fused_render_bwd_sg", "lsregress_coef",
                            "lsregress_diffspec_coef", "render_loss", "render_loss_bwd", "render_loss_finalize", "recon_loss_parts", "recon_loss_bwd", "light_heads", "light_heads_bwd", "sg_shading",
                            "light_albedo_scale", "light_encoder_input", "rescale_grads_", "attach_grads", "light_objective_fwdbwd", "light_objective",
-                           "light_objective_stage1", "light_objective_stage2", "light_objective_stage3"})
+                           "light_objective_stage1", "light_objective_stage2", "light_objective_stage3", "allreduce_sum_"})
     m.impl(name, torch::CppFunction::makeFromBoxedFunction<&no_cpu_path>());
 }

@@ -43,6 +43,9 @@ class CapturedStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.outputs = fn()
+        # the constant tables the captured launches read live in a bounded cache of the extension (64 view-vector tables, oldest evicted:
+        # testReal.py builds a layer per image size); holding them here keeps their memory alive for as long as this graph can replay
+        self._tables = list(torch.ops.sgrender.cached_tables())
         self.replays = 0
 
     def replay(self):

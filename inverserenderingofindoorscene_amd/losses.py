@@ -28,7 +28,7 @@ from .layers import _prepool, _sg_dims
 _sg = torch.ops.sgrender
 
 __all__ = ["LSregress", "LSregressDiffSpec", "render_loss", "recon_loss", "combine_loss_parts", "light_objective",
-           "light_objective_supported"]
+           "light_objective_supported", "enable_native_allreduce", "disable_native_allreduce", "native_allreduce_enabled"]
 
 
 def _lsregress_diffspec_live(diff, spec, imOrig, diffOrig, specOrig):
@@ -94,6 +94,62 @@ def _sharded(group) -> bool:
     return group is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
 
 
+# --------------------------------------------------------------------------- #
+# the loss collectives: c10d, or the extension's own in-stream RCCL all-reduce   #
+# --------------------------------------------------------------------------- #
+_NATIVE_COMMS = {}      # process group (None = the default group) -> communicator handle of torch.ops.sgrender
+
+
+def _group_key(group):
+    return None if group is None or group is dist.group.WORLD else group
+
+
+def enable_native_allreduce(group=None) -> int:
+    """Give ``group`` (default: the world) an RCCL communicator owned by the extension, so that the loss collectives of
+    :func:`render_loss` / :func:`light_objective` / :func:`combine_loss_parts` on that group are enqueued by
+    ``torch.ops.sgrender.allreduce_sum_`` on the CURRENT HIP stream -- SURVEY.md section 8e's "ncclAllReduce on the same HIP
+    stream from the extension": no c10d call, no side stream, no event pair inside the step.
+
+    COLLECTIVE: every rank of the group calls it once (``ncclCommInitRank`` synchronises the ranks); rank 0's
+    ``ncclGetUniqueId`` travels through the existing c10d group.  RCCL needs one GPU per rank, so this is for the ``nccl``
+    backend only; gloo groups (the CPU tests, the rehearsal mode of bench.py) keep the c10d route.  Idempotent; returns the handle."""
+    key = _group_key(group)
+    if key in _NATIVE_COMMS:
+        return _NATIVE_COMMS[key]
+    if not (dist.is_available() and dist.is_initialized()):
+        raise RuntimeError("sgrender: enable_native_allreduce needs an initialised torch.distributed process group")
+    if dist.get_backend(group) != "nccl":
+        raise RuntimeError("sgrender: the in-stream all-reduce is RCCL's; this group's backend is " + str(dist.get_backend(group)))
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    uid = _sg.comm_unique_id() if rank == 0 else torch.zeros(128, dtype=torch.uint8)
+    wire = uid.to(dev)
+    dist.broadcast(wire, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    handle = int(_sg.comm_init(wire.cpu(), rank, world, dev.index))
+    _NATIVE_COMMS[key] = handle
+    return handle
+
+
+def disable_native_allreduce(group=None) -> None:
+    """Destroy the extension's communicator of ``group`` (before ``dist.destroy_process_group()``); the c10d route takes over."""
+    handle = _NATIVE_COMMS.pop(_group_key(group), None)
+    if handle is not None:
+        _sg.comm_destroy(handle)
+
+
+def native_allreduce_enabled(group=None) -> bool:
+    return _group_key(group) in _NATIVE_COMMS
+
+
+def _allreduce_sum_(t: torch.Tensor, group) -> None:
+    """In place, on the current stream when the group has a native communicator; else ``dist.all_reduce``."""
+    handle = _NATIVE_COMMS.get(_group_key(group))
+    if handle is not None and t.is_cuda:
+        _sg.allreduce_sum_(t, handle)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
 def ddp_loss_scale(group=None) -> float:
     """Factor that makes DistributedDataParallel's gradient AVERAGING reproduce the single-process gradient of the
     batch-global losses of this module (see :func:`combine_loss_parts`): the world size of ``group``; 1.0 when
@@ -119,7 +175,7 @@ def combine_loss_parts(num: torch.Tensor, den_raw: torch.Tensor, group=None, div
     communication hook (tests/test_sharded_loss_gloo.py::test_ddp_gradients_match_single_process)."""
     if _sharded(group):
         pair = torch.stack([num.detach(), den_raw.detach().to(num.dtype)])
-        dist.all_reduce(pair, op=dist.ReduceOp.SUM, group=group)
+        _allreduce_sum_(pair, group)
         num_g, den_g = pair[0], pair[1]
     else:
         num_g, den_g = num.detach(), den_raw.detach()
@@ -143,7 +199,7 @@ def render_loss(diffuse, spec, im, seg, envRow: int, envCol: int, group=None) ->
         # every rank gets the gradient of the global loss w.r.t. its shard).  Five launches + one collective per step, no torch glue.
         with torch.no_grad():
             _, _, parts, rendered, im_s, seg_s, coef = _sg.render_loss(diffuse, spec, im, seg, envRow, envCol, False)
-            dist.all_reduce(parts, op=dist.ReduceOp.SUM, group=group)
+            _allreduce_sum_(parts, group)
         loss, _ = _sg.render_loss_finalize(diffuse, spec, parts, im_s, seg_s, coef)
         return loss, rendered
     # one rank: three launches, the third pass forms the loss value itself; the backward is one more (four small launches per step
@@ -265,12 +321,12 @@ def light_objective(renderLayer, albedoPred, normalPred, roughPred, axisPred, la
     with torch.no_grad():
         diffuse, spec, mask, coef, im_s, seg_s, rendered, coef_ds, sums, ws, lam_t, w_t = _sg.light_objective_stage1(
             a, n, r, axisPred, lambPred, weightPred, im, seg, envmapsBatch, envmapsIndBatch, eh, ew, fov, F0, cam, heads, handoff and need)
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)      # [num_r, den_r, 0, den_e]: one all-reduce before the backward pass
+        _allreduce_sum_(sums, group)      # [num_r, den_r, 0, den_e]: one all-reduce before the backward pass
         render_err, g_axis, g_lamb, g_weight, parts_b = _sg.light_objective_stage2(
             a, n, r, axisPred, lambPred, weightPred, envmapsBatch, mask, coef, diffuse, spec, im_s, seg_s, coef_ds, sums, ws, lam_t, w_t,
             eh, ew, fov, F0, cam, float(renderWeight), float(reconWeight), float(offset), heads, need)
         num_e = parts_b[0:1]
-        dist.all_reduce(num_e, op=dist.ReduceOp.SUM, group=group)     # the second and last collective: the reconstruction numerator
+        _allreduce_sum_(num_e, group)     # the second and last collective: the reconstruction numerator
         objective, recon_err = _sg.light_objective_stage3(render_err, num_e, sums, float(renderWeight), float(reconWeight), eh, ew)
     if need:      # every rank holds the gradient of the GLOBAL objective w.r.t. ITS shard (see combine_loss_parts)
         applied = torch.ones(2, device=objective.device, dtype=torch.float32)

@@ -95,3 +95,93 @@ def test_bench_stdout_is_the_json_line_alone():
     assert p.stdout == '{"metric": 1}\n', repr(p.stdout)
     for needle in ("native banner", "python print after the claim", "raw write to fd 1"):
         assert needle in p.stderr, (needle, p.stderr[-500:])
+
+
+# --------------------------------------------------------------------------- #
+# round 6: the line's size limits, the self-launch, the anchors                 #
+# --------------------------------------------------------------------------- #
+def check_line_limits(line: str, b=None):
+    """What the driver's record keeps of the contract line (Missing 3): an 8.7 KB tail, `parsed.config` without nested
+    objects, keys cut at 40 characters, strings at 120.  bench.py promises <= 6 KB, flat scalar `config`, keys <= 40, strings <= 120."""
+    b = b or _bench()
+    assert "\n" not in line
+    assert len(line.encode()) <= b.LINE_LIMIT, len(line.encode())
+    out = json.loads(line)
+    cfg = out["config"]
+    for k, v in cfg.items():
+        assert len(k) <= b.KEY_LIMIT, k
+        assert v is None or isinstance(v, (bool, int, float, str)), (k, type(v))
+        if isinstance(v, str):
+            assert len(v) <= b.STR_LIMIT, (k, len(v))
+    for obj in ("roofline", "cpu_baseline", "roofline_valu", "eager_gpu_baseline"):
+        for k, v in (out.get(obj) or {}).items():
+            assert len(k) <= b.KEY_LIMIT, (obj, k)
+            assert not isinstance(v, (dict, list)), (obj, k)
+            if isinstance(v, str):
+                assert len(v) <= b.STR_LIMIT, (obj, k, len(v))
+    return out
+
+
+def test_fit_line_trims_to_the_limit_and_clip_marks_the_cut():
+    b = _bench()
+    out = {"metric": "m", "value": 1.0, "config": {"workload": "w", **{f"none_{i}": None for i in range(400)}, "kept": 1.5},
+           "roofline": {"frac": 0.4}, "roofline_valu": {"x": "y" * 100}, "eager_gpu_baseline": {"value": 35.0}}
+    assert len(json.dumps(out)) > b.LINE_LIMIT
+    line = b.fit_line(out)
+    got = check_line_limits(line, b)
+    assert got["config"]["kept"] == 1.5 and got["roofline"]["frac"] == 0.4 and "none_3" not in got["config"]
+    assert b.clip("a" * 200) == "a" * 119 + "~" and b.clip("short") == "short" and b.clip(None) is None and b.clip(3.5) == 3.5
+
+
+def test_flat_config_keys_in_the_source_respect_the_key_limit():
+    """Every key bench.py puts into `flat` / `config` literally: <= 40 characters (the GPU test checks the emitted line itself)."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    keys = set(re.findall(r'flat\[f?"([A-Za-z0-9_{}]+)"\]', src)) | set(re.findall(r'config\["([A-Za-z0-9_]+)"\]', src))
+    i = src.index("        config = {")
+    keys |= set(re.findall(r'"([A-Za-z0-9_]+)":', src[i:src.index("        }\n", i)]))
+    keys |= set(re.findall(r'\(\("((?:rccl1|cfg\d|obj)_[A-Za-z0-9_]+)", "', src)) | set(re.findall(r'\("((?:rccl1|cfg\d|obj)_[A-Za-z0-9_]+)", "ms_per_step', src))
+    assert len(keys) > 40, sorted(keys)
+    for k in keys:
+        assert len(k.replace("{tag}", "cfg3").replace("{side}", "bwd")) <= 40, k
+    for want in ("cfg3_ms", "cfg3_ms_graph", "cfg4_ms", "cfg5_Mpix_per_s", "cfg5_ms", "rccl1_loss_ms", "rccl1_obj_ms", "obj_ms", "strong16_ms", "n_ranks_seen",
+                 "scaling_anchor_Mpix_per_s", "Mpix_with_loss", "Mpix_layer_only"):
+        assert want in keys, want
+    for want in ("ms_per_step_cold", "obj_ms_cold", "cfg5_{side}_frac", "{tag}_{side}_frac", "{tag}_{side}_traffic_ratio"):
+        assert want in src, want
+
+
+def test_self_launch_command_is_the_drivers_form():
+    """`python bench.py --gpus 8 ...` outside torchrun re-executes as `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...` (round 5 raised SystemExit instead)."""
+    import sys
+    b = _bench()
+    cmd = b.self_launch_command(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"])
+    assert cmd[:4] == [sys.executable, "-m", "torch.distributed.run", "--nnodes=1"]
+    assert "--nproc-per-node=8" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 <= int(cmd[cmd.index("--master-port") + 1]) <= 65535
+    k = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[k + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    a = b.parse_args(["--gpus", "4", "--per-gpu-batch", "8", "--strong"])
+    assert a.gpus == 4 and a.batch == 8 and a.strong and b.parse_args([]).batch == 16 and b.parse_args([]).gpus == 1
+
+
+def test_help_goes_to_stdout():
+    """_claim_stdout() ran before argparse, so --help went to stderr."""
+    import subprocess
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "--per-gpu-batch" in p.stdout and "--strong" in p.stdout, (p.stdout[-300:], p.stderr[-300:])
+
+
+def test_anchor_file_round_trip(tmp_path, monkeypatch):
+    b = _bench()
+    monkeypatch.setattr(b, "ANCHOR_FILE", str(tmp_path / "anchor.json"))
+    assert b._read_anchor("cfg2_b16_env") == {}
+    b._write_anchor("cfg2_b16_env", dict(Mpix_with_loss=3050.0, Mpix_layer_only=3200.0))
+    a = b._read_anchor("cfg2_b16_env")
+    assert a["Mpix_with_loss"] == 3050.0 and "this host" in a["source"]
+    assert b._read_anchor("cfg2_b8_env") == {}
+    rec = json.load(open(b.ANCHOR_FILE))
+    rec["cfg2_b16_env"]["host"] = "another-box"
+    json.dump(rec, open(b.ANCHOR_FILE, "w"))
+    assert b._read_anchor("cfg2_b16_env") == {}       # never a figure from another box

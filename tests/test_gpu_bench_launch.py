@@ -1,0 +1,84 @@
+"""GPU: bench.py as the driver starts it ("Next round" items 1 and 3).
+
+* `python bench.py --gpus 2 ...` WITHOUT torchrun must launch itself (round 5 raised SystemExit unless WORLD_SIZE was already set: the
+  driver's N = 1 command form with `--gpus 8` died before touching a GPU).  A test box has one GPU and RCCL wants one per rank, so the
+  N > 1 flow is rehearsed with `SGR_BENCH_BACKEND=gloo` (both ranks on device 0, collectives through the host, the line flagged
+  `config.rehearsal`): barriers, the sharded render loss with its all-reduce inside the timed step, max over ranks, rank 0's ONE line.
+* with the default backend the same command must fail LOUDLY on a one-GPU box (no silent switch to the rehearsal).
+* the contract line of a (shortened) full run stays inside what the driver's record keeps: <= 6 KB, `config` flat with keys <= 40
+  characters and strings <= 120, and carries the config-3 / config-4 / cold / RCCL figures as flat keys; the nested detail goes to the file
+  `config.detail_file` names."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+from test_bench_contract import check_line_limits
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(args, extra_env=None, timeout=850):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):      # as the driver starts it: outside torchrun
+        env.pop(k, None)
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("n", [2, 4])
+def test_bench_launches_itself_for_n_gpus_rehearsal(n, tmp_path):
+    p = _run(["--gpus", str(n), "--steps", "2", "--warmup", "1", "--reps", "1", "--layer-only", "--batch", "2"],
+             {"SGR_BENCH_BACKEND": "gloo", "SGR_BENCH_DETAIL": str(tmp_path / "detail.json")})
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = check_line_limits(lines[0])
+    assert out["n_gpus"] == n and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    cfg = out["config"]
+    assert cfg["rehearsal"] and "gloo" in cfg["rehearsal"]
+    assert cfg["n_ranks_seen"] == n and cfg["batch_per_gpu"] == 2 and cfg["global_batch"] == 2 * n
+    assert "all-reduce" in cfg["timed_step"] and cfg["parallelism"] == f"batch-sharded x{n}"
+    # the headline is the with-loss step; the layer-only step rides along for the like-for-like ratio against the N = 1 headline
+    assert out["ms_per_step"] == cfg["ms_with_loss"] and cfg["ms_layer_only"] > 0
+    assert abs(out["value"] - n * 2 * 240 * 320 / (out["ms_per_step"] * 1e-3) / 1e6) <= 0.06 * out["value"]
+
+
+@pytest.mark.timeout(600)
+def test_bench_n2_over_rccl_refuses_a_one_gpu_box_loudly():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has the GPUs: the driver's scaling run covers it")
+    p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--reps", "1", "--layer-only"])
+    assert p.returncode != 0 and p.stdout.strip() == ""
+    assert "RCCL needs one per rank" in p.stderr and "SGR_BENCH_BACKEND=gloo" in p.stderr
+
+
+@pytest.mark.timeout(900)
+def test_full_line_fits_the_drivers_record(tmp_path):
+    detail = tmp_path / "detail.json"
+    p = _run(["--steps", "3", "--warmup", "3", "--reps", "2", "--no-cpu-baseline", "--no-config5"], {"SGR_BENCH_DETAIL": str(detail)})
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = check_line_limits(lines[0])
+    cfg = out["config"]
+    assert out["n_gpus"] == 1 and cfg["rehearsal"] is None and cfg["n_ranks_seen"] == 1
+    assert cfg["scaling_anchor_Mpix_per_s"] == cfg["Mpix_with_loss"] and out["value"] == cfg["Mpix_layer_only"]
+    for k in ("obj_ms", "obj_unfused_ms", "obj_fwd_only_ms", "cfg3_ms", "cfg3_ms_graph", "cfg3_ms_standalone_heads", "cfg4_ms", "cfg4_Mpix_per_s", "ms_per_step_cold",
+              "ms_per_step_warm_same_loop", "obj_ms_cold", "obj_ms_warm_same_loop", "ms_with_loss_graph", "rccl1_loss_ms", "rccl1_loss_native_ms", "rccl1_obj_ms",
+              "rccl1_obj_native_ms", "obj_fwd_frac", "obj_bwd_frac", "cfg3_bwd_frac", "fwd_frac", "bwd_frac"):
+        assert isinstance(cfg.get(k), (int, float)) and cfg[k] > 0, (k, cfg.get(k))
+    assert out["roofline"]["frac"] == max(cfg["fwd_frac"], cfg["bwd_frac"]) or out["roofline"]["frac"] in (cfg["fwd_frac"], cfg["bwd_frac"])
+    # cold steps are not faster than warm ones beyond noise, and the objective stays within 25 % of warm (profiles/r05l: 11 % on its forward)
+    assert cfg["ms_per_step_cold"] >= 0.97 * cfg["ms_per_step_warm_same_loop"]
+    assert cfg["obj_ms_cold"] <= 1.25 * cfg["obj_ms_warm_same_loop"]
+    d = json.load(open(detail))
+    assert cfg["detail_file"] == "detail.json" and d["line"]["value"] == out["value"]
+    for k in ("config3", "rccl_world1", "kernels", "ms_per_step_repetitions"):
+        assert k in d, k
+    assert "native_error" not in d["rccl_world1"], d["rccl_world1"]

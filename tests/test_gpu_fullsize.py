@@ -107,8 +107,10 @@ def test_one_image_vs_reference_fixture(sgr, g7):
     # that is larger: on this image the reference's fp32 specular term is 2.7e-4 off its fp64 one in the max norm, the kernel 6e-5
     for k, v in (("diffuse", d), ("spec", s)):
         own = rel_max(z["ref32_" + k], z["ref64_" + k])
+        # the widened bound belongs to the fp32 comparison ALONE (a distance between two fp32 evaluations, each `own` from the
+        # truth); against the reference's fp64 run SURVEY 8c's 2e-4 stands as written -- the kernel is at ~6e-5 there
         assert rel_max(v.cpu(), z["ref32_" + k]) <= max(2e-4, 2.0 * own), (k, rel_max(v.cpu(), z["ref32_" + k]), own)
-        assert rel_max(v.cpu(), z["ref64_" + k]) <= max(2e-4, 2.0 * own), (k, rel_max(v.cpu(), z["ref64_" + k]), own)
+        assert rel_max(v.cpu(), z["ref64_" + k]) <= 2e-4, (k, rel_max(v.cpu(), z["ref64_" + k]), own)
     assert abs(env.double().norm().item() - float(z["ref32_env_norm"][0])) < 1e-5 * float(z["ref32_env_norm"][0])
     for k in SG:
         n = float(z[f"ref32_glin_{k}_norm"][0])

@@ -9,6 +9,9 @@ output and EVERY GRADIENT must be BIT-identical to the unsharded call's -- and a
 term and the weighted sum) may differ by one rounding: the one-rank operator folds the batch totals and the scalar tail in one kernel, the
 staged route in a stage operator's fold plus the finalize operator (1.1e-7 relative on two images of config 2, 0 on the small cases): held to
 2e-7.  Runs in a subprocess: a process group must not outlive the test in the pytest process.
+Round 6: the same again with the extension's OWN communicator (``sgr.enable_native_allreduce``: ``ncclGetUniqueId`` / ``ncclCommInitRank`` from
+libsgrender_torch.so, ``ncclAllReduce`` enqueued on the current HIP stream by ``torch.ops.sgrender.allreduce_sum_``; SURVEY.md 8e's native
+variant) -- ``dist.all_reduce`` is replaced by a function that raises while that route runs, and the results are held to the same bits.
 tests/test_gpu_sharded.py covers world size 2 (gloo, host copies); N > 1 over RCCL has never been run -- it is the driver's."""
 import json
 import os
@@ -46,7 +49,19 @@ for case, (bn, imH, imW, R, C, K, eh, ew, heads) in {"k12_8x16": (3, 24, 32, 12,
     sg = [x[k].requires_grad_(True) for k in ("axis", "lamb", "weight")]
     layer = sgr.renderingLayer(imWidth=C, imHeight=R, envWidth=ew, envHeight=eh)
     res = {}
-    for tag, group in (("plain", None), ("rccl", dist.group.WORLD)):
+    for tag, group in (("plain", None), ("rccl", dist.group.WORLD), ("native", dist.group.WORLD)):
+        if tag == "native":      # round 6: the extension's own communicator -- ncclAllReduce enqueued on the current stream by
+            # torch.ops.sgrender.allreduce_sum_; c10d's all_reduce must not be reached any more
+            handle = sgr.enable_native_allreduce(dist.group.WORLD)
+            assert sgr.native_allreduce_enabled(dist.group.WORLD) and sgr.enable_native_allreduce(None) == handle
+            assert torch.ops.sgrender.comm_world_size(handle) == 1
+            probe = torch.tensor([1.5, -2.0, 3.25], device=dev); probe64 = probe.double()
+            torch.ops.sgrender.allreduce_sum_(probe, handle); torch.ops.sgrender.allreduce_sum_(probe64, handle)
+            assert probe.tolist() == [1.5, -2.0, 3.25] and probe64.tolist() == [1.5, -2.0, 3.25]
+            c10d_all_reduce = dist.all_reduce
+            def _refuse(*a, **k):
+                raise AssertionError("dist.all_reduce reached although the group has a native communicator")
+            dist.all_reduce = _refuse
         if heads:
             a, l, w, _ = sgr.light_heads(*sg)
         else:
@@ -62,24 +77,29 @@ for case, (bn, imH, imW, R, C, K, eh, ew, heads) in {"k12_8x16": (3, 24, 32, 12,
                                          group=group, decoder_outputs=heads)
         torch.cuda.synchronize()
         res[tag] = dict(err=err, rendered=rendered, g_loss=g_loss, obj=obj, g_obj=g_obj, obj_ng=obj_ng)
-    p, r = res["plain"], res["rccl"]
-    rec = {}
-    rec["render_err_equal"] = bool(torch.equal(p["err"], r["err"]))
-    rec["rendered_equal"] = bool(torch.equal(p["rendered"], r["rendered"]))
-    rec["render_grads_equal"] = all(bool(torch.equal(a_, b_)) for a_, b_ in zip(p["g_loss"], r["g_loss"]))
-    rec["obj_render_err_equal"] = bool(torch.equal(p["obj"][1], r["obj"][1]))
-    rec["obj_rendered_equal"] = bool(torch.equal(p["obj"][3], r["obj"][3])) and bool(torch.equal(p["obj"][4], r["obj"][4]))
-    rec["obj_grads_equal"] = all(bool(torch.equal(a_, b_)) for a_, b_ in zip(p["g_obj"], r["g_obj"]))
-    relt = lambda a_, b_: float((a_.double() - b_.double()).norm() / b_.double().norm().clamp_min(1e-300))
-    rec["render_grads_rel"] = max(relt(a_, b_) for a_, b_ in zip(r["g_loss"], p["g_loss"]))
-    rec["obj_grads_rel"] = max(relt(a_, b_) for a_, b_ in zip(r["g_obj"], p["g_obj"]))
-    rec["rendered_rel"] = max(relt(r["rendered"], p["rendered"]), relt(r["obj"][3], p["obj"][3]), relt(r["obj"][4], p["obj"][4]))
-    rec["render_err_rel"] = max(abs(float(r["err"]) - float(p["err"])) / abs(float(p["err"])), abs(float(r["obj"][1]) - float(p["obj"][1])) / abs(float(p["obj"][1])))
-    rec["obj_grads_finite_nonzero"] = all(bool(torch.isfinite(t).all()) and float(t.abs().max()) > 0 for t in r["g_obj"])
-    rel = lambda a_, b_: abs(float(a_) - float(b_)) / max(abs(float(b_)), 1e-30)
-    rec["obj_rel"] = rel(r["obj"][0], p["obj"][0]); rec["recon_rel"] = rel(r["obj"][2], p["obj"][2])
-    rec["obj_ng_rel"] = rel(r["obj_ng"][0], p["obj_ng"][0]); rec["obj_ng_vs_grad_rel"] = rel(r["obj_ng"][0], r["obj"][0])
-    out[case] = rec
+        if tag == "native":
+            dist.all_reduce = c10d_all_reduce
+            sgr.disable_native_allreduce(dist.group.WORLD)
+            assert not sgr.native_allreduce_enabled(None)
+    for route in ("rccl", "native"):
+        p, r = res["plain"], res[route]
+        rec = {}
+        rec["render_err_equal"] = bool(torch.equal(p["err"], r["err"]))
+        rec["rendered_equal"] = bool(torch.equal(p["rendered"], r["rendered"]))
+        rec["render_grads_equal"] = all(bool(torch.equal(a_, b_)) for a_, b_ in zip(p["g_loss"], r["g_loss"]))
+        rec["obj_render_err_equal"] = bool(torch.equal(p["obj"][1], r["obj"][1]))
+        rec["obj_rendered_equal"] = bool(torch.equal(p["obj"][3], r["obj"][3])) and bool(torch.equal(p["obj"][4], r["obj"][4]))
+        rec["obj_grads_equal"] = all(bool(torch.equal(a_, b_)) for a_, b_ in zip(p["g_obj"], r["g_obj"]))
+        relt = lambda a_, b_: float((a_.double() - b_.double()).norm() / b_.double().norm().clamp_min(1e-300))
+        rec["render_grads_rel"] = max(relt(a_, b_) for a_, b_ in zip(r["g_loss"], p["g_loss"]))
+        rec["obj_grads_rel"] = max(relt(a_, b_) for a_, b_ in zip(r["g_obj"], p["g_obj"]))
+        rec["rendered_rel"] = max(relt(r["rendered"], p["rendered"]), relt(r["obj"][3], p["obj"][3]), relt(r["obj"][4], p["obj"][4]))
+        rec["render_err_rel"] = max(abs(float(r["err"]) - float(p["err"])) / abs(float(p["err"])), abs(float(r["obj"][1]) - float(p["obj"][1])) / abs(float(p["obj"][1])))
+        rec["obj_grads_finite_nonzero"] = all(bool(torch.isfinite(t).all()) and float(t.abs().max()) > 0 for t in r["g_obj"])
+        rel = lambda a_, b_: abs(float(a_) - float(b_)) / max(abs(float(b_)), 1e-30)
+        rec["obj_rel"] = rel(r["obj"][0], p["obj"][0]); rec["recon_rel"] = rel(r["obj"][2], p["obj"][2])
+        rec["obj_ng_rel"] = rel(r["obj_ng"][0], p["obj_ng"][0]); rec["obj_ng_vs_grad_rel"] = rel(r["obj_ng"][0], r["obj"][0])
+        out[case + "/" + route] = rec
 dist.barrier()
 dist.destroy_process_group()
 print("RESULT " + json.dumps(out))
@@ -100,7 +120,7 @@ def test_render_loss_and_light_objective_through_rccl_world_of_one():
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")]
     assert line, p.stdout[-2000:]
     out = json.loads(line[-1][7:])
-    assert len(out) == 4
+    assert len(out) == 8 and sum(k.endswith("/native") for k in out) == 4
     print(json.dumps(out))
     for case, rec in out.items():
         assert rec["obj_grads_finite_nonzero"] is True, (case, rec)

@@ -185,3 +185,35 @@ def test_drop_in_functions_keep_the_reference_behaviour(tmp_path):
     from inverserenderingofindoorscene_amd import unpack_envmaps
     a, l, w = unpack_envmaps(torch.from_numpy(got["env"]).unsqueeze(0), K)
     assert tuple(a.shape) == (1, K, 3, R, C) and tuple(l.shape) == (1, K, R, C) and tuple(w.shape) == (1, 3 * K, R, C)
+
+
+def test_loader_skips_a_candidate_that_cannot_serve(tmp_path):
+    """load_once() stopped at the first candidate that dlopen()ed -- a library without the HDF5 API (here: libm through
+    $SGR_HDF5_LIB, first in the list; in the wild an HDF5 < 1.10 dev package's unversioned libhdf5.so) ended the search and the hand-off was
+    reported unavailable.  Now each candidate is validated, a failing one is closed and the next is tried."""
+    import sys
+    code = ("import ctypes, os, sys\n"
+            f"sys.path.insert(0, {ROOT!r})\n"
+            "from inverserenderingofindoorscene_amd import handoff as H\n"
+            "lib = H._load()\n"
+            "v = (ctypes.c_uint * 3)()\n"
+            "ok = lib.sgr_h5_available(v)\n"
+            "print('AVAILABLE', ok, v[0], v[1])\n")
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SGR_HDF5_LIB="libm.so.6"), capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-1500:]
+    assert "AVAILABLE 1 1 " in p.stdout, p.stdout
+
+
+def test_lzf_decoder_rejects_malformed_streams_without_growing():
+    """A truncated literal run, a truncated back reference and a reference before the start of the output: 0, whatever the output size."""
+    lib = H._load()
+    lib.sgr_lzf_decompress.restype = ctypes.c_size_t
+    lib.sgr_lzf_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+    out = ctypes.create_string_buffer(1 << 16)
+    for bad in (bytes([5, 1, 2]), bytes([0x40]), bytes([0x20, 0x10]), bytes([0xE0, 0x01])):
+        buf = ctypes.create_string_buffer(bad, len(bad))
+        assert lib.sgr_lzf_decompress(buf, len(bad), out, len(out)) == 0, bad
+    good = bytes([2, 65, 66, 67, 0x20, 0x02])                # literal "ABC", then a 3-byte reference back over it
+    buf = ctypes.create_string_buffer(good, len(good))
+    assert lib.sgr_lzf_decompress(buf, len(good), out, len(out)) == 6 and out.raw[:6] == b"ABCABC"
+    assert lib.sgr_lzf_decompress(buf, len(good), out, 4) == 0          # output too small: also 0 through the public entry point
