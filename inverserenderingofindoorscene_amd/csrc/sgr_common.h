@@ -296,15 +296,18 @@ constexpr int kPx = 32;
 constexpr int kT32Floats = 3 * kPx * 16;
 template <int AUX = SGR_DMA_AUX>
 __device__ __forceinline__ void tile32_dma_issue(float* tile, __amdgpu_buffer_rsrc_t rsrc, int p0, int RC, int J, int j0, int lane) {
+  // Rows lrow and 16 + lrow carry the same swizzle ((row >> 2) & 3 is unchanged by + 16), so the second request's lane offset is the
+  // first's + 16 rows: ONE lane-offset register, the 16 rows ride in the wave-uniform offset.  Round 6: as two registers the pair was what
+  // the objective's backward kernel spilled -- and reloaded from scratch in front of every row's requests, where the reload's
+  // s_waitcnt vmcnt(0) also waited for the three requests just issued (a full memory latency per row and wave: 4-6 % of that kernel).
   const int lrow = lane >> 2, slot = lane & 3;
+  const int col4 = slot ^ ((lrow >> 2) & 3);
+  const int voff = (lrow * J + col4 * 4) * 4;                            // the lane's byte offset (32-bit)
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
-    const int row = it * 16 + lrow;
-    const int col4 = slot ^ ((row >> 2) & 3);
-    const int voff = (row * J + col4 * 4) * 4;                           // the lane's byte offset (32-bit)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const int soff = (int)((((size_t)c * RC + p0) * J + j0) * 4);      // wave-uniform byte offset
+      const int soff = (int)((((size_t)c * RC + p0 + it * 16) * J + j0) * 4);      // wave-uniform byte offset
       float* dst = tile + (c * kPx + it * 16) * 16;                      // wave-uniform, + lane*16 B implicitly
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)dst, 16, voff, soff, 0, AUX);
     }

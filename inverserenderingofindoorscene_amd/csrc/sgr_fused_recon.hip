@@ -115,9 +115,16 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
   const int nvr = a.eh * Q;
 
   __amdgpu_buffer_rsrc_t gimg = env_rsrc(a.env_gt + (size_t)b * 3 * RC * a.J, RC, a.J);
+  // Round 6 (the review's ISA finding, tools/loop_scratch.py): at 256 VGPRs the requests' lane offsets were spilled and RELOADED FROM SCRATCH in
+  // front of every row's requests -- scratch loads count in vmcnt like the LDS-DMA requests, so the reload's s_waitcnt vmcnt(0) between the
+  // two halves of the burst waited for the three requests just issued: a full memory latency per row and wave (base vs the loop without those
+  // reloads, kbench: 314-324 vs 304-310 us).  The lane id now comes from v_mbcnt each time (a one-wave workgroup: lane == threadIdx.x; asm
+  // volatile, so that it is not hoisted and spilled again) and the offset is re-formed from it: 7 VALU instructions per row, no live register.
   auto issue = [&](float* dst, int vr) {
-    if constexpr (NG == 2) tile32_dma_issue_vrow<SGR_DMA_AUX, EW>(dst, gimg, x.p0, RC, a.J, vr, lane);
-    else tile16_dma_issue_vrow<SGR_DMA_AUX, EW>(dst, gimg, x.p0, RC, a.J, vr, lane);
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    if constexpr (NG == 2) tile32_dma_issue_vrow<SGR_DMA_AUX, EW>(dst, gimg, x.p0, RC, a.J, vr, l);
+    else tile16_dma_issue_vrow<SGR_DMA_AUX, EW>(dst, gimg, x.p0, RC, a.J, vr, l);
   };
   if (!(SGR_ABLATE & 1)) issue(tile, 0);
 
@@ -156,6 +163,20 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
 
   LobesPk<KPW> P;      // axes pre-multiplied by lp = lam * log2e (floored), as in sg_bwd_pk_kernel
   load_lobes_pk<KPW, true, HEADS>(a, b, (unsigned)p, x.active, grp * KPW, P, false);
+  // (az lp) of the lobe pairs is read once per ROW (czr below): parked in lane-private LDS slots (1.5 KB of the 8 KB a wave has left at two
+  // waves per SIMD) instead of six registers -- the compiler's own choice was to spill one pair to scratch and reload it behind the row's
+  // DMA requests (vmcnt(0) again: the decoder-heads instantiation), ds_read counts in lgkmcnt and waits for nothing but itself
+  // -- and lp itself likewise (once per row in czr, once in the epilogue; with the heads as prologue the compiler spilled THAT pair next).
+  // Only where the gradient accumulators make registers scarce: the loss-value-only instantiation (GRADS = false, 97 VGPRs) keeps them.
+  constexpr bool PARK = GRADS;
+  __shared__ __attribute__((aligned(8))) f32x2 az_slots[PARK ? KH : 1][PARK ? kWave : 1];
+  __shared__ __attribute__((aligned(8))) f32x2 lp_slots[PARK ? KH : 1][PARK ? kWave : 1];
+  if constexpr (PARK) {
+#pragma unroll
+    for (int mm = 0; mm < KH; ++mm) { az_slots[mm][lane] = P.azp[mm]; lp_slots[mm][lane] = P.lpp[mm]; }
+  }
+  auto az_of = [&](int mm) -> f32x2 { if constexpr (PARK) return az_slots[mm][lane]; else return P.azp[mm]; };
+  auto lp_of = [&](int mm) -> f32x2 { if constexpr (PARK) return lp_slots[mm][lane]; else return P.lpp[mm]; };
   f32x2 gw0[KPW], gw1[KPW], gw2[KPW], gl[KPW], gz[KPW], gx[KPW], gy[KPW];
 #pragma unroll
   for (int k = 0; k < KPW; ++k) gw0[k] = gw1[k] = gw2[k] = gl[k] = gz[k] = gx[k] = gy[k] = splat2(0.f);
@@ -164,7 +185,7 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
   const PairTable cpt = as_pair_table(a.cols, EW);
   const XTable xt = (XTable)(a.cols + EW);
 
-  auto row_loop = [&](auto ortho_c) {
+  auto row_loop = [&](auto ortho_c, PixLocal& q) {      // q: the caller's frame (the degenerate-frame path brings its own, see below)
     constexpr bool ORTHO = decltype(ortho_c)::value;
     for (int vr = 0; vr < nvr; ++vr) {
       const int e = Q == 1 ? vr : (vr >> 1), aoff = Q == 1 ? 0 : (vr & 1) * NP;      // table row; first azimuth pair of this virtual row
@@ -183,7 +204,7 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
       const float sr = row[0], cr = row[1];
       f32x2 czr[KH];
 #pragma unroll
-      for (int mm = 0; mm < KH; ++mm) czr[mm] = pfma(P.azp[mm], splat2(cr), -P.lpp[mm]);      // lp (az c_e - 1)
+      for (int mm = 0; mm < KH; ++mm) czr[mm] = pfma(az_of(mm), splat2(cr), -lp_of(mm));      // lp (az c_e - 1)
       const RowCtx rc = make_row_ctx(q, row, GRADS);
       OrthoRow orow = make_ortho_row(rc.ro);
 
@@ -343,7 +364,24 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
       }
     }
   };
-  if ((SGR_ABLATE & 64) || ortho) row_loop(std::true_type{}); else row_loop(std::false_type{});      // ablation 64: the degenerate-frame loop compiled out
+  // The degenerate-frame loop (N parallel to up, |N|^2 off 1 by more than 2e-6: a handful of pixels in real data, none in most waves) reads
+  // nine more frame terms than the orthonormal one.  Kept live from the prologue they were what pushed the kernel over 256 VGPRs -- spill
+  // stores in the prologue and reloads in the epilogue of EVERY wave (tools/ablate.sh 64: that loop compiled out = 12 B of scratch and
+  // 304-310 us against 314-324).  Round 6: that path re-derives its frame from memory (the pixel index passes through an opaque asm, so the
+  // loads are not merged with the prologue's), and nothing but the orthonormal path's own terms lives across the branch.
+  if ((SGR_ABLATE & 64) || ortho) {
+    row_loop(std::true_type{}, q);
+  } else {
+    PixLocal q2 = q;
+    if constexpr (GRADS) {
+      Pix x2 = x;
+      asm volatile("" : "+v"(x2.p));
+      float alb2[3];
+      const Frame f2 = load_frame<POOL>(a, x2, alb2);
+      q2 = make_local(f2, a.F0);
+    }
+    row_loop(std::false_type{}, q2);
+  }
 
   // loss partial of the tile: sum_p m_p sum_{c,j} (ln x - ln(gt+off))^2   (each group holds its directions' share)
   {
@@ -363,7 +401,8 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
     for (int k = 0; k < KPW; ++k) {
       const int kk = grp * KPW + k;
       if (kk < K) {
-        const float lpk = (k & 1) ? P.lpp[k / 2].y : P.lpp[k / 2].x;
+        const f32x2 lp2 = lp_of(k / 2);
+        const float lpk = (k & 1) ? lp2.y : lp2.x;
         const float w0 = P.w01[k].x, w1 = P.w01[k].y, w2 = (k & 1) ? P.w2p[k / 2].y : P.w2p[k / 2].x;
         const float lam = fabsf(lpk) <= kLpFloor ? 0.0f : lpk * kLn2;      // the floor stands for lam == 0
         float glk = (gl[k].x + gl[k].y) * frcp(lpk), q0 = gw0[k].x + gw0[k].y, q1 = gw1[k].x + gw1[k].y, q2 = gw2[k].x + gw2[k].y;

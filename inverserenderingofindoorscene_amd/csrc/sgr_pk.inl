@@ -587,15 +587,14 @@ __device__ __forceinline__ void tile32_dma_issue_vrow(float* tile, __amdgpu_buff
   } else {
     const int e = vr >> 1, q = vr & 1;
     const int lrow = lane >> 2, slot = lane & 3;
+    const int ls = slot ^ ((lrow >> 2) & 3);                               // logical 16-byte slot this lane fills (rows lrow and 16 + lrow alike)
+    const int col = 4 * ls + 8 * q + (ls >= 2 ? 8 : 0);                    // slots 0,1: half row 0; slots 2,3: half row 1
+    const int voff = (lrow * J + col) * 4;                                 // one lane offset; the second request's 16 rows are wave-uniform (tile32_dma_issue)
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      const int row = it * 16 + lrow;
-      const int ls = slot ^ ((row >> 2) & 3);                              // logical 16-byte slot this lane fills
-      const int col = 4 * ls + 8 * q + (ls >= 2 ? 8 : 0);                  // slots 0,1: half row 0; slots 2,3: half row 1
-      const int voff = (row * J + col) * 4;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const int soff = (int)((((size_t)c * RC + p0) * J + e * 32) * 4);
+        const int soff = (int)((((size_t)c * RC + p0 + it * 16) * J + e * 32) * 4);
         float* dst = tile + (c * kPx + it * 16) * 16;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)dst, 16, voff, soff, 0, AUX);
       }

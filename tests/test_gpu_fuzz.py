@@ -15,6 +15,15 @@ from conftest import oracle_with_noise, rel_l2, scalar_close, tol2
 pytestmark = pytest.mark.gpu
 SG = ("axis", "lamb", "weight")
 N_CASES = 30
+# Ratio-1 cases (q = 1: the BRDF maps AT the env-grid resolution, unit input normals): every pixel sits on the |N|^2 == 1 side of the two-sided
+# clamp (models.py:467-468) with |N|^2 = 1 +- one ulp, and the GGX denominator ndh^2 (a^2 - 1) + 1 (models.py:499) is then uncertain by
+# eps / a^2 -- 1.4e-3 relative at roughness -0.8 -- in ANY fp32 evaluation.  The reference's own fp32-vs-fp64 error of the specular image on
+# such inputs is 1.78e-4 (reference-made fixture g9_ratio1_unit_normals, 120x160; 4.98e-5 on the pooled fixture g7), and it reaches the
+# objective's gradients through the render-loss cotangent 2 (rendered - im) seg.  The fp32 oracle's own error on the same inputs -- the proxy
+# e_ref of this file -- is ONE sample of that noise and came out at 4e-5 where the kernels' sample was 1.3e-4 (case 16 with F0 = 0.115; the
+# fused and the unfused HIP routes agree to 1e-7 there, each pixel but one within 1e-7).  So for q = 1 the objective's gradient bound has
+# the reference-made yardstick as its floor: max(2 e_proxy, 2 x 1.78e-4); the layer-level quantities keep max(2 e_proxy, 1e-4).
+E_REF_SPEC_RATIO1 = 1.78e-4
 
 
 def _cases():
@@ -96,7 +105,8 @@ def test_random_case_vs_oracle(sgr, c):
         if float(b.norm()) == 0.0:      # every image of the case without a ground-truth env AND no live render pixel: nothing to compare
             assert float(a.abs().max()) == 0.0
             continue
-        assert rel_l2(a, b) <= tol2(rel_l2(b32, b)), (c, "objective g_" + k, rel_l2(a, b), rel_l2(b32, b))
+        bound = tol2(rel_l2(b32, b)) if q > 1 else max(tol2(rel_l2(b32, b)), 2.0 * E_REF_SPEC_RATIO1)
+        assert rel_l2(a, b) <= bound, (c, "objective g_" + k, rel_l2(a, b), rel_l2(b32, b))
     with torch.no_grad():               # the forward-only route (no gradient kernel) returns the same values
         ng = sgr.light_objective(layer, x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], x["im"], x["seg"], x["env_gt"], ind.cuda(), 1.0, 10.0)
     assert abs(ng[0].item() - obj[0].item()) <= 2e-6 * abs(obj[0].item()), (c, ng[0].item(), obj[0].item())
