@@ -345,6 +345,15 @@ def main() -> None:
                 flat["strong16_ms"], flat["strong16_Mpix_per_s"] = round(ms, 4), round(16 * imH * imW / (ms * 1e-3) / 1e6, 1)
                 ws.release()
 
+        # the extension's in-stream all-reduce over N ranks (sgr.enable_native_allreduce: its own RCCL communicator, ncclAllReduce on the
+        # current HIP stream).  OPT-IN (SGR_BENCH_NATIVE_AR=1): the builder's boxes have one GPU, so this route has run with a world of one
+        # only (rccl1_*_native_ms in the N = 1 line, tests/test_gpu_rccl_world1.py) and the driver's scaling run must not depend on it
+        if os.environ.get("SGR_BENCH_NATIVE_AR") == "1" and backend == "nccl":
+            pkg.enable_native_allreduce(group)
+            flat["native_ms_with_loss"] = round(loop_ms(wl.step_with_loss), 4)
+            flat["native_obj_ms"] = round(loop_ms(wl.step_objective), 4)
+            pkg.disable_native_allreduce(group)
+
     # ---- single-process informational legs -------------------------------------------------------------------------------------------------
     cfg3 = cfg5 = rccl1 = None
     if world == 1 and legs:

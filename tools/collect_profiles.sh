@@ -18,3 +18,8 @@ for f in bench_fresh_records; do [ -f $G/$f.txt ] && last $G/$f.txt $P/${T}_$f.j
 [ -f $G/wavetrace_report.txt ] && cp $G/wavetrace_report.txt $P/${T}_wavetrace_report.txt
 cp $G/traffic.json $G/sq.json $P/
 ls $P | grep "^${T}_" | wc -l
+# round 6: the nested detail of the flat contract line, the N > 1 rehearsal lines, the FETCH_SIZE calibration
+for f in bench_detail bench_warmup5_detail bench_fresh_records_detail; do [ -f $G/$f.json ] && cp $G/$f.json $P/${T}_$f.json; done
+for n in 2 4 8; do [ -f $G/rehearsal_n$n.json ] && cp $G/rehearsal_n$n.json $P/${T}_rehearsal_gloo_n$n.json; done
+for f in fetch_calib_timing fetch_calib_counters; do [ -f $G/$f.txt ] && cp $G/$f.txt $P/${T}_$f.txt; done
+ls $P | grep "^${T}_" | wc -l
