@@ -598,13 +598,24 @@ def fit_line(out: dict) -> str:
     return json.dumps(out)
 
 
+def _host_id() -> str:
+    """hostname + boot id: GPU boxes of one pool share a hostname, a boot id they do not"""
+    try:
+        boot = open("/proc/sys/kernel/random/boot_id").read().strip()
+    except OSError:
+        boot = ""
+    return socket.gethostname() + "/" + boot
+
+
 def _write_anchor(key, rec):
+    if os.environ.get("SGR_BENCH_NO_ANCHOR"):      # test runs (three-step loops) must not leave figures a later N > 1 run would quote
+        return
     try:
         try:
             allrec = json.load(open(ANCHOR_FILE))
         except Exception:
             allrec = {}
-        allrec[key] = dict(rec, host=socket.gethostname(), time=time.time())
+        allrec[key] = dict(rec, host=_host_id(), time=time.time())
         with open(ANCHOR_FILE, "w") as fh:
             json.dump(allrec, fh)
     except OSError:
@@ -616,7 +627,7 @@ def _read_anchor(key) -> dict:
     driver runs N = 1, 2, 4, 8 back to back); otherwise nothing -- never a figure from another box."""
     try:
         rec = json.load(open(ANCHOR_FILE)).get(key)
-        if rec and rec.get("host") == socket.gethostname() and time.time() - rec.get("time", 0) < 7200:
+        if rec and rec.get("host") == _host_id() and time.time() - rec.get("time", 0) < 7200:
             return dict(rec, source="N=1 run of this bench on this host, %d s earlier" % int(time.time() - rec["time"]))
     except Exception:
         pass

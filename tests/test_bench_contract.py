@@ -176,6 +176,7 @@ def test_help_goes_to_stdout():
 def test_anchor_file_round_trip(tmp_path, monkeypatch):
     b = _bench()
     monkeypatch.setattr(b, "ANCHOR_FILE", str(tmp_path / "anchor.json"))
+    monkeypatch.delenv("SGR_BENCH_NO_ANCHOR", raising=False)
     assert b._read_anchor("cfg2_b16_env") == {}
     b._write_anchor("cfg2_b16_env", dict(Mpix_with_loss=3050.0, Mpix_layer_only=3200.0))
     a = b._read_anchor("cfg2_b16_env")
@@ -185,3 +186,6 @@ def test_anchor_file_round_trip(tmp_path, monkeypatch):
     rec["cfg2_b16_env"]["host"] = "another-box"
     json.dump(rec, open(b.ANCHOR_FILE, "w"))
     assert b._read_anchor("cfg2_b16_env") == {}       # never a figure from another box
+    monkeypatch.setenv("SGR_BENCH_NO_ANCHOR", "1")
+    b._write_anchor("cfg2_b8_env", dict(Mpix_with_loss=1.0))
+    assert "cfg2_b8_env" not in json.load(open(b.ANCHOR_FILE))

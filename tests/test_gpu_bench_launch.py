@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _run(args, extra_env=None, timeout=850):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SGR_BENCH_NO_ANCHOR="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):      # as the driver starts it: outside torchrun
         env.pop(k, None)
     env.update(extra_env or {})
