@@ -137,6 +137,19 @@ def disable_native_allreduce(group=None) -> None:
         _sg.comm_destroy(handle)
 
 
+def _destroy_native_comms() -> None:
+    for key in list(_NATIVE_COMMS):
+        try:
+            _sg.comm_destroy(_NATIVE_COMMS.pop(key))
+        except Exception:      # interpreter shutdown: the runtime may already be on its way out
+            pass
+
+
+import atexit  # noqa: E402
+
+atexit.register(_destroy_native_comms)      # a caller that forgets disable_native_allreduce() must not leave RCCL communicators to the teardown order
+
+
 def native_allreduce_enabled(group=None) -> bool:
     return _group_key(group) in _NATIVE_COMMS
 

@@ -48,6 +48,33 @@ def test_bench_launches_itself_for_n_gpus_rehearsal(n, tmp_path):
     assert abs(out["value"] - n * 2 * 240 * 320 / (out["ms_per_step"] * 1e-3) / 1e6) <= 0.06 * out["value"]
 
 
+@pytest.mark.timeout(900)
+def test_bench_under_torchrun_the_drivers_n_gt_1_form(tmp_path):
+    """The driver's own N > 1 launch: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus 2 --steps K --warmup W` -- bench.py finds WORLD_SIZE and must NOT launch a second torchrun underneath."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SGR_BENCH_NO_ANCHOR="1", SGR_BENCH_BACKEND="gloo", SGR_BENCH_DETAIL=str(tmp_path / "d.json"))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--reps", "1", "--layer-only", "--batch", "2"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=850)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = check_line_limits(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["n_ranks_seen"] == 2 and out["config"]["rehearsal"]
+    assert "outside torchrun" not in p.stderr          # no self-launch under torchrun
+    # a WORLD_SIZE that contradicts --gpus is refused, not silently accepted
+    cmd[cmd.index("--gpus") + 1] = "4"
+    cmd[cmd.index("--master-port") + 1] = str(port + 1 if port < 65000 else port - 1)
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=850)
+    assert p.returncode != 0 and p.stdout.strip() == "" and "WORLD_SIZE=2" in p.stderr
+
+
 @pytest.mark.timeout(600)
 def test_bench_n2_over_rccl_refuses_a_one_gpu_box_loudly():
     import torch
