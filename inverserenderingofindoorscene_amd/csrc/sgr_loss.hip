@@ -17,6 +17,14 @@ namespace sgr {
 constexpr int kLossThreads = 256;
 static_assert(kLossThreads == kRThreads, "the fold side job of stage A runs on a stage-A workgroup");
 constexpr int kSplit = 16;           // blocks per image (passes over data the previous pass left in cache; 32: no change in the loop)
+#ifndef SGR_LOSS_SPLIT_BC
+#define SGR_LOSS_SPLIT_BC 16         // development knob: workgroups per image of the second and third pass; 64 = one partial per lane, butterfly folds.
+                                     // Round 6 (the review asked for >= 2 resident waves per SIMD here), profiles/r06d_loss_stages_64_workgroups.txt: the three
+                                     // launches 39.3 us against 25.1 (kbench), the with-loss step 0.405-0.407 ms against 0.393-0.399 -- every one of the 4x more
+                                     // workgroups repeats the per-image folds in its prologue.  16 stays (round 3 found the same for 64 and no change for 32).
+#endif
+constexpr int kSplitBC = SGR_LOSS_SPLIT_BC;
+static_assert(kSplitBC == kSplit || kSplitBC == 64, "the second / third pass fold their partials either sequentially (kSplit) or one per lane (64)");
 constexpr int kStreamUnroll = 4;      // elements per thread and round of the streaming passes, all loads issued before the first use
 constexpr int kSplitA = 64;          // blocks per image of the FIRST pass (stage A / diffspec_partial_a): it reads the full-resolution
                                      // image and mask cold from HBM, and a quarter of the blocks left it latency-bound (16.7 us in the
@@ -52,6 +60,27 @@ __device__ __forceinline__ void fold(const float* __restrict__ ws, int b, double
   for (int s = 0; s < kSplit; ++s) {
 #pragma unroll
     for (int i = 0; i < N; ++i) out[i] += (double)ws[((size_t)b * kSplit + s) * N + i];
+  }
+}
+
+// the second pass's partials of image b (2 values each): sequentially (kSplit of them), or -- 64 of them -- one per lane and an xor butterfly
+// in double like fold_a (same bits in every lane of every wave)
+__device__ __forceinline__ void fold_bc(const float* __restrict__ wsB, int b, double (&out)[2]) {
+  if constexpr (kSplitBC == kSplit) {
+    out[0] = out[1] = 0.0;
+    for (int s = 0; s < kSplit; ++s) {
+      out[0] += (double)wsB[((size_t)b * kSplit + s) * 2 + 0];
+      out[1] += (double)wsB[((size_t)b * kSplit + s) * 2 + 1];
+    }
+  } else {
+    const int lane = threadIdx.x & 63;
+    out[0] = (double)wsB[((size_t)b * kSplitBC + lane) * 2 + 0];
+    out[1] = (double)wsB[((size_t)b * kSplitBC + lane) * 2 + 1];
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      out[0] += __shfl_xor(out[0], off, 64);
+      out[1] += __shfl_xor(out[1], off, 64);
+    }
   }
 }
 
@@ -160,7 +189,7 @@ __global__ __launch_bounds__(kLossThreads) void loss_stage_b(const float* __rest
   float cd, cs;
   diffspec_coefs(s5, (float)n, cd, cs);
   float acc[2] = {0.f, 0.f};
-  constexpr int stride = kSplit * kLossThreads;
+  constexpr int stride = kSplitBC * kLossThreads;
   for (int i0 = blockIdx.x * kLossThreads + threadIdx.x; i0 < n; i0 += kStreamUnroll * stride) {      // loads of a round in flight together (see stage A)
     float dv[kStreamUnroll], sv[kStreamUnroll], iv[kStreamUnroll];
 #pragma unroll
@@ -179,8 +208,8 @@ __global__ __launch_bounds__(kLossThreads) void loss_stage_b(const float* __rest
   }
   block_reduce<2>(acc, lds);
   if (threadIdx.x == 0) {
-    wsB[((size_t)b * kSplit + blockIdx.x) * 2 + 0] = acc[0];
-    wsB[((size_t)b * kSplit + blockIdx.x) * 2 + 1] = acc[1];
+    wsB[((size_t)b * kSplitBC + blockIdx.x) * 2 + 0] = acc[0];
+    wsB[((size_t)b * kSplitBC + blockIdx.x) * 2 + 1] = acc[1];
   }
 }
 
@@ -237,7 +266,7 @@ __global__ __launch_bounds__(kLossThreads) void loss_stage_c(const float* __rest
   }
   double sA[6], sB[2];
   fold_a(wsA, b, sA);
-  fold<2>(wsB, b, sB);
+  fold_bc(wsB, b, sB);
   const double s5[5] = {sA[0], sA[1], sA[2], sA[3], sA[4]};
   float cd, cs;
   diffspec_coefs(s5, (float)n, cd, cs);
@@ -248,7 +277,7 @@ __global__ __launch_bounds__(kLossThreads) void loss_stage_c(const float* __rest
     coef[2 * b + 1] = ks;
   }
   float acc[1] = {0.f};
-  constexpr int stride = kSplit * kLossThreads;
+  constexpr int stride = kSplitBC * kLossThreads;
   for (int i0 = blockIdx.x * kLossThreads + threadIdx.x; i0 < n; i0 += kStreamUnroll * stride) {      // loads of a round in flight together (see stage A)
     float dv[kStreamUnroll], sv[kStreamUnroll], iv[kStreamUnroll], gv[kStreamUnroll];
 #pragma unroll
@@ -280,7 +309,7 @@ __global__ __launch_bounds__(kLossThreads) void loss_stage_c(const float* __rest
   // back -- in index order, in double, through a fixed LDS tree: the result does not depend on which workgroup that is.
   const int nparts = (int)(gridDim.x * gridDim.y);
   if (threadIdx.x == 0) {
-    __hip_atomic_store(&wsC[(size_t)b * kSplit + blockIdx.x], acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&wsC[(size_t)b * kSplitBC + blockIdx.x], acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // RELEASE on the ticket: this workgroup's partial is visible at agent scope before its ticket is; the RMWs of the other
     // workgroups continue the release sequence, so the ACQUIRE fence of the last arrival synchronises with every one of them
     // (round 3 relied on the write-through store being counted in vmcnt -- true on gfx950, a data race in the memory model)
@@ -400,7 +429,7 @@ __global__ __launch_bounds__(64) void diffspec_finish(const float* __restrict__ 
   const int b = blockIdx.x;      // one wave per image (fold_a is lane-cooperative)
   double sA[6], sB[2];
   fold_a(wsA, b, sA);
-  fold<2>(wsB, b, sB);
+  fold_bc(wsB, b, sB);
   const double s5[5] = {sA[0], sA[1], sA[2], sA[3], sA[4]};
   float cd, cs;
   diffspec_coefs(s5, (float)n, cd, cs);
@@ -415,7 +444,7 @@ __global__ __launch_bounds__(64) void diffspec_finish(const float* __restrict__ 
 
 using namespace sgr;
 
-extern "C" int sgr_loss_workspace_floats(int bn) { return bn * (kSplitA * 6 + kSplit * (2 + 1)) + 1; }      // + the arrival counter
+extern "C" int sgr_loss_workspace_floats(int bn) { return bn * (kSplitA * 6 + (kSplitBC > kSplit ? kSplitBC : kSplit) * (2 + 1)) + 1; }      // + the arrival counter
 
 // the three passes; shared with sgr_light_objective_fwd (sgr_fused_recon.hip), which hands the env-statistics fold to the first one
 int sgr::render_loss_fwd_launch(const float* diffuse, const float* spec, const float* im, const float* seg, float* im_small, float* seg_small,
@@ -431,9 +460,9 @@ int sgr::render_loss_fwd_launch(const float* diffuse, const float* spec, const f
   const hipStream_t st = (hipStream_t)stream;
   float* wsA = workspace;
   float* wsB = wsA + (size_t)bn * kSplitA * 6;
-  float* wsC = wsB + (size_t)bn * kSplit * 2;
-  unsigned* ticket = reinterpret_cast<unsigned*>(wsC + (size_t)bn * kSplit);
-  const dim3 grid(kSplit, bn), block(kLossThreads);
+  float* wsC = wsB + (size_t)bn * kSplitBC * 2;
+  unsigned* ticket = reinterpret_cast<unsigned*>(wsC + (size_t)bn * kSplitBC);
+  const dim3 grid(kSplitBC, bn), block(kLossThreads);
   const int RC = R * C;
   const dim3 grid_a(kSplitA + (job.ws ? 1 : 0), bn);
   if (imH == R)
@@ -519,7 +548,7 @@ extern "C" int sgr_lsregress_diffspec_coef(const float* diffuse, const float* sp
   const hipStream_t st = (hipStream_t)stream;
   float* wsA = workspace;
   float* wsB = wsA + (size_t)bn * kSplitA * 6;
-  const dim3 grid(kSplit, bn), block(kLossThreads);
+  const dim3 grid(kSplitBC, bn), block(kLossThreads);
   hipLaunchKernelGGL(diffspec_partial_a, dim3(kSplitA, bn), block, 0, st, diffuse, spec, im, wsA, n);
   hipLaunchKernelGGL(loss_stage_b, grid, block, 0, st, diffuse, spec, im, wsA, wsB, n);
   hipLaunchKernelGGL(diffspec_finish, dim3(bn), dim3(64), 0, st, wsA, wsB, coef, n);
