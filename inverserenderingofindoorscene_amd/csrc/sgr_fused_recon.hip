@@ -30,8 +30,8 @@
 namespace sgr {
 
 // ---- the pass in azimuth pairs (sgr_pk.inl): v_pk_fma_f32 over the directions (e, a), (e, a+1) ----
-// Per azimuth pair and lobe: 8 packed instructions + 4 v_exp for the exponentials and the partial radiance, 23 packed for the
-// gradient accumulation (the exponentials are kept, u / t are re-formed: registers); per pair 6 swaps + 3 packed adds for the
+// Per azimuth pair and lobe: 10 packed instructions + 4 v_exp for the exponentials and the partial radiance, 18 packed for the
+// gradient accumulation (the exponentials are kept; round 6: no sum T t, see sharpness_grad); per pair 6 swaps + 3 packed adds for the
 // radiance, 6 v_rcp + 6 v_log for loss and cotangent, 6 swaps to hand the cotangents round.
 //
 // Round 3: EW = 32 walks a table row as two virtual rows of 8 + 8 directions (tile32_dma_issue_vrow, as sg_bwd_pk_kernel), and
@@ -177,9 +177,9 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
   }
   auto az_of = [&](int mm) -> f32x2 { if constexpr (PARK) return az_slots[mm][lane]; else return P.azp[mm]; };
   auto lp_of = [&](int mm) -> f32x2 { if constexpr (PARK) return lp_slots[mm][lane]; else return P.lpp[mm]; };
-  f32x2 gw0[KPW], gw1[KPW], gw2[KPW], gl[KPW], gz[KPW], gx[KPW], gy[KPW];
+  f32x2 gw0[KPW], gw1[KPW], gw2[KPW], gz[KPW], gx[KPW], gy[KPW];
 #pragma unroll
-  for (int k = 0; k < KPW; ++k) gw0[k] = gw1[k] = gw2[k] = gl[k] = gz[k] = gx[k] = gy[k] = splat2(0.f);
+  for (int k = 0; k < KPW; ++k) gw0[k] = gw1[k] = gw2[k] = gz[k] = gx[k] = gy[k] = splat2(0.f);
 
   const SepTable rows = as_sep_table(a.rows);
   const PairTable cpt = as_pair_table(a.cols, EW);
@@ -346,16 +346,15 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
         if constexpr (GRADS) {
 #pragma unroll
         for (int k = 0; k < KPW; ++k) {
-          const f32x2 cz = half_of(czr[k / 2], k & 1), w2 = half_of(P.w2p[k / 2], k & 1);
-          const f32x2 u = pfma(SGR_HI(P.axy[k]), sa, SGR_LO(P.axy[k]) * ca);
-          const f32x2 tp = pfma(srv, u, cz), tm = pfma(-srv, u, cz);      // lp t: gl accumulates lp sum T t
+          // (round 6: no sum T t accumulator -- dL/dlam = a . S - w . q in the epilogue, sgr_pk.inl: sharpness_grad -- so u and lp t are
+          // not needed here and T enters through its sum and difference alone: 18 packed instructions per lobe)
+          const f32x2 w2 = half_of(P.w2p[k / 2], k & 1);
           gw0[k] = pfma(g[0][0], ep[k], gw0[k]); gw1[k] = pfma(g[0][1], ep[k], gw1[k]); gw2[k] = pfma(g[0][2], ep[k], gw2[k]);
           gw0[k] = pfma(g[1][0], em[k], gw0[k]); gw1[k] = pfma(g[1][1], em[k], gw1[k]); gw2[k] = pfma(g[1][2], em[k], gw2[k]);
-          const f32x2 Tp = pfma(g[0][2], w2, pfma(g[0][1], SGR_HI(P.w01[k]), g[0][0] * SGR_LO(P.w01[k]))) * ep[k];
-          const f32x2 Tm = pfma(g[1][2], w2, pfma(g[1][1], SGR_HI(P.w01[k]), g[1][0] * SGR_LO(P.w01[k]))) * em[k];
-          gl[k] = pfma(Tp, tp, gl[k]);
-          gl[k] = pfma(Tm, tm, gl[k]);
-          const f32x2 Ts = Tp + Tm, Td = Tp - Tm;
+          const f32x2 Sp = pfma(g[0][2], w2, pfma(g[0][1], SGR_HI(P.w01[k]), g[0][0] * SGR_LO(P.w01[k])));
+          const f32x2 Sm = pfma(g[1][2], w2, pfma(g[1][1], SGR_HI(P.w01[k]), g[1][0] * SGR_LO(P.w01[k])));
+          const f32x2 Tm = Sm * em[k];
+          const f32x2 Ts = pfma(Sp, ep[k], Tm), Td = pfma(Sp, ep[k], -Tm);
           gz[k] = pfma(splat2(cr), Ts, gz[k]);
           gx[k] = pfma(sca, Td, gx[k]);
           gy[k] = pfma(ssa, Td, gy[k]);
@@ -405,12 +404,15 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
         const float lpk = (k & 1) ? lp2.y : lp2.x;
         const float w0 = P.w01[k].x, w1 = P.w01[k].y, w2 = (k & 1) ? P.w2p[k / 2].y : P.w2p[k / 2].x;
         const float lam = fabsf(lpk) <= kLpFloor ? 0.0f : lpk * kLn2;      // the floor stands for lam == 0
-        float glk = (gl[k].x + gl[k].y) * frcp(lpk), q0 = gw0[k].x + gw0[k].y, q1 = gw1[k].x + gw1[k].y, q2 = gw2[k].x + gw2[k].y;
+        float q0 = gw0[k].x + gw0[k].y, q1 = gw1[k].x + gw1[k].y, q2 = gw2[k].x + gw2[k].y;
+        const float sx = gx[k].x + gx[k].y, sy = gy[k].x + gy[k].y, sz = gz[k].x + gz[k].y;
+        const f32x2 az2 = az_of(k / 2);
+        float glk = sharpness_grad(P.axy[k].x, P.axy[k].y, (k & 1) ? az2.y : az2.x, lpk, sx, sy, sz, w0, w1, w2, q0, q1, q2);
         if (HEADS || a.premap) {
           glk *= premap_grad(lam);
           q0 *= premap_grad(w0); q1 *= premap_grad(w1); q2 *= premap_grad(w2);
         }
-        float gax = lam * (gx[k].x + gx[k].y), gay = lam * (gy[k].x + gy[k].y), gaz = lam * (gz[k].x + gz[k].y);
+        float gax = lam * sx, gay = lam * sy, gaz = lam * sz;
         if (HEADS)      // decoder heads as a prologue: their chain rule as the epilogue
           heads_bwd_lobe(reinterpret_cast<const char*>(a.axis + (size_t)b * K * 3 * RC) + (size_t)k * 3 * RC * 4,
                          reinterpret_cast<const char*>(a.lamb + (size_t)b * K * RC) + (size_t)k * RC * 4,

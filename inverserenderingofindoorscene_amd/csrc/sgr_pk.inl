@@ -224,6 +224,23 @@ __device__ __forceinline__ void heads_bwd_lobe(const char* xa, const char* xl, c
 // 1e-9-sized cotangents of a normalised training loss (1e-30, the first choice, did not: ADVICE round 2)
 constexpr float kLpFloor = 9.094947017729282e-13f;
 
+// dL/dlam of a lobe WITHOUT a per-direction accumulator (round 6).  With T_j = (g_j . w) E_j and t_j = a . l_j - 1:
+//     dL/dlam = sum_j T_j t_j = a . (sum_j T_j l_j) - sum_j T_j = a . S - w . q,
+// where S = (sum T s_e ca, sum T s_e sa, sum T c_e) are the axis accumulators the kernels carry anyway (dL/da = lam S) and
+// q_c = sum_j g_cj E_j the intensity gradients (sum_j T_j = sum_c w_c q_c).  The backward loops therefore need T only through
+// T+ + T- and T+ - T- -- three packed instructions per lobe and azimuth pair (T-, then two FMAs) instead of four plus two for sum T t:
+// 231 -> 213 VALU instructions per azimuth pair in the layer's backward (254 -> 228 VGPRs), 308 -> 290 in the objective's, whose
+// exponents lp t no longer stay live through its gradient half.  The difference cancels by a factor ~1 / mean|t| (up to ~100 for the sharpest
+// lobes on the 8x16 grid), so the four-term sum is formed in double; measured on 20 000 random lobes (lam = tan(pi/2 0.999 U[0,1]),
+// signed and unsigned cotangents, weighted by the pre-map's 1 + lam^2): 3e-6 .. 9e-6 rel-L2 against 0.5e-6 .. 1.6e-6 for the
+// direct sum -- an order below the kernels' other fp32 error (3e-5 .. 8e-5).  `afx, afy, afz, lp`: the FOLDED axis (lp a) and lp.
+__device__ __forceinline__ float sharpness_grad(float afx, float afy, float afz, float lp, float sx, float sy, float sz, float w0, float w1, float w2,
+                                                float q0, float q1, float q2) {
+  const double aS = (double)afx * (double)sx + (double)afy * (double)sy + (double)afz * (double)sz;      // lp (a . S)
+  const double wq = (double)w0 * (double)q0 + (double)w1 * (double)q1 + (double)w2 * (double)q2;
+  return (float)(aS - (double)lp * wq) * frcp(lp);
+}
+
 // Loads (and pre-maps) the lobes straight into pairs; same two-pass structure as load_lobes (sgr_fast.inl): every load
 // of every lobe is in flight before the pre-map consumes any.  `kg` = first lobe (may differ between the two halves of
 // a wave, so the lobe planes are addressed by 32-bit per-lane offsets into the image's SG block); lobes past K re-read
@@ -1057,9 +1074,9 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
   LobesPk<KPW> P;
   load_lobes_pk<KPW, true, HEADS>(a, b, (unsigned)p, x.active, grp * 2 * KPW + half * KPW, P, false);
 
-  f32x2 gw0[KPW], gw1[KPW], gw2[KPW], gl[KPW], gz[KPW], gx[KPW], gy[KPW];
+  f32x2 gw0[KPW], gw1[KPW], gw2[KPW], gz[KPW], gx[KPW], gy[KPW];
 #pragma unroll
-  for (int k = 0; k < KPW; ++k) gw0[k] = gw1[k] = gw2[k] = gl[k] = gz[k] = gx[k] = gy[k] = splat2(0.f);
+  for (int k = 0; k < KPW; ++k) gw0[k] = gw1[k] = gw2[k] = gz[k] = gx[k] = gy[k] = splat2(0.f);
 
   const SepTable rows = as_sep_table(a.rows);
   const PairTable cpt = as_pair_table(a.cols, EW);
@@ -1153,11 +1170,11 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
           const f32x2 ep = {fexp2(tp.x), fexp2(tp.y)}, em = {fexp2(tm.x), fexp2(tm.y)};
           gw0[k] = pfma(g[0][0], ep, gw0[k]); gw1[k] = pfma(g[0][1], ep, gw1[k]); gw2[k] = pfma(g[0][2], ep, gw2[k]);
           gw0[k] = pfma(g[1][0], em, gw0[k]); gw1[k] = pfma(g[1][1], em, gw1[k]); gw2[k] = pfma(g[1][2], em, gw2[k]);
-          const f32x2 Tp = pfma(g[0][2], w2, pfma(g[0][1], SGR_HI(P.w01[k]), g[0][0] * SGR_LO(P.w01[k]))) * ep;
-          const f32x2 Tm = pfma(g[1][2], w2, pfma(g[1][1], SGR_HI(P.w01[k]), g[1][0] * SGR_LO(P.w01[k]))) * em;
-          gl[k] = pfma(Tp, tp, gl[k]);
-          gl[k] = pfma(Tm, tm, gl[k]);
-          const f32x2 Ts = Tp + Tm, Td = Tp - Tm;
+          // T+- = (g . w) E+-  enter through their sum and difference alone (no sum T t: see the epilogue) -- 3 packed instructions
+          const f32x2 Sp = pfma(g[0][2], w2, pfma(g[0][1], SGR_HI(P.w01[k]), g[0][0] * SGR_LO(P.w01[k])));
+          const f32x2 Sm = pfma(g[1][2], w2, pfma(g[1][1], SGR_HI(P.w01[k]), g[1][0] * SGR_LO(P.w01[k])));
+          const f32x2 Tm = Sm * em;
+          const f32x2 Ts = pfma(Sp, ep, Tm), Td = pfma(Sp, ep, -Tm);
           gz[k] = pfma(splat2(cr), Ts, gz[k]);
           gx[k] = pfma(sca, Td, gx[k]);
           gy[k] = pfma(ssa, Td, gy[k]);
@@ -1185,12 +1202,14 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
         const float lpk = (k & 1) ? P.lpp[k / 2].y : P.lpp[k / 2].x;
         const float w0 = P.w01[k].x, w1 = P.w01[k].y, w2 = (k & 1) ? P.w2p[k / 2].y : P.w2p[k / 2].x;
         const float lam = fabsf(lpk) <= kLpFloor ? 0.0f : lpk * kLn2;      // the floor stands for lam == 0
-        float glk = (gl[k].x + gl[k].y) * frcp(lpk), q0 = gw0[k].x + gw0[k].y, q1 = gw1[k].x + gw1[k].y, q2 = gw2[k].x + gw2[k].y;
+        float q0 = gw0[k].x + gw0[k].y, q1 = gw1[k].x + gw1[k].y, q2 = gw2[k].x + gw2[k].y;
+        const float sx = gx[k].x + gx[k].y, sy = gy[k].x + gy[k].y, sz = gz[k].x + gz[k].y;
+        float glk = sharpness_grad(P.axy[k].x, P.axy[k].y, (k & 1) ? P.azp[k / 2].y : P.azp[k / 2].x, lpk, sx, sy, sz, w0, w1, w2, q0, q1, q2);
         if (HEADS || a.premap) {
           glk *= premap_grad(lam);
           q0 *= premap_grad(w0); q1 *= premap_grad(w1); q2 *= premap_grad(w2);
         }
-        float gax = lam * (gx[k].x + gx[k].y), gay = lam * (gy[k].x + gy[k].y), gaz = lam * (gz[k].x + gz[k].y);
+        float gax = lam * sx, gay = lam * sy, gaz = lam * sz;
         if (HEADS)
           heads_bwd_lobe(reinterpret_cast<const char*>(a.axis + (size_t)b * K * 3 * RC) + (size_t)ks * 3 * RC * 4,
                          reinterpret_cast<const char*>(a.lamb + (size_t)b * K * RC) + (size_t)ks * RC * 4,
