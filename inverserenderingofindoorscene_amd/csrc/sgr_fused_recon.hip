@@ -206,7 +206,7 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
 #pragma unroll
       for (int mm = 0; mm < KH; ++mm) czr[mm] = pfma(az_of(mm), splat2(cr), -lp_of(mm));      // lp (az c_e - 1)
       const RowCtx rc = make_row_ctx(q, row, GRADS);
-      OrthoRow orow = make_ortho_row(rc.ro);
+      OrthoRow orow = make_ortho_row(rc.ro, q.vv);
 
 #pragma unroll 1
       for (int ap = 0; ap < NP; ++ap) {
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
 #pragma unroll
         for (int c = 0; c < 3; ++c) SGR_FENCE2(gds[c]);
         SGR_FENCE2(grec);
-        if (ORTHO) { SGR_FENCE2(oq.vB); SGR_FENCE2(oq.ff); SGR_FENCE2(oq.vvk); SGR_FENCE2(orow.nwc); SGR_FENCE2(orow.cvc); }
+        if (ORTHO) { SGR_FENCE2(oq.vB); SGR_FENCE2(oq.ff); SGR_FENCE2(orow.n2c); SGR_FENCE2(orow.cvc); }
 #endif
         const f32x4 cs = cpt[aoff + ap];
         const f32x2 ca = {cs[0], cs[1]}, sa = {cs[2], cs[3]};
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_recon_pk_kernel(const Args a)
             float dx = v[1][c].x, sx = v[0][c].x, dy = v[1][c].y, sy = v[0][c].y;
             swap32(dx, sx);
             swap32(dy, sy);
-            tot[c] = f32x2{dx + sx, dy + sy};
+            tot[c] = f32x2{dx, dy} + f32x2{sx, sy};      // one v_pk_add_f32
           }
         }
         f32x2 g[2][3];

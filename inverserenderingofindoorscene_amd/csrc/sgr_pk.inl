@@ -358,31 +358,35 @@ __device__ __forceinline__ void fence_lobes(LobesPk<KP>& P) {
 }
 
 // Per-pixel and per-(pixel, table row) constants of the orthonormal microfacet path, in pairs (see brdf_ortho_dir)
-struct OrthoPix { f32x2 vB, ff, vvk; };       // (vBx, vBy), (fb, fa), (vv, -)
-struct OrthoRow { f32x2 nwc, cvc; };          // (nw, rowc), (Cv, c1n2)
+struct OrthoPix { f32x2 vB, ff; };            // (vBx, vBy), (fb, fa)
+struct OrthoRow { f32x2 n2c, cvc; float rowe; };      // (nw^2, rowc), (vv + Cv, c1n2), 4e-6 - nw^2
 __device__ __forceinline__ OrthoPix make_ortho_pix(const PixLocal& q) {
   OrthoPix o;
-  o.vB = f32x2{q.vBx, q.vBy}; o.ff = f32x2{q.fb, q.fa}; o.vvk = f32x2{q.vv, 0.0f};
+  o.vB = f32x2{q.vBx, q.vBy}; o.ff = f32x2{q.fb, q.fa};
   return o;
 }
-__device__ __forceinline__ OrthoRow make_ortho_row(const RowOrtho& r) {
+__device__ __forceinline__ OrthoRow make_ortho_row(const RowOrtho& r, float vv) {
   OrthoRow o;
-  o.nwc = f32x2{r.nw, r.rowc}; o.cvc = f32x2{r.Cv, r.c1n2};
+  const float n2 = r.nw * r.nw;
+  o.n2c = f32x2{n2, r.rowc}; o.cvc = f32x2{vv + r.Cv, r.c1n2}; o.rowe = 4e-6f - n2;
   return o;
 }
 // spec of the directions (ss ca_i, ss sa_i, c_e), i = 0, 1: brdf_ortho_dir (sgr_math.h), two azimuths per instruction.
 // Pv = vBx ca + vBy sa.  `ss` = +-s_e (wave-uniform).
+// Round 6: the clamp |v + l|^2 >= 4e-6 moved onto the azimuth part alone -- with T2c = max(T2, 4e-6 - nw^2) both  max(T2 + nw^2, 4e-6) =
+// T2c + nw^2  and the numerator  T2 + (Hm - hh4) + rowc = T2c + rowc  are one packed add each (the same sums of non-negative terms as
+// brdf_ortho_dir's, three packed instructions fewer), and |v|^2 rides in the row constant of v.l: 26 instructions per pair instead of 29.
 __device__ __forceinline__ f32x2 brdf_ortho_pair(const OrthoPix& q, const OrthoRow& r, float ss, f32x2 ca, f32x2 sa, f32x2 Pv) {
   const f32x2 sv = splat2(ss);
   const f32x2 tx = pfma(sv, ca, SGR_LO(q.vB)), ty = pfma(sv, sa, SGR_HI(q.vB));
   const f32x2 T2 = pfma(tx, tx, ty * ty);
-  const f32x2 hh4 = pfma(SGR_LO(r.nwc), SGR_LO(r.nwc), T2);
-  const f32x2 Hm = {fmaxf(hh4.x, 4e-6f), fmaxf(hh4.y, 4e-6f)};
+  const f32x2 T2c = {fmaxf(T2.x, r.rowe), fmaxf(T2.y, r.rowe)};
+  const f32x2 Hm = T2c + SGR_LO(r.n2c);
   const f32x2 r4 = {frsq(Hm.x), frsq(Hm.y)};
-  const f32x2 vdh = (SGR_LO(q.vvk) + pfma(sv, Pv, SGR_LO(r.cvc))) * r4;
+  const f32x2 vdh = pfma(sv, Pv, SGR_LO(r.cvc)) * r4;
   const f32x2 pa = pfma(splat2(-5.55472f), vdh, splat2(-6.98316f)) * vdh;
   const f32x2 pw = {fexp2(pa.x), fexp2(pa.y)};
-  const f32x2 nom0 = ((T2 + (Hm - hh4)) + SGR_HI(r.nwc)) * (r4 * r4);
+  const f32x2 nom0 = (T2c + SGR_HI(r.n2c)) * (r4 * r4);
   const f32x2 nr = (nom0 * nom0) * SGR_HI(r.cvc);
   const f32x2 rn = {frcp(clampf(nr.x, 1e-6f, kFourPi)), frcp(clampf(nr.y, 1e-6f, kFourPi))};
   return pfma(SGR_LO(q.ff), pw, SGR_HI(q.ff)) * rn;
@@ -467,13 +471,13 @@ __device__ __forceinline__ void fwd_pk_body(const Args& a, int unit, float* tile
 #pragma unroll
       for (int m = 0; m < KP / 2; ++m) Ck[m] = pfma(P.azp[m], splat2(row[1]), -P.lpp[m]);
       const RowCtx rc = make_row_ctx(q, row, DO_RENDER);
-      OrthoRow orow = make_ortho_row(rc.ro);
+      OrthoRow orow = make_ortho_row(rc.ro, q.vv);
 #pragma unroll 1
       for (int aq = 0; aq < NQ; ++aq) {
         fence_lobes<KP>(P);
 #pragma unroll
         for (int m = 0; m < KP / 2; ++m) SGR_FENCE2(Ck[m]);
-        if (DO_RENDER && ORTHO) { SGR_FENCE2(oq.vB); SGR_FENCE2(oq.ff); SGR_FENCE2(oq.vvk); SGR_FENCE2(orow.nwc); SGR_FENCE2(orow.cvc); }
+        if (DO_RENDER && ORTHO) { SGR_FENCE2(oq.vB); SGR_FENCE2(oq.ff); SGR_FENCE2(orow.n2c); SGR_FENCE2(orow.cvc); }
         const f32x4 t0 = cpt[2 * aq], t1 = cpt[2 * aq + 1];
         const f32x2 ca[2] = {f32x2{t0[0], t0[1]}, f32x2{t1[0], t1[1]}}, sa[2] = {f32x2{t0[2], t0[3]}, f32x2{t1[2], t1[3]}};
         f32x2 acc[2][3][2];   // [sign][colour][azimuth pair of the quad]
@@ -685,7 +689,7 @@ __device__ __forceinline__ void fwd_pk_half_body(const Args& a, const Pix x, flo
 #pragma unroll
       for (int m = 0; m < KPW / 2; ++m) Ck[m] = pfma(P.azp[m], splat2(row[1]), -P.lpp[m]);
       const RowCtx rc = make_row_ctx(q, row, DO_RENDER);
-      OrthoRow orow = make_ortho_row(rc.ro);
+      OrthoRow orow = make_ortho_row(rc.ro, q.vv);
 #pragma unroll 1
       for (int aq = 0; aq < NQ; ++aq) {
         const int vr = e * Q + (aq >> 1);               // virtual row of this quad (two quads each)
@@ -702,7 +706,7 @@ __device__ __forceinline__ void fwd_pk_half_body(const Args& a, const Pix x, flo
         fence_lobes<KPW>(P);
 #pragma unroll
         for (int m = 0; m < KPW / 2; ++m) SGR_FENCE2(Ck[m]);
-        if (DO_RENDER && ORTHO) { SGR_FENCE2(oq.vB); SGR_FENCE2(oq.ff); SGR_FENCE2(oq.vvk); SGR_FENCE2(orow.nwc); SGR_FENCE2(orow.cvc); }
+        if (DO_RENDER && ORTHO) { SGR_FENCE2(oq.vB); SGR_FENCE2(oq.ff); SGR_FENCE2(orow.n2c); SGR_FENCE2(orow.cvc); }
         const f32x4 t0 = cpt[2 * aq], t1 = cpt[2 * aq + 1];
         const f32x2 ca[2] = {f32x2{t0[0], t0[1]}, f32x2{t1[0], t1[1]}}, sa[2] = {f32x2{t0[2], t0[3]}, f32x2{t1[2], t1[3]}};
         f32x2 acc[2][3][2];   // [sign][colour][azimuth pair of the quad]: this half's six lobes' share
@@ -737,7 +741,7 @@ __device__ __forceinline__ void fwd_pk_half_body(const Args& a, const Pix x, flo
             float dx = acc[1][c][h].x, sx = acc[0][c][h].x, dy = acc[1][c][h].y, sy = acc[0][c][h].y;
             swap32(dx, sx);
             swap32(dy, sy);
-            tot[c][h] = f32x2{dx + sx, dy + sy};
+            tot[c][h] = f32x2{dx, dy} + f32x2{sx, sy};      // one v_pk_add_f32: the swapped halves stay in their register pairs
           }
         if (DO_RENDER) {
 #pragma unroll
@@ -910,10 +914,10 @@ __global__ __launch_bounds__(kWave, 3) void render_pk_half_kernel(const Args a) 
       }
       if (!ORTHO) fence_row_invariants(q);
       const RowCtx rc = make_row_ctx(q, rows[e], true);
-      OrthoRow orow = make_ortho_row(rc.ro);
+      OrthoRow orow = make_ortho_row(rc.ro, q.vv);
 #pragma unroll 1
       for (int ap = 0; ap < NP; ++ap) {
-        if (ORTHO) { SGR_FENCE2(oq.vB); SGR_FENCE2(oq.ff); SGR_FENCE2(oq.vvk); SGR_FENCE2(orow.nwc); SGR_FENCE2(orow.cvc); }
+        if (ORTHO) { SGR_FENCE2(oq.vB); SGR_FENCE2(oq.ff); SGR_FENCE2(orow.n2c); SGR_FENCE2(orow.cvc); }
         const f32x4 cs = cpt[aoff + ap];
         const f32x2 ca = {cs[0], cs[1]}, sa = {cs[2], cs[3]};
         float g[3][2];
@@ -991,10 +995,10 @@ __global__ __launch_bounds__(kWave, 3) void render_genv_pk_half_kernel(const Arg
     for (int e = 0; e < eh; ++e) {
       if (!ORTHO) fence_row_invariants(q);
       const RowCtx rc = make_row_ctx(q, rows[e], true);
-      OrthoRow orow = make_ortho_row(rc.ro);
+      OrthoRow orow = make_ortho_row(rc.ro, q.vv);
 #pragma unroll 1
       for (int aq = 0; aq < NQ; ++aq) {
-        if (ORTHO) { SGR_FENCE2(oq.vB); SGR_FENCE2(oq.ff); SGR_FENCE2(oq.vvk); SGR_FENCE2(orow.nwc); SGR_FENCE2(orow.cvc); }
+        if (ORTHO) { SGR_FENCE2(oq.vB); SGR_FENCE2(oq.ff); SGR_FENCE2(orow.n2c); SGR_FENCE2(orow.cvc); }
 #pragma unroll
         for (int c = 0; c < 3; ++c) SGR_FENCE2(gds[c]);
         const f32x4 t0 = cpt[2 * aq], t1 = cpt[2 * aq + 1];
@@ -1103,7 +1107,7 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
 #pragma unroll
       for (int m = 0; m < KPW / 2; ++m) czr[m] = pfma(P.azp[m], splat2(cr), -P.lpp[m]);      // lp (az c_e - 1)
       const RowCtx rc = make_row_ctx(q, row, HAS_RENDER);
-      OrthoRow orow = make_ortho_row(rc.ro);
+      OrthoRow orow = make_ortho_row(rc.ro, q.vv);
 
 #pragma unroll 1
       for (int ap = 0; ap < NP; ++ap) {
@@ -1116,7 +1120,7 @@ __global__ __launch_bounds__(kWave, 2) void sg_bwd_pk_kernel(const Args a) {
         if (HAS_RENDER) {
 #pragma unroll
           for (int c = 0; c < 3; ++c) SGR_FENCE2(gds[c]);
-          if (ORTHO) { SGR_FENCE2(oq.vB); SGR_FENCE2(oq.ff); SGR_FENCE2(oq.vvk); SGR_FENCE2(orow.nwc); SGR_FENCE2(orow.cvc); }
+          if (ORTHO) { SGR_FENCE2(oq.vB); SGR_FENCE2(oq.ff); SGR_FENCE2(orow.n2c); SGR_FENCE2(orow.cvc); }
         }
 #endif
         // (round 4, measured and not adopted: this pair's table entries requested one iteration ahead, and the cotangent pairs read behind
