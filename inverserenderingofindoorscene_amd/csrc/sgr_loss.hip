@@ -26,6 +26,12 @@ constexpr int kSplit = 16;           // blocks per image (passes over data the p
 constexpr int kSplitBC = SGR_LOSS_SPLIT_BC;
 static_assert(kSplitBC == kSplit || kSplitBC == 64, "the second / third pass fold their partials either sequentially (kSplit) or one per lane (64)");
 constexpr int kStreamUnroll = 4;      // elements per thread and round of the streaming passes, all loads issued before the first use
+#ifndef SGR_LOSS_UNROLL_BC
+#define SGR_LOSS_UNROLL_BC 16
+#endif
+constexpr int kStreamUnrollBC = SGR_LOSS_UNROLL_BC;      // the second / third pass: 16 workgroups per image leave 14 elements per thread at config 2 -- ONE round of loads
+                                                        // instead of four dependent ones (same elements per thread in the same order: same sums).  Round 6, kbench, the three
+                                                        // launches: 25.1-25.5 -> 23.2 us (profiles/r06k_*); requesting that round BEFORE the per-image folds as well: 24.1-24.2, not kept
 constexpr int kSplitA = 64;          // blocks per image of the FIRST pass (stage A / diffspec_partial_a): it reads the full-resolution
                                      // image and mask cold from HBM, and a quarter of the blocks left it latency-bound (16.7 us in the
                                      // training loop for 32 MB); = lanes of a wave, see fold_a
@@ -190,15 +196,15 @@ __global__ __launch_bounds__(kLossThreads) void loss_stage_b(const float* __rest
   diffspec_coefs(s5, (float)n, cd, cs);
   float acc[2] = {0.f, 0.f};
   constexpr int stride = kSplitBC * kLossThreads;
-  for (int i0 = blockIdx.x * kLossThreads + threadIdx.x; i0 < n; i0 += kStreamUnroll * stride) {      // loads of a round in flight together (see stage A)
-    float dv[kStreamUnroll], sv[kStreamUnroll], iv[kStreamUnroll];
+  for (int i0 = blockIdx.x * kLossThreads + threadIdx.x; i0 < n; i0 += kStreamUnrollBC * stride) {      // loads of a round in flight together (see stage A)
+    float dv[kStreamUnrollBC], sv[kStreamUnrollBC], iv[kStreamUnrollBC];
 #pragma unroll
-    for (int u = 0; u < kStreamUnroll; ++u) {
+    for (int u = 0; u < kStreamUnrollBC; ++u) {
       const size_t o = (size_t)b * n + (i0 + u * stride < n ? i0 + u * stride : i0);
       dv[u] = diffuse[o]; sv[u] = spec[o]; iv[u] = im_s[o];
     }
 #pragma unroll
-    for (int u = 0; u < kStreamUnroll; ++u) {
+    for (int u = 0; u < kStreamUnrollBC; ++u) {
       if (i0 + u * stride < n) {
         const float r = fminf(fmaxf(cd * dv[u] + cs * sv[u], 0.0f), 1.0f);
         acc[0] = fmaf(r, iv[u], acc[0]);
@@ -278,16 +284,16 @@ __global__ __launch_bounds__(kLossThreads) void loss_stage_c(const float* __rest
   }
   float acc[1] = {0.f};
   constexpr int stride = kSplitBC * kLossThreads;
-  for (int i0 = blockIdx.x * kLossThreads + threadIdx.x; i0 < n; i0 += kStreamUnroll * stride) {      // loads of a round in flight together (see stage A)
-    float dv[kStreamUnroll], sv[kStreamUnroll], iv[kStreamUnroll], gv[kStreamUnroll];
+  for (int i0 = blockIdx.x * kLossThreads + threadIdx.x; i0 < n; i0 += kStreamUnrollBC * stride) {      // loads of a round in flight together (see stage A)
+    float dv[kStreamUnrollBC], sv[kStreamUnrollBC], iv[kStreamUnrollBC], gv[kStreamUnrollBC];
 #pragma unroll
-    for (int u = 0; u < kStreamUnroll; ++u) {
+    for (int u = 0; u < kStreamUnrollBC; ++u) {
       const int i = i0 + u * stride < n ? i0 + u * stride : i0;
       const size_t o = (size_t)b * n + i;
       dv[u] = diffuse[o]; sv[u] = spec[o]; iv[u] = im_s[o]; gv[u] = seg_s[(size_t)b * RC + i % RC];
     }
 #pragma unroll
-    for (int u = 0; u < kStreamUnroll; ++u) {
+    for (int u = 0; u < kStreamUnrollBC; ++u) {
       if (i0 + u * stride < n) {
         const size_t o = (size_t)b * n + i0 + u * stride;
         const float raw = kd * dv[u] + ks * sv[u];
