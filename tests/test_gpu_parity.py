@@ -398,3 +398,50 @@ def test_zero_sharpness_lobes(sgr):
         assert torch.isfinite(a).all(), k
         assert rel_l2(a.cpu(), b) <= tol2(rel_l2(b32, b)), (k, rel_l2(a.cpu(), b), rel_l2(b32, b))
     assert float(g2[0][:, 0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("lo", [0.9, 0.99], ids=["lam_6_to_636", "lam_64_to_636"])
+def test_sharp_lobes_sharpness_gradient(sgr, lo):
+    """Round 6: the backward kernels form dL/dlam as  a . S - w . q  in the epilogue (csrc/sgr_pk.inl: sharpness_grad) instead of summing
+    T t per direction -- a difference that cancels by ~1 / mean|a . l - 1|, i.e. worst for the sharpest lobes.  Here EVERY lobe is sharp
+    (decoder output in [lo, 1): lam = tan(pi/2 0.999 x) from 6.3 or 64 up to the pre-map's maximum 636), fused layer and fused objective,
+    against the fp64 oracle at the usual bound max(2 e_ref, 1e-4) with e_ref = the fp32 oracle's own error on these inputs."""
+    from oracle import sg_oracle as O
+    bn, imH, imW, R, C, K, eh, ew = 2, 24, 32, 12, 16, 12, 8, 16
+    inp = O.synthetic_inputs(bn, imH, imW, R, C, K, eh, ew, seed=606)
+    g0 = torch.Generator().manual_seed(17)
+    inp["lamb"] = lo + (0.99999 - lo) * torch.rand(inp["lamb"].shape, generator=g0)
+    x = {k: v.cuda() for k, v in inp.items()}
+    xo = {k: v.double() for k, v in inp.items()}
+    for k in ("axis", "lamb", "weight"):
+        x[k].requires_grad_(True)
+        xo[k].requires_grad_(True)
+    layer = sgr.renderingLayer(imWidth=C, imHeight=R, envWidth=ew, envHeight=eh)
+    env, d, s = layer.forwardSG(x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], need_env=True)
+    eo, do, so = O.render_from_sg(xo["albedo"], xo["normal"], xo["rough"], xo["axis"], xo["lamb"], xo["weight"], eh, ew)
+    g = torch.Generator().manual_seed(3)
+    ct = [torch.randn(t.shape, generator=g) for t in (env, d, s)]
+    gr = torch.autograd.grad([env, d, s], [x[k] for k in ("axis", "lamb", "weight")], grad_outputs=[t.cuda() for t in ct])
+    go = torch.autograd.grad([eo, do, so], [xo[k] for k in ("axis", "lamb", "weight")], grad_outputs=[t.double() for t in ct], retain_graph=True)
+    _, _, e32 = oracle_with_noise(O, inp, ct, eh, ew, ("axis", "lamb", "weight"), "cuda")
+    for k, a, b in zip(("axis", "lamb", "weight"), gr, go):
+        assert torch.isfinite(a).all(), k
+        assert rel_l2(a.cpu(), b) <= tol2(e32["g_" + k]), ("layer", k, rel_l2(a.cpu(), b), e32["g_" + k])
+    print(f"sharp lobes (x >= {lo}): layer sharpness-gradient error {rel_l2(gr[1].cpu(), go[1]):.2e} (fp32 oracle's own {e32['g_lamb']:.2e})", end=" ")
+    ind = torch.ones(bn, 1, 1, 1)
+    obj = sgr.light_objective(layer, x["albedo"], x["normal"], x["rough"], x["axis"], x["lamb"], x["weight"], x["im"], x["seg"],
+                              x["env_gt"], ind.cuda(), 1.0, 10.0)
+    g2 = torch.autograd.grad(obj[0], [x[k] for k in ("axis", "lamb", "weight")])
+    ro, _, _, _ = O.render_loss(do, so, xo["im"], xo["seg"], R, C)
+    co, _, _, _ = O.recon_loss(eo, xo["env_gt"], xo["seg"], ind.double(), R, C)
+    g3 = torch.autograd.grad(ro + 10.0 * co, [xo[k] for k in ("axis", "lamb", "weight")])
+    x32 = {k: v.clone() for k, v in inp.items()}
+    for k in ("axis", "lamb", "weight"):
+        x32[k].requires_grad_(True)
+    e32_, d32_, s32_ = O.render_from_sg(x32["albedo"], x32["normal"], x32["rough"], x32["axis"], x32["lamb"], x32["weight"], eh, ew)
+    g3_32 = torch.autograd.grad(O.render_loss(d32_, s32_, x32["im"], x32["seg"], R, C)[0] + 10.0 * O.recon_loss(e32_, x32["env_gt"], x32["seg"], ind, R, C)[0],
+                                [x32[k] for k in ("axis", "lamb", "weight")])
+    for k, a, b, b32 in zip(("axis", "lamb", "weight"), g2, g3, g3_32):
+        assert torch.isfinite(a).all(), k
+        assert rel_l2(a.cpu(), b) <= tol2(rel_l2(b32, b)), ("objective", k, rel_l2(a.cpu(), b), rel_l2(b32, b))
+    print(f"objective {rel_l2(g2[1].cpu(), g3[1]):.2e} ({rel_l2(g3_32[1], g3[1]):.2e})")
