@@ -65,7 +65,7 @@ def main():
             c3, _, _, _ = O.recon_loss(e3, x32["env_gt"], x32["seg"], ind.float(), R, C)
             o32 = torch.autograd.grad(r3 + 10.0 * c3, [x32["axis"], x32["lamb"], x32["weight"]])
             y = dict(env=rel(e3, eo), d=rel(d3, do), s=rel(s3, so), **{f"g{i}": rel(a, b) for i, (a, b) in enumerate(zip(g32, go))},
-                     render=abs(r3.item() - ro.item()) / abs(ro.item()), recon=abs(c3.item() - co.item()) / abs(co.item()),
+                     render=abs(r3.item() - ro.item()) / max(1e-12, abs(ro.item())), recon=abs(c3.item() - co.item()) / max(1e-12, abs(co.item())),
                      **{f"o{i}": rel(a, b) for i, (a, b) in enumerate(zip(o32, g3))})
             print(f"   case {case}: " + "  ".join(f"{k} {v:.1e} (fp32 oracle {y.get(k, float('nan')):.1e})" for k, v in errs.items()))
         ok = worst < 5e-4 and all(torch.isfinite(t).all() for t in list(gr) + list(go2))
